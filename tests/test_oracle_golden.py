@@ -1,0 +1,133 @@
+"""CPU: the oracle restatement against the fixtures the reference produced
+(tools/gen_golden.py).  This is what pins the oracle."""
+import torch
+
+from oracle import infodiff_oracle as O
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_schedule_bit_exact(gold):
+    g = gold('schedule')
+    for T in (100, 1000):
+        b, al, ab, apb = O.noise_schedule(1e-5, 1e-2, T)
+        assert torch.equal(b, g['betas_%d' % T])
+        assert torch.equal(ab, g['alpha_bars_%d' % T])
+        assert torch.equal(apb, g['alpha_prev_bars_%d' % T])
+        tab = O.sinusoid_table(T, 64)
+        assert torch.equal(tab[g['table_rows_%d' % T]], g['table_%d' % T])
+    assert torch.equal(O.timestep_embedding(g['tse_t'], 64), g['tse'])
+
+
+def test_mmd(gold):
+    g = gold('mmd')
+    for tag in ('b32d32', 'b32d256', 'b7d5'):
+        y = g[tag + '.y'].clone().requires_grad_(True)
+        v = O.compute_mmd(g[tag + '.x'], y)
+        v.backward()
+        assert rel(v.detach(), g[tag + '.v']) < 1e-5
+        assert rel(y.grad, g[tag + '.gy']) < 1e-4
+
+
+def _sd(man, tag):
+    return {('.' + k): O.synth_tensor(k, s) for k, s in man[tag]}
+
+
+def test_blocks(gold, manifest):
+    g, man = gold('blocks'), manifest('blocks_manifest')
+    temb, aemb, nod = g['temb'], g['aemb'], O.Drop(None)
+    fns = {
+        'aux64': lambda sd, x: O.aux_res_block(sd, '', x, temb, aemb, False, nod),
+        'aux192_64': lambda sd, x: O.aux_res_block(sd, '', x, temb, aemb, False, nod),
+        'aux128_attn': lambda sd, x: O.aux_res_block(sd, '', x, temb, aemb, True, nod),
+        'enc64_128': lambda sd, x: O.res_block_encoder(sd, '', x, False, nod),
+        'res64': lambda sd, x: O.res_block(sd, '', x, temb, False, nod),
+        'attn128': lambda sd, x: O.attn_block(sd, '', x),
+        'down64': lambda sd, x: O.down_sample(sd, '', x),
+        'up64': lambda sd, x: O.up_sample(sd, '', x),
+    }
+    for tag, fn in fns.items():
+        sd = _sd(man, tag)
+        x = g[tag + '.x'].clone().requires_grad_(True)
+        y = fn(sd, x)
+        (y * g[tag + '.gy']).sum().backward()
+        assert rel(y.detach(), g[tag + '.y']) < 1e-5, tag
+        assert rel(x.grad, g[tag + '.gx']) < 1e-4, tag
+
+
+def _model_case(gold, manifest, tag, cfg):
+    g = gold('model_' + tag)
+    sd = O.synth_state_dict(manifest('manifest_' + tag))
+    sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+    with torch.no_grad():
+        loss, terms = O.infodiff_loss(sd, cfg, g['x'], g['idx'], g['eps'], sched, prior=g['prior'],
+                                      reparam_noise=g['reparam'])
+    assert torch.equal(terms['x_tilde'], g['x_tilde'])
+    assert rel(terms['out'], g['out']) < 2e-5
+    assert rel(terms['a'], g['a']) < 2e-5
+    assert rel(loss, g['loss']) < 1e-5
+    with torch.no_grad():
+        e = O.infodiff_eps(sd, cfg, g['samp_x'], 17, g['samp_a'])
+    assert rel(e, g['samp_eps17']) < 2e-5
+    # samplers with the real model on a 4-step schedule
+    for key, det in (('ddim', True), ('ddpm', False)):
+        cfg_s = O.Cfg(**{**cfg.__dict__, 'diffusion_steps': 4, 'deterministic': det})
+        sd_s = dict(sd)
+        sd_s['backbone.time_embedding.timembedding.0.weight'] = O.sinusoid_table(4, cfg.unets_channels)
+        sched_s = O.noise_schedule(cfg.beta1, cfg.betaT, 4)
+        a2 = g[key + '.a']
+        noises = {3: g[key + '.noise'][0], 2: g[key + '.noise'][1], 1: g[key + '.noise'][2]}
+        with torch.no_grad():
+            tr = O.sample_loop(sched_s, lambda xx, i: O.infodiff_eps(sd_s, cfg_s, xx, i, a2),
+                               g[key + '.xT'], det, noises)
+        for k in range(4):
+            assert rel(tr[k], g[key + '.trace'][k]) < 5e-5, (key, k)
+
+
+def test_model_fmnist(gold, manifest):
+    _model_case(gold, manifest, 'fmnist', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1))
+
+
+def test_model_fmnist_kld(gold, manifest):
+    _model_case(gold, manifest, 'fmnist_kld',
+                O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01))
+
+
+def test_model_celeba(gold, manifest):
+    _model_case(gold, manifest, 'celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1))
+
+
+def test_sampler_stub(gold):
+    g = gold('sampler_stub')
+    fn = lambda x, i: 0.1 * x + 0.01 * i
+    for T in (4, 10):
+        sched = O.noise_schedule(1e-5, 1e-2, T)
+        for key, det in (('ddim', True), ('ddpm', False)):
+            tag = 'T%d_%s' % (T, key)
+            nz = g[tag + '.noise']
+            noises = {i: nz[k] for k, i in enumerate(reversed(range(1, T)))}
+            tr = O.sample_loop(sched, fn, g[tag + '.xT'], det, noises)
+            assert rel(torch.stack(tr), g[tag + '.trace']) < 1e-6
+            if det:
+                ro = O.reverse_sample_loop(sched, fn, g[tag + '.xT'])
+                assert rel(torch.stack(ro), g[tag + '.rev_trace']) < 1e-6
+
+
+def test_latent(gold, manifest):
+    g = gold('latent')
+    sd = O.synth_state_dict(manifest('manifest_latent32'))
+    with torch.no_grad():
+        y = O.latent_unet(sd, 'backbone', g['x'], torch.full((6,), 123, dtype=torch.long), 32)
+    assert rel(y, g['y123']) < 1e-5
+
+
+def test_vanilla(gold, manifest):
+    g = gold('vanilla_twophase')
+    sd = O.synth_state_dict(manifest('manifest_vanilla_fmnist'))
+    cfg = O.dataset_cfg('fmnist', a_dim=8, diffusion_steps=3)
+    with torch.no_grad():
+        y = O.vanilla_unet(sd, 'backbone', g['x'], torch.full((2,), 2, dtype=torch.long),
+                           cfg.unets_channels, O.ch_mult_for(cfg, vanilla=True))
+    assert rel(y, g['y2']) < 2e-5

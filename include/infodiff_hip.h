@@ -1,0 +1,130 @@
+/* libinfodiff_hip -- C ABI of the MI355X (gfx950) kernels behind InfoDiffusion's
+ * data-parallel hot path (AVDM UNet forward/backward, diffusion loss, DDPM/DDIM
+ * sampler updates).
+ *
+ * The reference (isjakewong/InfoDiffusion) is pure PyTorch and has no FFI of its
+ * own; this header is the boundary SURVEY.md section 8b proposes underneath the
+ * reference's Python surface.  Each entry cites the reference code it replaces
+ * (file:line in the reference tree).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; the caller owns all memory (inputs, outputs,
+ *    workspaces).  Nothing is allocated, freed or retained by the library.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - Activations are dense NHWC.  `dtype` selects the activation/weight storage
+ *    type: IDF_F32 (0) or IDF_BF16 (1); accumulation, statistics, FiLM
+ *    coefficients, losses and weight gradients are always fp32.
+ *  - Return 0 on success, a hipError_t value on a launch failure, or
+ *    IDF_ERR_UNSUPPORTED / IDF_ERR_BADARG; idf_last_error() (thread-local) holds
+ *    the message.  Never aborts, never throws.
+ *  - Re-entrant and stateless: safe to call from PyTorch's autograd thread.
+ */
+#ifndef INFODIFF_HIP_H
+#define INFODIFF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDF_F32 0
+#define IDF_BF16 1
+#define IDF_ERR_UNSUPPORTED 1001
+#define IDF_ERR_BADARG 1002
+
+/* conv gather modes */
+#define IDF_CONV_S1 0  /* stride 1, pad taps/2                                  */
+#define IDF_CONV_S2 1  /* stride 2 (DownSample, modules.py:66)                   */
+#define IDF_CONV_UP2 2 /* nearest x2 upsample fused into the read (modules.py:89-92) */
+#define IDF_CONV_T2 3  /* transposed stride 2: data gradient of IDF_CONV_S2      */
+
+int idf_version(void);
+const char* idf_last_error(void);
+
+/* ---- convolution (modules.py:63-93, 133-136, 264-293, 335-348; models.py:246, 280-284)
+ * y[m,n] = sum_{tap,c} act(x[gather(m,tap),c]) * w[n][tap][c] + bias[n] (+ res[m,n])
+ *   x [B,Hs,Ws,Cin], w [Cout][taps][Cin], y/res [B,Ho,Wo,Cout]; taps 1 or 9.
+ *   act 0: none; 1: u = x*sc[b,c]+sh[b,c] (GroupNorm+FiLM fold, see idf_gn_coef_fwd);
+ *   2: SiLU(u) then dropout(p_drop) when seed != NULL (counter-based, keyed by
+ *   (*seed, salt, element index of x)).
+ * The data gradient is the same call on dy with the flipped/transposed weight
+ * shadow (idf_pack_conv_weight) and mode S1 (for S1/UP2 forward) or T2 (for S2). */
+int idf_conv2d_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
+                   const float* sc, const float* sh, const uint64_t* seed, uint32_t salt, float p_drop,
+                   int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int mode, int taps, int act,
+                   int dtype, void* stream);
+
+/* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
+ * same prologue arguments as the forward so the activated input is recomputed. */
+int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, const float* sh,
+                     const uint64_t* seed, uint32_t salt, float p_drop, int B, int Hs, int Ws, int Cin,
+                     int Ho, int Wo, int Cout, int mode, int taps, int act, int dtype, void* stream);
+
+/* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
+ * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */
+int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fwd, void* w_dgrad, int O, int I,
+                         int taps, int dtype, void* stream);
+
+/* ---- GroupNorm(32) + AdaGN/FiLM fold (modules.py:132, 214-228, 312-318; nn.GroupNorm eps 1e-5)
+ * Writes mean/rstd [B,32] and the per-(b,c) affine sc/sh [B,C]:
+ *   sc = rstd*gamma*(1+s_t)*(1+s_a),  sh = ((beta-mean*rstd*gamma)*(1+s_t)+b_t)*(1+s_a)+b_a
+ * film_t / film_a: [B,2C] (scale = first half, shift = second half; torch.chunk order,
+ * modules.py:314,317) or NULL.  workspace: idf_gn_workspace_floats(B,HW,C) floats. */
+int idf_gn_workspace_floats(int B, int HW, int C);
+int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
+                    const float* film_a, float eps, float* mean, float* rstd, float* sc, float* sh,
+                    float* workspace, int B, int HW, int C, int dtype, void* stream);
+/* Backward through act(GN/FiLM(x)) given dA (gradient w.r.t. the activated tensor):
+ * dx (+ dres), dfilm_t/dfilm_a [B,2C], dgb [B][2][C] (per-sample dgamma, dbeta;
+ * sum over B with idf_colsum), k1/k0 [B,32] scratch. */
+int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
+                    const float* beta, const float* film_t, const float* film_a, const float* mean,
+                    const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
+                    float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed, uint32_t salt,
+                    float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
+
+/* ---- dense contractions: attention bmm's (modules.py:152-159), linears
+ * (modules.py:22-27, 269-276; models.py:244, 470-472, LatentUNet 147-163) and gradients.
+ * C[b][m][n] = alpha * sum_k opA[m][k]*opB[n][k] (+bias[n]); ta/tb = 1 when the operand
+ * is stored K-major ([K][M] / [K][N]).  splitk > 1 accumulates with fp32 atomics into a
+ * pre-zeroed fp32 C (out_f32 = 1). */
+int idf_bgemm(const void* A, const void* B, void* C, const float* bias, int batch, long sA, long sB, long sC,
+              int lda, int ldb, int ldc, int M, int N, int K, int ta, int tb, float alpha, int out_f32,
+              int splitk, int dtype, void* stream);
+int idf_softmax_fwd(void* s, long R, int N, int dtype, void* stream);            /* modules.py:156 */
+int idf_softmax_bwd(const void* P, void* dP, long R, int N, int dtype, void* stream);
+
+/* ---- elementwise / reductions */
+/* q_sample, models.py:702-704: xt = sqrt_ab[idx[b]]*x + sqrt_1mab[idx[b]]*eps; the two [T] tables
+ * hold sqrt(alpha_bar), sqrt(1-alpha_bar) (host torch CPU ops => bit-exact gathers and fp32 result) */
+int idf_qsample(const float* x, const float* eps, const long* idx, const float* sqrt_ab, const float* sqrt_1mab,
+                float* xt32, void* xt, long per_sample, long n, int dtype, void* stream);
+/* nn.Embedding lookup of the frozen sinusoid table, modules.py:23 */
+int idf_gather_rows(const float* table, const long* idx, float* out, int B, int D, void* stream);
+int idf_silu_fwd(const float* x, float* y, long n, void* stream);
+int idf_silu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+/* models.py:640-646: res[0] = mean((out-eps)^2); res[1] = mean((c0*(x-c1*out)-x)^2)/T */
+int idf_loss_fwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T, float* res,
+                 float* workspace, long n, int dtype, void* stream);
+int idf_loss_bwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T,
+                 const float* g, void* dout, long n, int dtype, void* stream);
+/* sampling.py:29-37 (mode 0 DDPM), 52-59 (1 DDIM as written, eta 0.01), 71-72 (2 reverse DDIM).
+ * coef: [T][8] per-step scalars {c0,c1,c2,c3,d0,d1,sigma,-} built on the host with the reference's
+ * fp32 expressions; *idx selects the row.  x/xo fp32 state, eps (and optional xo_t copy) in dtype. */
+int idf_sampler_step(const float* x, const void* eps, const float* noise, float* xo, void* xo_t,
+                     const long* idx, const float* coef, int mode, long n, int dtype, void* stream);
+/* utils.py:74-90 RBF-kernel MMD (bandwidth dim^2); workspace 2n+m floats */
+int idf_mmd_fwd(const float* x, const float* y, int n, int m, int D, float* out, float* workspace, void* stream);
+int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, const float* g, float* dy, void* stream);
+/* out[N] = sum over R rows; workspace idf_colsum_blocks(R)*N floats */
+int idf_colsum_blocks(long R);
+int idf_colsum(const void* in, float* out, float* workspace, long R, int N, int in_dtype, void* stream);
+/* 2x2 sum pool [B,2Ho,2Wo,C] -> [B,Ho,Wo,C]: data gradient of the fused nearest upsample */
+int idf_pool2_sum(const void* in, void* out, int B, int Ho, int Wo, int C, int dtype, void* stream);
+/* test hook: the dropout keep-mask (scaled) a call site would apply */
+int idf_dropout_mask(const uint64_t* seed, uint32_t salt, float p_drop, float* mask, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

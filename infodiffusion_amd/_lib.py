@@ -1,0 +1,81 @@
+"""ctypes binding of libinfodiff_hip.so (include/infodiff_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is
+missing or a kernel rejects its arguments, this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libinfodiff_hip.so')
+
+F32, BF16 = 0, 1
+ERR_UNSUPPORTED, ERR_BADARG = 1001, 1002
+
+_p, _i, _l, _f, _u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
+
+SIGNATURES = {
+    'idf_version': ([], C.c_int),
+    'idf_last_error': ([], C.c_char_p),
+    'idf_conv2d_fwd': ([_p, _p, _p, _p, _p, _p, _p, _p, _u32, _f] + [_i] * 11 + [_p], C.c_int),
+    'idf_conv2d_wgrad': ([_p, _p, _p, _p, _p, _p, _u32, _f] + [_i] * 11 + [_p], C.c_int),
+    'idf_pack_conv_weight': ([_p, _l, _l, _l, _p, _p, _i, _i, _i, _i, _p], C.c_int),
+    'idf_gn_workspace_floats': ([_i, _i, _i], C.c_int),
+    'idf_gn_coef_fwd': ([_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
+    'idf_gn_coef_bwd': ([_p] * 18 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_bgemm': ([_p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
+    'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),
+    'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),
+    'idf_qsample': ([_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p], C.c_int),
+    'idf_gather_rows': ([_p, _p, _p, _i, _i, _p], C.c_int),
+    'idf_silu_fwd': ([_p, _p, _l, _p], C.c_int),
+    'idf_silu_bwd': ([_p, _p, _p, _l, _p], C.c_int),
+    'idf_loss_fwd': ([_p, _p, _p, _f, _f, _f, _p, _p, _l, _i, _p], C.c_int),
+    'idf_loss_bwd': ([_p, _p, _p, _f, _f, _f, _p, _p, _l, _i, _p], C.c_int),
+    'idf_sampler_step': ([_p] * 7 + [_i, _l, _i, _p], C.c_int),
+    'idf_mmd_fwd': ([_p, _p, _i, _i, _i, _p, _p, _p], C.c_int),
+    'idf_mmd_bwd': ([_p, _p, _i, _i, _i, _p, _p, _p], C.c_int),
+    'idf_colsum_blocks': ([_l], C.c_int),
+    'idf_colsum': ([_p, _p, _p, _l, _i, _i, _p], C.c_int),
+    'idf_pool2_sum': ([_p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_dropout_mask': ([_p, _u32, _f, _p, _l, _p], C.c_int),
+}
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (build it first with `python -m infodiffusion_amd.build`
+    or `__graft_entry__.build()`).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libinfodiff_hip.so not found at %s -- the HIP extension is required '
+            '(no fallback path); run `python -m infodiffusion_amd.build`' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc == 0:
+        return
+    msg = load().idf_last_error().decode(errors='replace')
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError('%s: %s' % (name, msg))
+    raise HipKernelError('%s failed (code %d): %s' % (name, rc, msg))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,123 @@
+// Shared device/host helpers for libinfodiff_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define IDF_OK 0
+#define IDF_ERR_UNSUPPORTED 1001   // shape/dtype outside what the kernels cover
+#define IDF_ERR_BADARG 1002
+
+#define IDF_F32 0
+#define IDF_BF16 1
+
+extern "C" const char* idf_last_error(void);
+void idf_set_error(const char* fmt, ...);
+
+#define IDF_FAIL(code, ...)            \
+  do {                                 \
+    idf_set_error(__VA_ARGS__);        \
+    return (code);                     \
+  } while (0)
+
+#define IDF_CHECK_LAUNCH()                                        \
+  do {                                                            \
+    hipError_t _e = hipGetLastError();                            \
+    if (_e != hipSuccess) {                                       \
+      idf_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \
+                    hipGetErrorString(_e));                       \
+      return (int)_e;                                             \
+    }                                                             \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even; a plain cast keeps NaN a NaN (MI355X_MICROARCH correctness table)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VE = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector <-> VE floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  __device__ static __forceinline__ void load(const float* p, float* o) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float* o) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct Vec16<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float* o) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* o) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// d/du [u * sigmoid(u)]
+__device__ __forceinline__ float dsilu_f(float u) {
+  float s = 1.0f / (1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+// Counter-based dropout: keep decision for element `idx` of call site `salt`
+// under step seed `seed`.  16 random bits per element (two elements per hash).
+__device__ __forceinline__ uint32_t idf_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool idf_keep(uint64_t seed, uint32_t salt, uint64_t idx, uint32_t thresh16) {
+  uint32_t pair = (uint32_t)(idx >> 1);
+  uint32_t hi = (uint32_t)(idx >> 33);
+  uint32_t h = idf_hash32(pair ^ (uint32_t)seed);
+  h = idf_hash32(h + salt * 0x9E3779B9u + (uint32_t)(seed >> 32) + hi * 0x85ebca6bU);
+  uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return r >= thresh16;
+}
+__host__ __device__ __forceinline__ uint32_t idf_drop_thresh(float p) {
+  return (uint32_t)(p * 65536.0f + 0.5f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int idf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,334 @@
+// GroupNorm(32) statistics and the AdaGN / FiLM coefficient fold, forward and
+// backward (HBM-bound kernels).  Replaces nn.GroupNorm(32, C) + the FiLM
+// scale-shift of modules.py:312-318 (and 132, 214-228, 335-344; models.py:280-284).
+//
+// Forward: per (b, group) mean / rstd over (C/32)*H*W elements (eps 1e-5, biased
+// variance), folded with gamma/beta and the two FiLM pairs into one affine per
+// (b, channel):   u = x * sc[b,c] + sh[b,c]
+//   sc = rstd*gamma*(1+s_t)*(1+s_a)
+//   sh = ((beta - mean*rstd*gamma)*(1+s_t) + b_t)*(1+s_a) + b_a
+// which the conv kernel applies while staging (followed by SiLU / dropout).
+//
+// Backward (given dA = gradient w.r.t. the activated tensor fed to the conv):
+//   du = dA * keep * dsilu(u);  S1[b,c] = sum_p du;  S2[b,c] = sum_p du*x
+//   dx = sc*du + k1[b,g]*x + k0[b,g]      (+ dres)
+// with k1, k0, dgamma, dbeta and the FiLM gradients derived from S1, S2 only.
+#include "idf_common.h"
+
+namespace {
+
+constexpr int G = 32;
+
+// ---------------------------------------------------------------- statistics
+// grid (nchunk, B); each block reduces `chunk` pixels x all C channels to
+// per-group (sum, sumsq) partials.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_partial(const T* __restrict__ x, float2* __restrict__ part,
+                                                        int HW, int C, int chunk) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [lanes][C][2] then [C][2]
+  const int vpp = C / VE, lanes = 256 / vpp, tid = threadIdx.x;
+  const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+  const int v = tid % vpp, pl = tid / vpp;
+  float s[VE], ss[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s[e] = ss[e] = 0.f;
+  const int pend = min(HW, (ck + 1) * chunk);
+  if (pl < lanes) {
+    for (int p = ck * chunk + pl; p < pend; p += lanes) {
+      float xv[VE];
+      Vec16<T>::load(x + ((size_t)b * HW + p) * C + v * VE, xv);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { s[e] += xv[e]; ss[e] += xv[e] * xv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[(pl * C + v * VE + e) * 2] = s[e];
+      red[(pl * C + v * VE + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  float* chs = red + lanes * C * 2;
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < lanes; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
+    chs[c * 2] = a; chs[c * 2 + 1] = q;
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int cpg = C / G;
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[c * 2]; q += chs[c * 2 + 1]; }
+    part[((size_t)b * nchunk + ck) * G + tid] = make_float2(a, q);
+  }
+}
+
+// grid B.  Merge partials (in double), write mean/rstd, fold coefficients.
+__global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ part, int nchunk, int HW, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ film_t, const float* __restrict__ film_a,
+                                                   float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                   float* __restrict__ sc, float* __restrict__ sh) {
+  __shared__ float sm[G], sr[G];
+  const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
+  if (tid < G) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      float2 v = part[((size_t)b * nchunk + k) * G + tid];
+      a += v.x; q += v.y;
+    }
+    double n = (double)HW * cpg;
+    double mu = a / n, var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    float r = (float)(1.0 / sqrt(var + (double)eps));
+    sm[tid] = (float)mu; sr[tid] = r;
+    mean[b * G + tid] = (float)mu; rstd[b * G + tid] = r;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    int g = c / cpg;
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float a = sr[g] * ga, d = be - sm[g] * a;
+    if (film_t) {
+      float f = 1.f + film_t[(size_t)b * 2 * C + c];
+      a *= f; d = d * f + film_t[(size_t)b * 2 * C + C + c];
+    }
+    if (film_a) {
+      float f = 1.f + film_a[(size_t)b * 2 * C + c];
+      a *= f; d = d * f + film_a[(size_t)b * 2 * C + C + c];
+    }
+    sc[(size_t)b * C + c] = a; sh[(size_t)b * C + c] = d;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T>
+__device__ __forceinline__ void du_vec(const float* dav, const float* xv, const float* scv, const float* shv,
+                                       int act, const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale,
+                                       size_t e0, float* du) {
+  constexpr int VE = Elem<T>::VE;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    float d = dav[e];
+    if (act == 2) {
+      float u = xv[e] * scv[e] + shv[e];
+      d *= dsilu_f(u);
+      if (seed) d = idf_keep(*seed, salt, e0 + e, thr) ? d * dscale : 0.f;
+    }
+    du[e] = d;
+  }
+}
+
+// grid (nchunk, B): per-channel partial S1 = sum du, S2 = sum du*x
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_partial(const T* __restrict__ dA, const T* __restrict__ x,
+                                                      const float* __restrict__ sc, const float* __restrict__ sh,
+                                                      float2* __restrict__ part, int HW, int C, int chunk, int act,
+                                                      const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [lanes][C][2]
+  const int vpp = C / VE, lanes = 256 / vpp, tid = threadIdx.x;
+  const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+  const int v = tid % vpp, pl = tid / vpp;
+  float s1[VE], s2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
+  const int pend = min(HW, (ck + 1) * chunk);
+  if (pl < lanes) {
+    float scv[VE], shv[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      scv[e] = sc[(size_t)b * C + v * VE + e];
+      shv[e] = sh[(size_t)b * C + v * VE + e];
+    }
+    for (int p = ck * chunk + pl; p < pend; p += lanes) {
+      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      float xv[VE], dav[VE], du[VE];
+      Vec16<T>::load(x + e0, xv);
+      Vec16<T>::load(dA + e0, dav);
+      du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { s1[e] += du[e]; s2[e] += du[e] * xv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[(pl * C + v * VE + e) * 2] = s1[e];
+      red[(pl * C + v * VE + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < lanes; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
+    part[((size_t)b * nchunk + ck) * C + c] = make_float2(a, q);
+  }
+}
+
+// grid B.  From S1,S2 derive k1,k0 per group, FiLM grads, and the per-sample
+// gamma/beta gradient contributions dgb[b][0][c] (dgamma), dgb[b][1][c] (dbeta).
+__global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict__ part, int nchunk, int HW, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ film_t, const float* __restrict__ film_a,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       float* __restrict__ k1, float* __restrict__ k0,
+                                                       float* __restrict__ dfilm_t, float* __restrict__ dfilm_a,
+                                                       float* __restrict__ dgb) {
+  extern __shared__ float sm[];   // P1c[C], P2c[C]
+  float* P1c = sm;
+  float* P2c = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
+  for (int c = tid; c < C; c += 256) {
+    float S1 = 0.f, S2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      float2 v = part[((size_t)b * nchunk + k) * C + c];
+      S1 += v.x; S2 += v.y;
+    }
+    int g = c / cpg;
+    float mu = mean[b * G + g], r = rstd[b * G + g];
+    float D1 = S1, D2 = r * (S2 - mu * S1);
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float st = 0.f, bt = 0.f, sa = 0.f;
+    if (film_t) { st = film_t[(size_t)b * 2 * C + c]; bt = film_t[(size_t)b * 2 * C + C + c]; }
+    if (film_a) { sa = film_a[(size_t)b * 2 * C + c]; }
+    float f = (1.f + st) * (1.f + sa);
+    float Gf = ga * D2 + be * D1, Ge = D1;
+    if (dfilm_t) {
+      dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa);
+      dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa);
+    }
+    if (dfilm_a) {
+      dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt;
+      dfilm_a[(size_t)b * 2 * C + C + c] = Ge;
+    }
+    dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
+    dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    P1c[c] = ga * f * D1;
+    P2c[c] = ga * f * D2;
+  }
+  __syncthreads();
+  if (tid < G) {
+    float P1 = 0.f, P2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { P1 += P1c[c]; P2 += P2c[c]; }
+    float mu = mean[b * G + tid], r = rstd[b * G + tid];
+    float invN = 1.f / ((float)HW * cpg);
+    k1[b * G + tid] = -r * r * P2 * invN;
+    k0[b * G + tid] = (-r * P1 + r * r * mu * P2) * invN;
+  }
+}
+
+// elementwise: dx = sc*du + k1*x + k0 (+ dres)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply(const T* __restrict__ dA, const T* __restrict__ x,
+                                                    const T* __restrict__ dres, T* __restrict__ dx,
+                                                    const float* __restrict__ sc, const float* __restrict__ sh,
+                                                    const float* __restrict__ k1, const float* __restrict__ k0,
+                                                    int HW, int C, long nvec, int act, const uint64_t* seed,
+                                                    uint32_t salt, uint32_t thr, float dscale) {
+  constexpr int VE = Elem<T>::VE;
+  const int vpp = C / VE, cpg = C / G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    long pix = i / vpp;
+    int v = (int)(i - pix * vpp);
+    int b = (int)(pix / HW);
+    size_t e0 = (size_t)i * VE;
+    float xv[VE], dav[VE], du[VE], scv[VE], shv[VE], o[VE];
+    Vec16<T>::load(x + e0, xv);
+    Vec16<T>::load(dA + e0, dav);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      scv[e] = sc[(size_t)b * C + v * VE + e];
+      shv[e] = sh[(size_t)b * C + v * VE + e];
+    }
+    du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      int g = (v * VE + e) / cpg;
+      o[e] = scv[e] * du[e] + k1[b * G + g] * xv[e] + k0[b * G + g];
+    }
+    if (dres) {
+      float rv[VE];
+      Vec16<T>::load(dres + e0, rv);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] += rv[e];
+    }
+    Vec16<T>::store(dx + e0, o);
+  }
+}
+
+int pick_chunk(int B, int HW) {
+  // aim for >= ~1024 blocks, chunks of at least 64 pixels
+  int nchunk = idf_cdiv(1024, B);
+  int chunk = idf_cdiv(HW, nchunk);
+  if (chunk < 64) chunk = 64;
+  if (chunk > HW) chunk = HW;
+  return chunk;
+}
+
+}  // namespace
+
+extern "C" int idf_gn_workspace_floats(int B, int HW, int C) {
+  int chunk = pick_chunk(B, HW);
+  int nchunk = idf_cdiv(HW, chunk);
+  return B * nchunk * (C > G ? C : G) * 2;
+}
+
+extern "C" int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
+                               const float* film_a, float eps, float* mean, float* rstd, float* sc, float* sh,
+                               float* workspace, int B, int HW, int C, int dtype, void* stream) {
+  if (B == 0) return IDF_OK;
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (C % G || C % VE || C / VE > 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "groupnorm: C=%d unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  int chunk = pick_chunk(B, HW), nchunk = idf_cdiv(HW, chunk);
+  int lanes = 256 / (C / VE);
+  size_t lds = (size_t)(lanes + 1) * C * 2 * sizeof(float);
+  dim3 g(nchunk, B);
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_stats_partial<float>, g, dim3(256), lds, st, (const float*)x, (float2*)workspace, HW, C, chunk);
+  else
+    hipLaunchKernelGGL(gn_stats_partial<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)x, (float2*)workspace, HW, C, chunk);
+  IDF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finalize, dim3(B), dim3(256), 0, st, (const float2*)workspace, nchunk, HW, C, gamma, beta,
+                     film_t, film_a, eps, mean, rstd, sc, sh);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
+                               const float* beta, const float* film_t, const float* film_a, const float* mean,
+                               const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
+                               float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed,
+                               uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
+  if (B == 0) return IDF_OK;
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (C % G || C % VE || C / VE > 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "groupnorm bwd: C=%d unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  int chunk = pick_chunk(B, HW), nchunk = idf_cdiv(HW, chunk);
+  int lanes = 256 / (C / VE);
+  size_t lds = (size_t)lanes * C * 2 * sizeof(float);
+  uint32_t thr = idf_drop_thresh(p_drop);
+  float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+  const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  dim3 g(nchunk, B);
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_bwd_partial<float>, g, dim3(256), lds, st, (const float*)dA, (const float*)x, sc, sh,
+                       (float2*)workspace, HW, C, chunk, act, sd, salt, thr, dscale);
+  else
+    hipLaunchKernelGGL(gn_bwd_partial<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)dA, (const bf16_t*)x, sc, sh,
+                       (float2*)workspace, HW, C, chunk, act, sd, salt, thr, dscale);
+  IDF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_finalize, dim3(B), dim3(256), 2 * C * sizeof(float), st, (const float2*)workspace, nchunk,
+                     HW, C, gamma, beta, film_t, film_a, mean, rstd, k1, k0, dfilm_t, dfilm_a, dgb);
+  IDF_CHECK_LAUNCH();
+  long nvec = (long)B * HW * C / VE;
+  int blocks = (int)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(blocks), dim3(256), 0, st, (const float*)dA, (const float*)x,
+                       (const float*)dres, (float*)dx, sc, sh, k1, k0, HW, C, nvec, act, sd, salt, thr, dscale);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dA, (const bf16_t*)x,
+                       (const bf16_t*)dres, (bf16_t*)dx, sc, sh, k1, k0, HW, C, nvec, act, sd, salt, thr, dscale);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

@@ -1,0 +1,311 @@
+"""AVDM networks and the diffusion training objective on the HIP kernels.
+
+Drop-in mirror of the reference's models.py surface: same class
+names, constructor / forward / loss_fn signatures, attribute names and state_dict
+keys.  Extra, optional knob: `args.act_dtype` ('fp32' default, or 'bf16') selects
+the activation / weight-shadow storage type of the kernels.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import ops
+from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
+                      _Shadows, _cfg, _ACT_NONE, _ACT_SILU, bind_context, timestep_embedding)
+from .utils import compute_mmd, gaussian_mixture, swiss_roll
+
+_DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
+           None: torch.float32}
+
+
+def _act_dtype(args):
+    v = getattr(args, 'act_dtype', None)
+    return v if isinstance(v, torch.dtype) else _DTYPES[v]
+
+
+class _UNetSkeleton(nn.Module):
+    """Down / middle / up scaffolding common to AuxiliaryUNet, Encoder and UNet
+    (models.py:248-284, 432-468, 16-52).  `make(in_ch, out_ch, attn)` builds a block."""
+
+    def _build(self, make, ch, ch_mult, attn, num_res_blocks, in_ch, out_ch):
+        assert all([i < len(ch_mult) for i in attn]), 'attn index out of bound'
+        self.head = nn.Conv2d(in_ch, ch, kernel_size=3, stride=1, padding=1)
+        self.downblocks = nn.ModuleList()
+        widths, now = [ch], ch
+        for level, mult in enumerate(ch_mult):
+            for _ in range(num_res_blocks):
+                self.downblocks.append(make(now, ch * mult, level in attn))
+                now = ch * mult
+                widths.append(now)
+            if level != len(ch_mult) - 1:
+                self.downblocks.append(DownSample(now))
+                widths.append(now)
+        self.middleblocks = nn.ModuleList([make(now, now, True), make(now, now, False)])
+        self.upblocks = nn.ModuleList()
+        for level, mult in reversed(list(enumerate(ch_mult))):
+            for _ in range(num_res_blocks + 1):
+                self.upblocks.append(make(widths.pop() + now, ch * mult, level in attn))
+                now = ch * mult
+            if level != 0:
+                self.upblocks.append(UpSample(now))
+        assert len(widths) == 0
+        self.tail = nn.Sequential(nn.GroupNorm(32, now), nn.SiLU(), nn.Conv2d(now, out_ch, 3, stride=1, padding=1))
+
+    def _init_ends(self):
+        init.xavier_uniform_(self.head.weight)
+        init.zeros_(self.head.bias)
+
+    def _init_tail(self):
+        init.xavier_uniform_(self.tail[-1].weight, gain=1e-5)
+        init.zeros_(self.tail[-1].bias)
+
+    def _post(self):
+        self.ctx = RunCtx()
+        bind_context(self, self.ctx)
+        self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)
+        self._cfg_tail = _cfg(_Shadows(self.tail[-1]), ops.S1, 9, _ACT_SILU)
+
+    def _prep(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('infodiffusion_amd runs on the GPU only: the HIP kernels have no CPU fallback')
+        self.ctx.seed = None
+        if self.training:
+            self.ctx.seed = torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64)
+        return x.to(self.ctx.act_dtype).contiguous(memory_format=torch.channels_last)
+
+    def _run(self, x, block_call):
+        h = ops.fused_conv(x, self.head.weight, self.head.bias, self._cfg_head)
+        skips = [h]
+        for layer in self.downblocks:
+            h = layer(h) if isinstance(layer, DownSample) else block_call(layer, h)
+            skips.append(h)
+        for layer in self.middleblocks:
+            h = block_call(layer, h)
+        for layer in self.upblocks:
+            if isinstance(layer, UpSample):
+                h = layer(h)
+            else:
+                h = block_call(layer, torch.cat([h, skips.pop()], dim=1))
+        assert len(skips) == 0
+        gn, conv = self.tail[0], self.tail[-1]
+        return ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias)
+
+
+class UNet(_UNetSkeleton):
+    """models.py:7-88 (vanilla epsilon-predictor; FiLM on t only)."""
+
+    def __init__(self, T, ch=64, ch_mult=[1, 2, 4, 8], attn=[2], num_res_blocks=2, dropout=0.1, shape=None):
+        super().__init__()
+        tdim = ch * 4
+        self.time_embedding = TimeEmbedding(T, ch, tdim)
+        self._build(lambda i, o, at: ResBlock(in_ch=i, out_ch=o, tdim=tdim, dropout=dropout, attn=at),
+                    ch, ch_mult, attn, num_res_blocks, shape[0], shape[0])
+        self.initialize()
+        self._post()
+
+    def initialize(self):
+        self._init_ends()
+        self._init_tail()
+
+    def forward(self, x, t):
+        x = self._prep(x)
+        temb = self.time_embedding(t)
+        return self._run(x, lambda blk, h: blk(h, temb))
+
+
+class AuxiliaryUNet(_UNetSkeleton):
+    """models.py:237-326."""
+
+    def __init__(self, T, ch=64, ch_mult=[1, 2, 4, 8], attn=[2], num_res_blocks=2, dropout=0.1, a_dim=32,
+                 shape=None):
+        super().__init__()
+        tdim = ch * 4
+        self.a_dim = a_dim
+        self.time_embedding = TimeEmbedding(T, ch, tdim)
+        self.fc_a = nn.Linear(self.a_dim, tdim)
+        self._build(lambda i, o, at: AuxResBlock(in_ch=i, out_ch=o, tdim=tdim, dropout=dropout, attn=at),
+                    ch, ch_mult, attn, num_res_blocks, shape[0], shape[0])
+        self.initialize()
+        self._post()
+
+    def initialize(self):
+        self._init_ends()
+        init.xavier_uniform_(self.fc_a.weight)
+        init.zeros_(self.fc_a.bias)
+        self._init_tail()
+
+    def forward(self, x, t, a):
+        x = self._prep(x)
+        aemb = ops.linear(a, self.fc_a.weight, self.fc_a.bias)
+        temb = self.time_embedding(t)
+        return self._run(x, lambda blk, h: blk(h, temb, aemb))
+
+
+class Encoder(_UNetSkeleton):
+    """models.py:424-518: UNet-shaped encoder -> 1 channel -> fc -> (a, a_q, mu, log_var)."""
+
+    def __init__(self, ch=64, ch_mult=[1, 2, 4, 8, 8], attn=[2], num_res_blocks=2, dropout=0.1, a_dim=32,
+                 shape=None):
+        super().__init__()
+        self.shape = shape
+        self.a_dim = a_dim
+        self._build(lambda i, o, at: ResBlock_encoder(in_ch=i, out_ch=o, dropout=dropout, attn=at),
+                    ch, ch_mult, attn, num_res_blocks, shape[0], 1)
+        self.fc_a = nn.Linear(self.shape[1] * self.shape[2], self.a_dim)
+        self.fc_mu = nn.Linear(self.a_dim, self.a_dim)
+        self.fc_var = nn.Linear(self.a_dim, self.a_dim)
+        self.initialize()
+        self._post()
+
+    def initialize(self):
+        self._init_ends()
+        for fc in (self.fc_a, self.fc_mu, self.fc_var):
+            init.xavier_uniform_(fc.weight)
+            init.zeros_(fc.bias)
+        self._init_tail()
+
+    def forward(self, x):
+        x = self._prep(x)
+        h = self._run(x, lambda blk, hh: blk(hh))
+        h = torch.flatten(h, start_dim=1).float()
+        a = ops.linear(h, self.fc_a.weight, self.fc_a.bias)
+        mu = ops.linear(a, self.fc_mu.weight, self.fc_mu.bias)
+        log_var = ops.linear(a, self.fc_var.weight, self.fc_var.bias)
+        a_q = mu + torch.randn_like(mu) * torch.exp(0.5 * log_var)
+        return a, a_q, mu, log_var
+
+
+def _schedule(args, device):
+    """models.py:615-618: identical torch CPU ops => bitwise-identical tables."""
+    T = args.diffusion_steps
+    alpha_bars = torch.cumprod(1 - torch.linspace(start=args.beta1, end=args.betaT, steps=T), dim=0).to(device=device)
+    betas = torch.linspace(start=args.beta1, end=args.betaT, steps=T).to(device=device)
+    alphas = 1 - betas
+    alpha_prev_bars = torch.cat([torch.Tensor([1]).to(device=device), alpha_bars[:-1]])
+    return alpha_bars, betas, alphas, alpha_prev_bars
+
+
+class InfoDiff(nn.Module):
+    """models.py:605-723."""
+
+    def __init__(self, args, device, shape):
+        super().__init__()
+        self.device = device
+        self.alpha_bars, self.betas, self.alphas, self.alpha_prev_bars = _schedule(args, device)
+        ch_mult = [1, 2, 4] if args.input_size == 28 else [1, 2, 2, 2]
+        if getattr(args, 'is_bottleneck', False):
+            raise NotImplementedError('--is_bottleneck (BottleneckAuxUNet) is outside the hot path (SURVEY.md 8f)')
+        self.backbone = AuxiliaryUNet(ch_mult=ch_mult, T=args.diffusion_steps, ch=args.unets_channels,
+                                      a_dim=args.a_dim, shape=shape)
+        self.encoder = Encoder(ch_mult=ch_mult, ch=args.encoder_channels, a_dim=args.a_dim, shape=shape)
+        self.mmd_weight: float = args.mmd_weight
+        self.kld_weight: float = args.kld_weight
+        self.verbose = getattr(args, 'verbose_loss', False)
+        self.set_act_dtype(_act_dtype(args))
+        self._qs_tables = ops.qsample_tables(self.alpha_bars)
+        # t = 0 constants of the reconstruction term (models.py:644), fp32 like the reference
+        ab0 = self.alpha_bars[0].cpu()
+        self._rec_c0 = float(torch.sqrt(1 / self.alphas[0].cpu()))
+        self._rec_c1 = float(self.betas[0].cpu() / torch.sqrt(1 - ab0))
+        self.to(device)
+
+    def set_act_dtype(self, dtype):
+        self.act_dtype = dtype
+        self.backbone.ctx.act_dtype = dtype
+        self.encoder.ctx.act_dtype = dtype
+
+    def _draw_idx(self, n):
+        # models.py:701 draws on the CPU; under stream capture the draw must stay on the device
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return torch.randint(0, len(self.alpha_bars), (n,), device=self.device)
+        return torch.randint(0, len(self.alpha_bars), (n,)).to(device=self.device)
+
+    def loss_fn(self, args, x, idx=None, curr_epoch=0):
+        output, epsilon, a, mu, log_var = self.forward(x, idx=idx, get_target=True)
+        terms = ops.diff_loss(output, epsilon, x, self._rec_c0, self._rec_c1, 1.0 / args.diffusion_steps)
+        loss = terms[0] + terms[1]
+        if self.verbose:
+            print('denoising loss:', terms[0])
+            print('recon loss:', terms[1])
+
+        def prior_samples(like):
+            if args.prior == 'regular':
+                return torch.randn_like(like, device=self.device)
+            if args.prior == '10mix':
+                return torch.FloatTensor(gaussian_mixture(args.batch_size, args.a_dim)).to(device=self.device)
+            return torch.FloatTensor(swiss_roll(args.batch_size)).to(device=self.device)
+
+        def kl_term():
+            kld_loss = torch.sum(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+            if args.use_C:
+                self.C_max = torch.FloatTensor([args.C_max]).to(device=self.device)
+                C = torch.clamp(self.C_max / args.epochs * curr_epoch,
+                                torch.FloatTensor([0]).to(device=self.device), self.C_max)
+                return args.kld_weight * (kld_loss - C.squeeze(dim=0)).abs()
+            return args.kld_weight * kld_loss
+
+        if self.mmd_weight != 0 and self.kld_weight != 0:
+            loss = loss + args.mmd_weight * compute_mmd(prior_samples(a), mu) + kl_term()
+        elif args.mmd_weight != 0:
+            loss = loss + args.mmd_weight * compute_mmd(prior_samples(a), a)
+        elif args.kld_weight != 0:
+            loss = loss + kl_term()
+        return loss
+
+    def forward(self, x, idx=None, a=None, get_target=False):
+        if idx is None:
+            idx = self._draw_idx(x.size(0))
+            epsilon = torch.randn_like(x)
+            x_tilde = ops.q_sample(x, epsilon, idx, self._qs_tables, self.act_dtype)
+        else:
+            if not torch.is_tensor(idx):
+                idx = torch.full((x.size(0),), int(idx), dtype=torch.long, device=self.device)
+            x_tilde = x
+        if a is None:
+            a, a_q, mu, log_var = self.encoder(x)
+        else:
+            a_q = a
+        use_q = self.kld_weight != 0     # models.py:714-721
+        output = self.backbone(x_tilde, idx, a_q if use_q else a)
+        return (output, epsilon, a, mu, log_var) if get_target else output
+
+
+class Diff(nn.Module):
+    """models.py:726-779 with the image-space UNet (the latent MLP lives in latent.py)."""
+
+    def __init__(self, args, device, shape):
+        super().__init__()
+        self.device = device
+        self.alpha_bars, self.betas, self.alphas, self.alpha_prev_bars = _schedule(args, device)
+        self.is_latent = args.is_latent or args.mode == 'train_latent_ddim'
+        ch_mult = [1, 2, 4] if args.input_size == 28 else [1, 2, 4, 8]
+        if self.is_latent:
+            from .latent import LatentUNet
+            self.backbone = LatentUNet(T=args.diffusion_steps, num_layers=10, dropout=0.1, shape=shape,
+                                       activation='silu')
+        else:
+            self.backbone = UNet(ch_mult=ch_mult, T=args.diffusion_steps, ch=args.unets_channels, shape=shape)
+            self.backbone.ctx.act_dtype = _act_dtype(args)
+        self.act_dtype = torch.float32 if self.is_latent else _act_dtype(args)
+        self._qs_tables = ops.qsample_tables(self.alpha_bars)
+        self.to(device)
+
+    def loss_fn(self, args, x, idx=None, curr_epoch=0):
+        output, epsilon = self.forward(x, idx=idx, get_target=True)
+        return (output.float() - epsilon).square().mean()
+
+    def forward(self, x, idx=None, get_target=False):
+        if idx is None:
+            idx = torch.randint(0, len(self.alpha_bars), (x.size(0),)).to(device=self.device)
+            epsilon = torch.randn_like(x)
+            if self.is_latent:
+                x_tilde = ops.q_sample(x[:, :, None, None], epsilon[:, :, None, None], idx, self._qs_tables,
+                                       torch.float32)[:, :, 0, 0]
+            else:
+                x_tilde = ops.q_sample(x, epsilon, idx, self._qs_tables, self.act_dtype)
+        else:
+            if not torch.is_tensor(idx):
+                idx = torch.full((x.size(0),), int(idx), dtype=torch.long, device=self.device)
+            x_tilde = x
+        output = self.backbone(x_tilde, idx)
+        return (output, epsilon) if get_target else output

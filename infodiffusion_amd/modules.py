@@ -1,0 +1,296 @@
+"""NN blocks of the AVDM UNet on the HIP kernels (mirror of the reference's
+modules.py: same class names, constructor arguments, module tree and therefore
+state_dict keys; forward passes are re-designed around fused NHWC kernels).
+
+Stock `nn.Conv2d / nn.GroupNorm / nn.Linear / nn.Embedding` objects are kept only
+as *parameter holders* (so checkpoints interchange with the reference and the
+initial weights under a seed are identical); their own forward is never called.
+Every block computes
+
+    conv( dropout( SiLU( GroupNorm(x) [* (1+s_t) + b_t] [* (1+s_a) + b_a] ) ) ) + bias [+ residual]
+
+as ONE conv launch whose input staging applies the per-(sample, channel) affine
+that `idf_gn_coef_fwd` folds from the GroupNorm statistics and the FiLM pairs.
+"""
+import math
+import types
+from typing import Union
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import ops
+
+_ACT_NONE, _ACT_AFFINE, _ACT_SILU = 0, 1, 2
+
+
+class RunCtx(types.SimpleNamespace):
+    """Per-network run state shared by reference (not a Module): the activation
+    dtype and the current step's dropout seed (1-element int64 CUDA tensor or None)."""
+
+    def __init__(self, act_dtype=torch.float32):
+        super().__init__(act_dtype=act_dtype, seed=None)
+
+
+class _Shadows:
+    """Cached kernel-layout copies of conv weights, rebuilt when a master weight
+    changes (optimizer step / load_state_dict bump `_version`)."""
+
+    def __init__(self, *convs):
+        self.convs = convs
+        self.key = None
+        self.val = [None, None]
+
+    def weight(self):
+        if len(self.convs) == 1:
+            return self.convs[0].weight
+        return torch.cat([c.weight for c in self.convs], dim=0)
+
+    def bias(self):
+        if len(self.convs) == 1:
+            return self.convs[0].bias
+        return torch.cat([c.bias for c in self.convs], dim=0)
+
+    def __call__(self, dtype, need_dgrad):
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
+        if key != self.key:
+            self.key, self.val = key, [None, None]
+        if self.val[0] is None or (need_dgrad and self.val[1] is None):
+            with torch.no_grad():
+                wf, wd = ops.pack_weight(self.weight(), dtype, self.val[0] is None, need_dgrad)
+            if wf is not None:
+                self.val[0] = wf
+            if wd is not None:
+                self.val[1] = wd
+        return self.val
+
+
+def _cfg(shadows, mode, taps, act, p_drop=0.0, salt=0):
+    return dict(shadows=shadows, mode=mode, taps=taps, act=act, p_drop=p_drop, salt=salt)
+
+
+def _xavier_all(module):
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            init.xavier_uniform_(m.weight)
+            init.zeros_(m.bias)
+
+
+class TimeEmbedding(nn.Module):
+    """modules.py:9-38: frozen interleaved sin/cos table -> Linear -> SiLU -> Linear."""
+
+    def __init__(self, T, d_model, dim):
+        assert d_model % 2 == 0
+        super().__init__()
+        freq = torch.exp(-(torch.arange(0, d_model, step=2) / torch.Tensor([d_model]) * math.log(10000)))
+        ang = torch.arange(T).float()[:, None] * freq[None, :]
+        table = torch.stack([torch.sin(ang), torch.cos(ang)], dim=-1).view(T, d_model)
+        self.timembedding = nn.Sequential(
+            nn.Embedding.from_pretrained(table), nn.Linear(d_model, dim), nn.SiLU(), nn.Linear(dim, dim))
+        _xavier_all(self)
+
+    def forward(self, t):
+        tab, l1, _, l2 = self.timembedding
+        e = ops.gather_rows(tab.weight, t)
+        e = ops.linear(e, l1.weight, l1.bias)
+        return ops.linear(e, l2.weight, l2.bias, silu_in=True)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """modules.py:41-60 ([cos..., sin...]); host-side torch, used by LatentUNet only."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) /
+                      half).to(device=timesteps.device)
+    ang = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class DownSample(nn.Module):
+    """modules.py:63-75: conv3x3 stride 2."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.main = nn.Conv2d(in_ch, in_ch, 3, stride=2, padding=1)
+        _xavier_all(self)
+        self._cfg = _cfg(_Shadows(self.main), ops.S2, 9, _ACT_NONE)
+
+    def forward(self, x, temb=None, aemb=None):
+        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg)
+
+
+class UpSample(nn.Module):
+    """modules.py:78-93: nearest x2 then conv3x3 -- the upsample is folded into the
+    conv's read addressing, the 4x tensor never exists."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.main = nn.Conv2d(in_ch, in_ch, 3, stride=1, padding=1)
+        _xavier_all(self)
+        self._cfg = _cfg(_Shadows(self.main), ops.UP2, 9, _ACT_NONE)
+
+    def forward(self, x, temb=None, aemb=None):
+        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg)
+
+
+class AttnBlock(nn.Module):
+    """modules.py:129-164: GN -> q,k,v 1x1 -> softmax(q k^T / sqrt(C)) v -> 1x1 proj -> + x.
+    q,k,v run as one GN-prologue 1x1 conv with the three weights concatenated."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, in_ch)
+        self.proj_q = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_k = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_v = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.initialize()
+        self._qkv = _Shadows(self.proj_q, self.proj_k, self.proj_v)
+        self._cfg_qkv = _cfg(self._qkv, ops.S1, 1, _ACT_AFFINE)
+        self._cfg_proj = _cfg(_Shadows(self.proj), ops.S1, 1, _ACT_NONE)
+
+    def initialize(self):
+        for m in (self.proj_q, self.proj_k, self.proj_v, self.proj):
+            init.xavier_uniform_(m.weight)
+            init.zeros_(m.bias)
+        init.xavier_uniform_(self.proj.weight, gain=1e-5)
+
+    def forward(self, x):
+        gn = self.group_norm
+        qkv = ops.fused_conv(x, self._qkv.weight(), self._qkv.bias(), self._cfg_qkv, gn.weight, gn.bias)
+        o = ops.attention(qkv)
+        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x)
+
+
+class CrossAttnBlock(nn.Module):
+    """modules.py:167-203.  Constructed by every AuxResBlock but never executed by
+    the reference (crossattn=False at every call site); kept for its state_dict keys."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, in_ch)
+        self.proj_q = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_k = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_v = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        AttnBlock.initialize(self)
+
+    def forward(self, x, a):
+        raise NotImplementedError('CrossAttnBlock is dead code in the reference (never executed)')
+
+
+def _gn_act_conv(in_ch, out_ch, dropout=None):
+    layers = [nn.GroupNorm(32, in_ch), nn.SiLU()]
+    if dropout is not None:
+        layers.append(nn.Dropout(dropout))
+    layers.append(nn.Conv2d(in_ch, out_ch, 3, stride=1, padding=1))
+    return nn.Sequential(*layers)
+
+
+class _ResBase(nn.Module):
+    """Shared machinery of ResBlock / AuxResBlock / ResBlock_encoder."""
+
+    def _finish_init(self, in_ch, out_ch, attn):
+        self.shortcut = nn.Conv2d(in_ch, out_ch, 1, stride=1, padding=0) if in_ch != out_ch else nn.Identity()
+        self.use_attn = attn
+        self.attn = AttnBlock(out_ch) if attn else nn.Identity()
+
+    def _setup(self, dropout):
+        self.ctx = RunCtx()
+        self.salt = 0
+        self.p_drop = dropout
+        for name in ('block1', 'block2', 'block3'):
+            blk = getattr(self, name, None)
+            if blk is not None:
+                setattr(self, '_sh_' + name, _Shadows(blk[-1]))
+        if isinstance(self.shortcut, nn.Conv2d):
+            self._cfg_sc = _cfg(_Shadows(self.shortcut), ops.S1, 1, _ACT_NONE)
+
+    def _gn_conv(self, name, x, film_t=None, film_a=None, drop_site=None, residual=None):
+        blk = getattr(self, name)
+        gn, conv = blk[0], blk[-1]
+        seed = self.ctx.seed if (drop_site is not None and self.training) else None
+        cfg = _cfg(getattr(self, '_sh_' + name), ops.S1, 9, _ACT_SILU, self.p_drop, self.salt + (drop_site or 0))
+        return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed)
+
+    def _shortcut(self, x):
+        if isinstance(self.shortcut, nn.Conv2d):
+            return ops.fused_conv(x, self.shortcut.weight, self.shortcut.bias, self._cfg_sc)
+        return x
+
+
+class ResBlock(_ResBase):
+    """modules.py:206-258 (vanilla UNet block: FiLM on t only, three 3x3 convs)."""
+
+    def __init__(self, in_ch, out_ch, tdim, dropout, attn=False):
+        super().__init__()
+        self.temb_proj = nn.Sequential(nn.SiLU(), nn.Linear(tdim, 2 * out_ch))
+        self.block1 = _gn_act_conv(in_ch, out_ch)
+        self.block2 = _gn_act_conv(out_ch, out_ch, dropout)
+        self.block3 = _gn_act_conv(out_ch, out_ch, dropout)
+        self._finish_init(in_ch, out_ch, attn)
+        _xavier_all(self)
+        self._setup(dropout)
+
+    def forward(self, x, temb):
+        h = self._gn_conv('block1', x)
+        ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
+        h = self._gn_conv('block2', h, film_t=ft, drop_site=1)
+        h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
+        return self.attn(h)
+
+
+class AuxResBlock(_ResBase):
+    """modules.py:261-328: AdaGN block conditioned on t and on the auxiliary latent a."""
+
+    def __init__(self, in_ch, out_ch, tdim, dropout, attn=False, crossattn: Union[bool, nn.Module] = False):
+        super().__init__()
+        self.block1 = _gn_act_conv(in_ch, out_ch)
+        self.temb_proj = nn.Sequential(nn.SiLU(), nn.Linear(tdim, 2 * out_ch))
+        self.aemb_proj = nn.Sequential(nn.SiLU(), nn.Linear(tdim, 2 * out_ch))
+        self.block2 = _gn_act_conv(out_ch, out_ch, dropout)
+        self.block3 = _gn_act_conv(out_ch, out_ch, dropout)
+        self._finish_init(in_ch, out_ch, attn)
+        self.use_crossattn = bool(crossattn)
+        self.crossattn = CrossAttnBlock(out_ch)
+        _xavier_all(self)   # also resets attn.proj to gain 1 (reference quirk 9)
+        self._setup(dropout)
+
+    def forward(self, x, temb, aemb=None):
+        h = self._gn_conv('block1', x)
+        ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
+        fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
+        h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1)
+        h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
+        h = self.attn(h)
+        if self.use_crossattn:
+            h = self.crossattn(h, aemb)
+        return h
+
+
+class ResBlock_encoder(_ResBase):
+    """modules.py:331-366: unconditioned block, two 3x3 convs."""
+
+    def __init__(self, in_ch, out_ch, dropout, attn=False):
+        super().__init__()
+        self.block1 = _gn_act_conv(in_ch, out_ch)
+        self.block2 = _gn_act_conv(out_ch, out_ch, dropout)
+        self._finish_init(in_ch, out_ch, attn)
+        _xavier_all(self)
+        self._setup(dropout)
+
+    def forward(self, x):
+        h = self._gn_conv('block1', x)
+        h = self._gn_conv('block2', h, drop_site=1, residual=self._shortcut(x))
+        return self.attn(h)
+
+
+def bind_context(net, ctx):
+    """Share one RunCtx across a network and give every dropout site a unique salt."""
+    for i, m in enumerate(net.modules()):
+        if isinstance(m, _ResBase):
+            m.ctx = ctx
+            m.salt = 4 * i

@@ -1,0 +1,421 @@
+"""Host-side operators over the C ABI (include/infodiff_hip.h).
+
+Raw launchers (`*_raw`) take/return torch CUDA tensors whose memory is dense NHWC
+(`channels_last` with the reference's logical NCHW shape) and enqueue on the
+current stream; `torch.autograd.Function`s on top provide backward through the
+hand-written gradient kernels.  There is no non-HIP fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, F32, BF16
+
+GN_EPS = 1e-5
+S1, S2, UP2, T2 = 0, 1, 2, 3
+CL = torch.channels_last
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError('unsupported activation dtype %s' % t.dtype)
+
+
+def _p(t, off=0):
+    if t is None:
+        return None
+    return t.data_ptr() + off * t.element_size()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _nhwc(t):
+    """Dense NHWC memory for a logical NCHW tensor."""
+    if not t.is_cuda:
+        raise RuntimeError('infodiffusion_amd kernels run on the GPU only (got a %s tensor)' % t.device)
+    return t.contiguous(memory_format=CL)
+
+
+def _f32c(t):
+    return None if t is None else t.contiguous().float()
+
+
+def empty_nhwc(B, C, H, W, dtype, device):
+    return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=CL)
+
+
+# ------------------------------------------------------------------ raw calls
+def pack_weight(weight, dtype, want_fwd, want_dgrad):
+    """weight: fp32 [O, I, kh, kw] (any strides with stride[2] == kw*stride[3])."""
+    O, I, kh, kw = weight.shape
+    taps = kh * kw
+    w = weight.detach()
+    if taps > 1 and w.stride(2) != kw * w.stride(3):
+        w = w.contiguous()
+    st = w.stride(3) if taps > 1 else 0
+    wf = torch.empty((O, taps, I), dtype=dtype, device=w.device) if want_fwd else None
+    wd = torch.empty((I, taps, O), dtype=dtype, device=w.device) if want_dgrad else None
+    call('idf_pack_conv_weight', _p(w), w.stride(0), w.stride(1), st, _p(wf), _p(wd), O, I, taps,
+         F32 if dtype == torch.float32 else BF16, _st())
+    return wf, wd
+
+
+def out_hw(mode, H, W):
+    if mode == S2:
+        return (H + 1) // 2, (W + 1) // 2
+    if mode == UP2:
+        return 2 * H, 2 * W
+    return H, W
+
+
+def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
+    """x logical [B,Cin,Hs,Ws] NHWC-dense; w_fwd [Cout][taps][Cin] in x.dtype."""
+    B, Cin, Hs, Ws = x.shape
+    Ho, Wo = out_hw_ if out_hw_ is not None else out_hw(mode, Hs, Ws)
+    y = empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+    call('idf_conv2d_fwd', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), _p(sc), _p(sh), _p(seed),
+         salt, float(p_drop), B, Hs, Ws, Cin, Ho, Wo, Cout, mode, taps, act, _dt(x), _st())
+    return y
+
+
+def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape):
+    """Data gradient w.r.t. the (activated) conv input of logical shape x_shape."""
+    B, Cin, Hs, Ws = x_shape
+    if mode_fwd == S2:
+        return conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, T2, taps, 0, Cin, (Hs, Ws))
+    if mode_fwd == UP2:
+        up = conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, S1, taps, 0, Cin)
+        out = empty_nhwc(B, Cin, Hs, Ws, dy.dtype, dy.device)
+        call('idf_pool2_sum', _p(up), _p(out), B, Hs, Ws, Cin, _dt(dy), _st())
+        return out
+    return conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, S1, taps, 0, Cin)
+
+
+def conv_wgrad_raw(x, dy, sc, sh, seed, salt, p_drop, mode, taps, act):
+    """Returns fp32 dW with logical shape [O, I, kh, kw] and memory [O][taps][I]."""
+    B, Cin, Hs, Ws = x.shape
+    _, Cout, Ho, Wo = dy.shape
+    k = 3 if taps == 9 else 1
+    dW = torch.empty((Cout, k, k, Cin), dtype=torch.float32, device=x.device)
+    call('idf_conv2d_wgrad', _p(x), _p(dy), _p(dW), _p(sc), _p(sh), _p(seed), salt, float(p_drop),
+         B, Hs, Ws, Cin, Ho, Wo, Cout, mode, taps, act, _dt(x), _st())
+    return dW.permute(0, 3, 1, 2)
+
+
+def colsum_raw(t2d):
+    """fp32 column sums of a [R, N] view (fp32 or bf16, dense)."""
+    R, N = t2d.shape
+    nb = _lib.load().idf_colsum_blocks(R)
+    ws = torch.empty((nb * N,), dtype=torch.float32, device=t2d.device)
+    out = torch.empty((N,), dtype=torch.float32, device=t2d.device)
+    call('idf_colsum', _p(t2d), _p(out), _p(ws), R, N, _dt(t2d), _st())
+    return out
+
+
+def gn_coef_fwd_raw(x, gamma, beta, film_t, film_a):
+    B, C, H, W = x.shape
+    dev = x.device
+    mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    sc = torch.empty((B, C), dtype=torch.float32, device=dev)
+    sh = torch.empty((B, C), dtype=torch.float32, device=dev)
+    ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
+    call('idf_gn_coef_fwd', _p(x), _p(gamma), _p(beta), _p(film_t), _p(film_a), GN_EPS, _p(mean), _p(rstd),
+         _p(sc), _p(sh), _p(ws), B, H * W, C, _dt(x), _st())
+    return mean, rstd, sc, sh
+
+
+def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act):
+    B, C, H, W = x.shape
+    dev = x.device
+    dx = torch.empty_like(x, memory_format=CL)
+    dft = torch.empty_like(film_t) if film_t is not None else None
+    dfa = torch.empty_like(film_a) if film_a is not None else None
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+    k1 = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    k0 = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
+    call('idf_gn_coef_bwd', _p(dA), _p(x), _p(dres), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a),
+         _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(k1), _p(k0), _p(ws), _p(seed),
+         salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
+    dgam = colsum_raw(dgb)
+    return dx, dgam[:C], dgam[C:], dft, dfa
+
+
+def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, ldc, M, N, K, ta, tb,
+              alpha=1.0, out_f32=False, splitk=1, dtype=None):
+    call('idf_bgemm', _p(A, offA), _p(B_, offB), _p(Cout, offC), _p(bias), batch, sA, sB, sC, lda, ldb, ldc,
+         M, N, K, ta, tb, float(alpha), int(out_f32), splitk, _dt(A) if dtype is None else dtype, _st())
+
+
+# ------------------------------------------------------------- fused conv op
+class _FusedConv(torch.autograd.Function):
+    """y = conv(act(GN/FiLM(x))) + bias (+ residual);  act per `cfg`.
+
+    cfg = dict(mode, taps, act, p_drop, salt, shadows) where shadows() returns the
+    (forward, data-gradient) weight shadows in the activation dtype.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg):
+        x = _nhwc(x)
+        residual = _nhwc(residual) if residual is not None else None
+        act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
+        p_drop = cfg['p_drop'] if seed is not None else 0.0
+        mean = rstd = sc = sh = None
+        if act:
+            mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
+        w_fwd = cfg['shadows'](x.dtype, False)[0]
+        y = conv_raw(x, w_fwd, bias, residual, sc, sh, seed, cfg['salt'], p_drop, mode, taps, act,
+                     weight.shape[0])
+        ctx.cfg, ctx.p_drop = cfg, p_drop
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
+        cfg, p_drop = ctx.cfg, ctx.p_drop
+        act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
+        dy = _nhwc(dy.to(x.dtype))
+        need = ctx.needs_input_grad
+        dW = db = dx = dgw = dgb = dft = dfa = dres = None
+        if need[1]:
+            dW = conv_wgrad_raw(x, dy, sc, sh, seed, salt, p_drop, mode, taps, act)
+        if bias is not None and need[2]:
+            B, Co, Ho, Wo = dy.shape
+            db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
+        if need[0] or (act and (need[3] or need[5] or need[6])):
+            w_dgrad = cfg['shadows'](x.dtype, True)[1]
+            dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
+            if act:
+                dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, None, gn_w, gn_b, film_t, film_a, mean, rstd,
+                                                         sc, sh, seed, salt, p_drop, act)
+            else:
+                dx = dA
+        if ctx.has_res and need[7]:
+            dres = dy
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None
+
+
+def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None):
+    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg)
+
+
+# ------------------------------------------------------------------ attention
+class _Attention(torch.autograd.Function):
+    """qkv [B, 3C, H, W] (NHWC-dense: [B, N, 3C]) -> softmax(q k^T C^-1/2) v as [B, C, H, W]."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        qkv = _nhwc(qkv)
+        B, C3, H, W = qkv.shape
+        C, N = C3 // 3, H * W
+        dev, dt = qkv.device, qkv.dtype
+        S = torch.empty((B, N, N), dtype=dt, device=dev)
+        bgemm_raw(qkv, 0, qkv, C, S, 0, None, B, N * C3, N * C3, N * N, C3, C3, N, N, N, C, 0, 0,
+                  alpha=float(int(C) ** (-0.5)))
+        call('idf_softmax_fwd', _p(S), B * N, N, _dt(S), _st())
+        o = empty_nhwc(B, C, H, W, dt, dev)
+        bgemm_raw(S, 0, qkv, 2 * C, o, 0, None, B, N * N, N * C3, N * C, N, C3, C, N, C, N, 0, 1)
+        ctx.save_for_backward(qkv, S)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P = ctx.saved_tensors
+        B, C3, H, W = qkv.shape
+        C, N = C3 // 3, H * W
+        do = _nhwc(do.to(qkv.dtype))
+        scale = float(int(C) ** (-0.5))
+        dqkv = torch.empty_like(qkv, memory_format=CL)
+        # dV = P^T dO
+        bgemm_raw(P, 0, do, 0, dqkv, 2 * C, None, B, N * N, N * C, N * C3, N, C, C3, N, C, N, 1, 1)
+        # dP = dO V^T
+        dP = torch.empty_like(P)
+        bgemm_raw(do, 0, qkv, 2 * C, dP, 0, None, B, N * C, N * C3, N * N, C, C3, N, N, N, C, 0, 0)
+        call('idf_softmax_bwd', _p(P), _p(dP), B * N, N, _dt(P), _st())
+        # dQ = scale * dS K ; dK = scale * dS^T Q
+        bgemm_raw(dP, 0, qkv, C, dqkv, 0, None, B, N * N, N * C3, N * C3, N, C3, C3, N, C, N, 0, 1, alpha=scale)
+        bgemm_raw(dP, 0, qkv, 0, dqkv, C, None, B, N * N, N * C3, N * C3, N, C3, C3, N, C, N, 1, 1, alpha=scale)
+        return dqkv
+
+
+def attention(qkv):
+    return _Attention.apply(qkv)
+
+
+# --------------------------------------------------------------------- linear
+class _Linear(torch.autograd.Function):
+    """y = silu?(x) @ W^T + b, fp32 [B, K] -> [B, N]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, silu_in):
+        x = _f32c(x)
+        if not x.is_cuda:
+            raise RuntimeError('infodiffusion_amd kernels run on the GPU only')
+        w = _f32c(weight)
+        xs = x
+        if silu_in:
+            xs = torch.empty_like(x)
+            call('idf_silu_fwd', _p(x), _p(xs), x.numel(), _st())
+        Bn, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((Bn, N), dtype=torch.float32, device=x.device)
+        bgemm_raw(xs, 0, w, 0, y, 0, _f32c(bias), 1, 0, 0, 0, K, K, N, Bn, N, K, 0, 0, dtype=F32)
+        ctx.silu_in = silu_in
+        ctx.save_for_backward(x, xs, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xs, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        Bn, K = x.shape
+        N = w.shape[0]
+        need = ctx.needs_input_grad
+        dx = dW = db = None
+        if need[0]:
+            dxs = torch.empty_like(x)
+            bgemm_raw(dy, 0, w, 0, dxs, 0, None, 1, 0, 0, 0, N, K, K, Bn, K, N, 0, 1, dtype=F32)
+            if ctx.silu_in:
+                dx = torch.empty_like(x)
+                call('idf_silu_bwd', _p(x), _p(dxs), _p(dx), x.numel(), _st())
+            else:
+                dx = dxs
+        if need[1]:
+            dW = torch.empty_like(w)
+            bgemm_raw(dy, 0, xs, 0, dW, 0, None, 1, 0, 0, 0, N, K, K, N, K, Bn, 1, 1, dtype=F32)
+        if need[2]:
+            db = colsum_raw(dy)
+        return dx, dW, db, None
+
+
+def linear(x, weight, bias=None, silu_in=False):
+    return _Linear.apply(x, weight, bias, silu_in)
+
+
+# --------------------------------------------------------- gather / q_sample
+def gather_rows(table, idx):
+    idx = idx.contiguous()
+    out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    call('idf_gather_rows', _p(table), _p(idx), _p(out), idx.numel(), table.shape[1], _st())
+    return out
+
+
+def qsample_tables(alpha_bars):
+    """sqrt(ab), sqrt(1-ab) by the reference's torch CPU ops (models.py:704), on ab's device."""
+    ab = alpha_bars.detach().cpu()
+    return torch.sqrt(ab).to(alpha_bars.device), torch.sqrt(1 - ab).to(alpha_bars.device)
+
+
+def q_sample(x, eps, idx, tables, act_dtype):
+    """models.py:702-704.  x, eps fp32; tables = qsample_tables(alpha_bars).  Returns x_tilde
+    in act_dtype (the fp32 result is bit-identical to the reference's CPU path)."""
+    x, eps = _nhwc(x.float()), _nhwc(eps.float())
+    xt = torch.empty_like(x, dtype=act_dtype, memory_format=CL)
+    per = x.numel() // x.shape[0]
+    call('idf_qsample', _p(x), _p(eps), _p(idx.contiguous()), _p(tables[0]), _p(tables[1]), None, _p(xt), per,
+         x.numel(), F32 if act_dtype == torch.float32 else BF16, _st())
+    return xt
+
+
+# ----------------------------------------------------------------------- loss
+class _DiffLoss(torch.autograd.Function):
+    """(mean((out-eps)^2), mean((x0-x)^2)/T) with x0 from the t=0 constants (models.py:640-646)."""
+
+    @staticmethod
+    def forward(ctx, out, eps, x, c0, c1, inv_T):
+        out, eps, x = _nhwc(out), _nhwc(eps), _nhwc(x)
+        res = torch.empty((2,), dtype=torch.float32, device=out.device)
+        ws = torch.empty((2048,), dtype=torch.float32, device=out.device)
+        call('idf_loss_fwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(res), _p(ws), out.numel(), _dt(out), _st())
+        ctx.k = (c0, c1, inv_T)
+        ctx.save_for_backward(out, eps, x)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        out, eps, x = ctx.saved_tensors
+        c0, c1, inv_T = ctx.k
+        dout = torch.empty_like(out, memory_format=CL)
+        call('idf_loss_bwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(_f32c(g)), _p(dout), out.numel(),
+             _dt(out), _st())
+        return dout, None, None, None, None, None
+
+
+def diff_loss(out, eps, x, c0, c1, inv_T):
+    return _DiffLoss.apply(out, eps, x, float(c0), float(c1), float(inv_T))
+
+
+class _MMD(torch.autograd.Function):
+    """utils.py:85-90; gradient w.r.t. y only (x = prior samples)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _f32c(x), _f32c(y)
+        n, D = x.shape
+        m = y.shape[0]
+        out = torch.empty((1,), dtype=torch.float32, device=y.device)
+        ws = torch.empty((2 * n + m,), dtype=torch.float32, device=y.device)
+        call('idf_mmd_fwd', _p(x), _p(y), n, m, D, _p(out), _p(ws), _st())
+        ctx.save_for_backward(x, y)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        n, D = x.shape
+        m = y.shape[0]
+        dy = torch.empty_like(y)
+        call('idf_mmd_bwd', _p(x), _p(y), n, m, D, _p(_f32c(g).reshape(1)), _p(dy), _st())
+        return None, dy
+
+
+def mmd(x, y):
+    return _MMD.apply(x, y)
+
+
+# ------------------------------------------------------------------- sampler
+def sampler_coef_table(betas, alphas, alpha_bars, alpha_prev_bars, eta=0.01):
+    """[3][T][8] per-step scalars, evaluated with the reference's own 0-dim fp32 torch
+    expressions on the CPU (sampling.py:30,35 / 52,57-58 / 71-72) => bitwise-equal scalars."""
+    b, al, ab, apb = [t.detach().cpu() for t in (betas, alphas, alpha_bars, alpha_prev_bars)]
+    T = len(ab)
+    tab = torch.zeros((3, T, 8), dtype=torch.float32)
+    for idx in range(T):
+        tab[0, idx, 0] = torch.sqrt(1 / al[idx])
+        tab[0, idx, 1] = b[idx] / torch.sqrt(1 - ab[idx])
+        tab[0, idx, 2] = torch.sqrt((1 - apb[idx]) / (1 - ab[idx]) * b[idx])
+        tab[1, idx, 0] = tab[2, idx, 0] = torch.sqrt(1 - apb[idx])
+        tab[1, idx, 1] = tab[2, idx, 1] = torch.sqrt(apb[idx])
+        if idx > 0:
+            sigma = eta * torch.sqrt((1 - apb[idx - 1]) / (1 - ab[idx - 1])) * torch.sqrt(b[idx - 1])
+            tab[1, idx, 4] = torch.sqrt(apb[idx - 1])
+            tab[1, idx, 5] = torch.sqrt(1 - apb[idx - 1] - sigma ** 2)
+            tab[1, idx, 6] = sigma
+        if idx + 1 < T:
+            tab[2, idx, 2] = torch.sqrt(apb[idx + 1])
+            tab[2, idx, 3] = torch.sqrt(1 - apb[idx + 1])
+    return tab.to(alpha_bars.device)
+
+
+def sampler_step(x, eps_hat, noise, idx_t, coef, mode, out_t_dtype=None):
+    """x fp32 state; eps_hat in its own dtype; idx_t: 1-element int64 CUDA tensor;
+    coef = sampler_coef_table(...)[mode].  Returns (x_next fp32, copy in out_t_dtype or None)."""
+    xo = torch.empty_like(x)
+    xo_t = torch.empty_like(x, dtype=out_t_dtype) if (out_t_dtype is not None and out_t_dtype != torch.float32) else None
+    call('idf_sampler_step', _p(x), _p(eps_hat), _p(noise), _p(xo), _p(xo_t), _p(idx_t), _p(coef), mode,
+         x.numel(), _dt(eps_hat), _st())
+    return xo, xo_t
+
+
+def dropout_mask(seed, salt, p, numel):
+    m = torch.empty((numel,), dtype=torch.float32, device=seed.device)
+    call('idf_dropout_mask', _p(seed), salt, float(p), _p(m), numel, _st())
+    return m

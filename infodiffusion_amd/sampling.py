@@ -1,0 +1,186 @@
+"""DDPM / DDIM denoising loops on the HIP kernels (mirror of the reference's
+sampling.py surface: same classes, constructor and method signatures).
+
+Each step = one network evaluation + ONE fused update kernel (`idf_sampler_step`)
+that gathers the step's scalars from a table built once with the reference's own fp32
+expressions and applies them in the reference's operation order, so no host scalar math, no tiny-op swarm and no
+per-step H2D copies remain.  The state `x` is kept in fp32.
+"""
+import torch
+
+from . import ops
+
+_DDPM, _DDIM, _REV = 0, 1, 2
+ETA = 0.01     # sampling.py:45
+
+
+def _tables(args, device):
+    """sampling.py:12-15 (same torch CPU ops; betas/alphas also moved to the device)."""
+    T = args.diffusion_steps
+    betas = torch.linspace(start=args.beta1, end=args.betaT, steps=T)
+    alphas = 1 - betas
+    alpha_bars = torch.cumprod(1 - torch.linspace(start=args.beta1, end=args.betaT, steps=T), dim=0)
+    alpha_prev_bars = torch.cat([torch.Tensor([1]), alpha_bars[:-1]])
+    return tuple(t.to(device=device).contiguous() for t in (betas, alphas, alpha_bars, alpha_prev_bars))
+
+
+class _ProcessBase:
+    def _init_common(self, args, device):
+        self.betas, self.alphas, self.alpha_bars, self.alpha_prev_bars = _tables(args, device)
+        self.deterministic = args.deterministic
+        self.a_dim = args.a_dim
+        self.model = args.model
+        self.device = device
+        self._steps = torch.arange(len(self.alpha_bars), dtype=torch.long, device=device)
+        self._coef = ops.sampler_coef_table(self.betas, self.alphas, self.alpha_bars, self.alpha_prev_bars, ETA)
+
+    # hooks (tests override to inject the reference's noise draws)
+    def _randn_like(self, x):
+        return torch.randn_like(x)
+
+    def _sched(self):
+        return (self.betas, self.alphas, self.alpha_bars, self.alpha_prev_bars)
+
+    def _update(self, x, eps_hat, idx, mode, noise):
+        x = x.float()
+        if x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+            eps_hat = eps_hat.contiguous(memory_format=torch.channels_last)
+            if noise is not None:
+                noise = noise.float().contiguous(memory_format=torch.channels_last)
+        else:
+            x, eps_hat = x.contiguous(), eps_hat.contiguous()
+        xo, _ = ops.sampler_step(x, eps_hat, noise, self._steps[idx:idx + 1], self._coef[mode], mode)
+        return xo
+
+    def _loop(self, x, eps_fn, deterministic):
+        for idx in reversed(range(len(self.alpha_bars))):
+            if deterministic:
+                eps_hat = eps_fn(x, idx)
+                noise = None if idx == 0 else self._randn_like(x)
+                x = self._update(x, eps_hat, idx, _DDIM, noise)
+            else:
+                noise = None if idx == 0 else self._randn_like(x)   # reference draws before the net call
+                eps_hat = eps_fn(x, idx)
+                x = self._update(x, eps_hat, idx, _DDPM, noise)
+            yield x
+
+    def _reverse_loop(self, x, eps_fn):
+        for idx in range(len(self.alpha_bars) - 1):
+            if idx > 0:
+                x = self._update(x, eps_fn(x, idx), idx, _REV, None)
+            yield x
+
+
+class DiffusionProcess(_ProcessBase):
+    """sampling.py:3-101."""
+
+    def __init__(self, args, diffusion_fn, device, shape):
+        self._init_common(args, device)
+        self.shape = shape
+        self.diffusion_fn = diffusion_fn.to(device=device)
+
+    def _eps(self, a):
+        if self.model == 'vanilla':
+            return lambda x, idx: self.diffusion_fn(x, idx)
+        return lambda x, idx: self.diffusion_fn(x, idx, a)
+
+    def _ddpm_one_diffusion_step(self, x, a=None):
+        return self._loop(x, self._eps(a), False)
+
+    def _ddim_one_diffusion_step(self, x, a=None):
+        return self._loop(x, self._eps(a), True)
+
+    def _ddim_one_reverse_diffusion_step(self, x, a=None):
+        return self._reverse_loop(x, self._eps(a))
+
+    def _one_diffusion_step(self, sample, a=None, deterministic=False):
+        return self._loop(sample, self._eps(a), bool(deterministic))
+
+    @torch.no_grad()
+    def reverse_sampling(self, x0, a=None):
+        # sampling.py:84 passes only `sample`: `a` is dropped and the model re-encodes x_t each step
+        final = x0
+        for sample in self._ddim_one_reverse_diffusion_step(x0):
+            final = sample
+        return final
+
+    @torch.no_grad()
+    def sampling(self, sampling_number=16, xT=None, a=None):
+        if xT is None:
+            xT = torch.randn([sampling_number, *self.shape]).to(device=self.device)
+        if self.model != 'vanilla' and a is None:
+            a = torch.randn([sampling_number, self.a_dim]).to(device=self.device)
+        final = xT
+        for sample in self._one_diffusion_step(sample=xT, a=a, deterministic=self.deterministic):
+            final = sample
+        return final
+
+
+class TwoPhaseDiffusionProcess(_ProcessBase):
+    """sampling.py:104-204.  As executed by the reference, `t` is captured by value
+    (sampling.py:199-202) and stays 0 <= split_step, so EVERY step calls
+    diffusion_fn_2(x, idx) -- reproduced here."""
+
+    def __init__(self, args, diffusion_fn_1, diffusion_fn_2, device, shape):
+        self._init_common(args, device)
+        self.shape = shape
+        self.split_step = args.split_step
+        self.mode = args.mode
+        self.diffusion_fn_1 = diffusion_fn_1.to(device=device)
+        self.diffusion_fn_2 = diffusion_fn_2.to(device=device)
+
+    def _eps(self, a, t):
+        if t <= self.split_step:
+            return lambda x, idx: self.diffusion_fn_2(x, idx)
+        return lambda x, idx: self.diffusion_fn_1(x, idx, a)
+
+    def _one_diffusion_step(self, sample, a=None, deterministic=False, t=None):
+        return self._loop(sample, self._eps(a, t), bool(deterministic))
+
+    @torch.no_grad()
+    def reverse_sampling(self, x0, a=None):
+        final = x0
+        for sample in self._reverse_loop(x0, lambda x, idx: self.diffusion_fn_1(x, idx, None)):
+            final = sample
+        return final
+
+    @torch.no_grad()
+    def sampling(self, sampling_number=16, xT=None, a=None):
+        if xT is None:
+            xT = torch.randn([sampling_number, *self.shape]).to(device=self.device)
+        if a is None:
+            a = torch.randn([sampling_number, self.a_dim]).to(device=self.device)
+        final = xT
+        for sample in self._one_diffusion_step(sample=xT, a=a, deterministic=self.deterministic, t=0):
+            final = sample
+        return final
+
+
+class LatentDiffusionProcess(_ProcessBase):
+    """sampling.py:207-292: the same loops on [B, a_dim] latents."""
+
+    def __init__(self, args, diffusion_fn, device):
+        self._init_common(args, device)
+        self.split_step = args.split_step
+        self.mode = args.mode
+        self.diffusion_fn = diffusion_fn.to(device=device)
+
+    def _one_diffusion_step(self, sample, deterministic=False):
+        return self._loop(sample, lambda x, idx: self.diffusion_fn(x, idx), bool(deterministic))
+
+    @torch.no_grad()
+    def reverse_sampling(self, x0):
+        final = x0
+        for sample in self._reverse_loop(x0, lambda x, idx: self.diffusion_fn(x, idx)):
+            final = sample
+        return final
+
+    @torch.no_grad()
+    def sampling(self, sampling_number=16, xT=None):
+        if xT is None:
+            xT = torch.randn([sampling_number, self.a_dim]).to(device=self.device)
+        final = xT
+        for sample in self._one_diffusion_step(sample=xT, deterministic=self.deterministic):
+            final = sample
+        return final

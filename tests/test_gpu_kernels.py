@@ -1,0 +1,188 @@
+"""GPU parity tests of the raw HIP kernels (through the C ABI) against plain
+PyTorch fp32 references computed on the host."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from infodiffusion_amd import ops  # noqa: E402
+
+CL = torch.channels_last
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rnd(seed, *shape):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [
+    # (B, Cin, H, W, Cout, taps, mode)
+    (2, 64, 16, 16, 64, 9, ops.S1), (3, 128, 8, 8, 128, 9, ops.S1), (2, 192, 8, 8, 64, 9, ops.S1),
+    (2, 64, 16, 16, 64, 9, ops.S2), (2, 64, 8, 8, 64, 9, ops.UP2), (2, 128, 8, 8, 384, 1, ops.S1),
+    (2, 3, 16, 16, 64, 9, ops.S1), (2, 64, 16, 16, 3, 9, ops.S1), (2, 1, 32, 32, 32, 9, ops.S1),
+    (2, 32, 8, 8, 1, 9, ops.S1), (5, 96, 4, 4, 32, 9, ops.S1), (2, 256, 32, 32, 128, 9, ops.S1),
+])
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    B, Cin, H, W, Cout, taps, mode = case
+    k = 3 if taps == 9 else 1
+    x = rnd(1, B, Cin, H, W)
+    w = rnd(2, Cout, Cin, k, k) / (Cin * taps) ** 0.5
+    b = rnd(3, Cout)
+    xq = x.to(dtype).float()
+    wq = w.to(dtype).float()
+    xin = F.interpolate(xq, scale_factor=2.0, mode='nearest') if mode == ops.UP2 else xq
+    xin = xin.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wr, b, stride=2 if mode == ops.S2 else 1, padding=k // 2)
+    res = rnd(4, *ref.shape).to(dtype).float()
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=CL)
+    wf, wd = ops.pack_weight(w.to(DEV), dtype, True, True)
+    y = ops.conv_raw(xd, wf, b.to(DEV), res.to(DEV).to(dtype).contiguous(memory_format=CL), None, None, None, 0,
+                     0.0, mode, taps, 0, Cout)
+    assert y.shape == ref.shape
+    assert rel(y, ref + res) < TOL[dtype]
+    gy = rnd(5, *ref.shape).to(dtype).float()
+    ref.backward(gy)
+    gyd = gy.to(DEV).to(dtype).contiguous(memory_format=CL)
+    dx = ops.conv_dgrad_raw(gyd, wd, mode, taps, x.shape)
+    gx_ref = xin.grad
+    if mode == ops.UP2:
+        gx_ref = gx_ref.view(B, Cin, H, 2, W, 2).sum(dim=(3, 5))
+    assert rel(dx, gx_ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    dW = ops.conv_wgrad_raw(xd, gyd, None, None, None, 0, 0.0, mode, taps, 0)
+    assert dW.shape == w.shape
+    assert rel(dW, wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,H', [(64, 16), (192, 8), (128, 4), (32, 32), (256, 8)])
+def test_gn_film_silu_conv_prologue(C, H, dtype):
+    """GroupNorm + FiLM(t) + FiLM(a) + SiLU folded into the conv staging, fwd + bwd."""
+    B, Cout = 3, 64
+    x = (rnd(1, B, C, H, H) * 1.5 + 0.3).to(dtype).float()
+    gam, bet = 1 + 0.1 * rnd(2, C), 0.1 * rnd(3, C)
+    ft, fa = 0.3 * rnd(4, B, 2 * C), 0.3 * rnd(5, B, 2 * C)
+    w = (rnd(6, Cout, C, 3, 3) / (9 * C) ** 0.5).to(dtype).float()
+    leaves = [t.clone().requires_grad_(True) for t in (x, gam, bet, ft, fa, w)]
+    xr, gr, br, ftr, far, wr = leaves
+    h = F.group_norm(xr, 32, gr, br, 1e-5)
+    st, bt = torch.chunk(ftr[:, :, None, None], 2, dim=1)
+    h = h * (1 + st) + bt
+    sa, ba = torch.chunk(far[:, :, None, None], 2, dim=1)
+    h = h * (1 + sa) + ba
+    ref = F.conv2d(F.silu(h), wr, None, padding=1)
+    gy = rnd(7, *ref.shape).to(dtype).float()
+    ref.backward(gy)
+
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=CL)
+    g = lambda t: t.to(DEV).contiguous()
+    mean, rstd, sc, sh = ops.gn_coef_fwd_raw(xd, g(gam), g(bet), g(ft), g(fa))
+    wf, wd = ops.pack_weight(w.to(DEV), dtype, True, True)
+    y = ops.conv_raw(xd, wf, None, None, sc, sh, None, 0, 0.0, ops.S1, 9, 2, Cout)
+    tol = TOL[dtype]
+    assert rel(y, ref) < tol
+    gyd = gy.to(DEV).to(dtype).contiguous(memory_format=CL)
+    dA = ops.conv_dgrad_raw(gyd, wd, ops.S1, 9, x.shape)
+    dx, dgam, dbet, dft, dfa = ops.gn_coef_bwd_raw(dA, xd, None, g(gam), g(bet), g(ft), g(fa), mean, rstd, sc, sh,
+                                                  None, 0, 0.0, 2)
+    btol = 3e-4 if dtype == torch.float32 else 4e-2
+    assert rel(dx, xr.grad) < btol
+    assert rel(dgam, gr.grad) < btol
+    assert rel(dbet, br.grad) < btol
+    assert rel(dft, ftr.grad) < btol
+    assert rel(dfa, far.grad) < btol
+    dW = ops.conv_wgrad_raw(xd, gyd, sc, sh, None, 0, 0.0, ops.S1, 9, 2)
+    assert rel(dW, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_dropout_mask_consistency():
+    """The conv prologue, the wgrad recompute and the GN backward all apply the
+    mask `idf_dropout_mask` exports; keep-rate matches p."""
+    B, C, H, Cout = 2, 64, 8, 64
+    dtype = torch.float32
+    x = rnd(1, B, C, H, H)
+    w = rnd(6, Cout, C, 3, 3) / (9 * C) ** 0.5
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    xd = x.to(DEV).contiguous(memory_format=CL)
+    ones = torch.ones(C, device=DEV)
+    zeros = torch.zeros(C, device=DEV)
+    mean, rstd, sc, sh = ops.gn_coef_fwd_raw(xd, ones, zeros, None, None)
+    mask = ops.dropout_mask(seed, 7, 0.1, x.numel()).view(B, H, H, C).permute(0, 3, 1, 2).cpu()
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - 0.9) < 0.02
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(F.silu(F.group_norm(xr, 32, None, None, 1e-5)) * mask, wr, None, padding=1)
+    wf, wd = ops.pack_weight(w.to(DEV), dtype, True, True)
+    y = ops.conv_raw(xd, wf, None, None, sc, sh, seed, 7, 0.1, ops.S1, 9, 2, Cout)
+    assert rel(y, ref) < 2e-5
+    gy = rnd(7, *ref.shape)
+    ref.backward(gy)
+    gyd = gy.to(DEV).contiguous(memory_format=CL)
+    dA = ops.conv_dgrad_raw(gyd, wd, ops.S1, 9, x.shape)
+    dx = ops.gn_coef_bwd_raw(dA, xd, None, ones, zeros, None, None, mean, rstd, sc, sh, seed, 7, 0.1, 2)[0]
+    assert rel(dx, xr.grad) < 3e-4
+    dW = ops.conv_wgrad_raw(xd, gyd, sc, sh, seed, 7, 0.1, ops.S1, 9, 2)
+    assert rel(dW, wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (2, 64, 4)])
+def test_attention(B, C, H, dtype):
+    qkv = rnd(1, B, 3 * C, H, H).to(dtype).float()
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = [t.permute(0, 2, 3, 1).reshape(B, H * H, C) for t in torch.chunk(qr, 3, dim=1)]
+    w = F.softmax(torch.bmm(q, k.transpose(1, 2)) * (int(C) ** (-0.5)), dim=-1)
+    ref = torch.bmm(w, v).view(B, H, H, C).permute(0, 3, 1, 2)
+    go = rnd(2, *ref.shape).to(dtype).float()
+    ref.backward(go)
+    qd = qkv.to(DEV).to(dtype).contiguous(memory_format=CL).requires_grad_(True)
+    o = ops.attention(qd)
+    assert rel(o, ref) < TOL[dtype]
+    o.backward(go.to(DEV).to(dtype).contiguous(memory_format=CL))
+    assert rel(qd.grad, qr.grad) < (1e-4 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize('B,K,N,silu', [(32, 256, 256, True), (3, 64, 256, False), (5, 4096, 32, False),
+                                        (7, 32, 128, True), (32, 256, 4992, True)])
+def test_linear(B, K, N, silu):
+    x, w, b = rnd(1, B, K), rnd(2, N, K) / K ** 0.5, rnd(3, N)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = F.linear(F.silu(xr) if silu else xr, wr, br)
+    gy = rnd(4, B, N)
+    ref.backward(gy)
+    xd, wd_, bd = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+    y = ops.linear(xd, wd_, bd, silu)
+    assert rel(y, ref) < 2e-5
+    y.backward(gy.to(DEV))
+    assert rel(xd.grad, xr.grad) < 5e-5
+    assert rel(wd_.grad, wr.grad) < 5e-5
+    assert rel(bd.grad, br.grad) < 5e-5
+
+
+def test_qsample_bit_exact_and_gather():
+    T = 1000
+    ab = torch.cumprod(1 - torch.linspace(start=1e-5, end=1e-2, steps=T), dim=0)
+    x, eps = rnd(1, 4, 3, 16, 16), rnd(2, 4, 3, 16, 16)
+    idx = torch.tensor([0, 17, 500, 999])
+    used = ab[idx][:, None, None, None]
+    ref = torch.sqrt(used) * x + torch.sqrt(1 - used) * eps
+    xt = ops.q_sample(x.to(DEV), eps.to(DEV), idx.to(DEV), ops.qsample_tables(ab.to(DEV)), torch.float32)
+    assert torch.equal(xt.cpu(), ref)
+    table = rnd(3, T, 64)
+    out = ops.gather_rows(table.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), table[idx])
+
+

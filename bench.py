@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Headline benchmark: InfoDiffusion CelebA 64x64 training throughput (images/s) on
+N MI355X, one process per GPU, data-parallel over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = `InfoDiff.loss_fn` (q_sample + encoder + AdaGN UNet + eps-MSE + recon + MMD)
+forward, backward, gradient all-reduce (N > 1), clip_grad_norm_(1.0), AdamW --
+BASELINE.json configs[1]: CelebA 3x64x64, a_dim 32, mmd_weight 0.1, B = 32 per GPU,
+T = 1000, dropout 0.1, bf16 activations.  Random-pixel batches resident in HBM.
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, HIP-event
+timed), `cpu_baseline` (the CPU oracle on the host cores, rank 0 at N = 1),
+`sampling` (DDIM-100 images/s, N = 1 only, --sampling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (reference run.sh: 32)')
+    ap.add_argument('--a_dim', type=int, default=32)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--sampling', action='store_true', help='also time DDIM-100 sampling (B=256)')
+    ap.add_argument('--sampling-batch', type=int, default=256)
+    return ap.parse_args()
+
+
+def make_args(a):
+    from types import SimpleNamespace
+    return SimpleNamespace(beta1=1e-5, betaT=1e-2, diffusion_steps=1000, input_size=64, input_channels=3,
+                           is_bottleneck=False, unets_channels=64, encoder_channels=64, a_dim=a.a_dim,
+                           mmd_weight=0.1, kld_weight=0.0, prior='regular', batch_size=a.batch, use_C=False,
+                           C_max=25.0, epochs=50, deterministic=True, model='diff', split_step=500, mode='train',
+                           is_latent=False, act_dtype=a.dtype, dataset='celeba')
+
+
+def cpu_baseline(margs):
+    """The CPU oracle (restatement of the reference's stock-ATen path, fp32 NCHW) doing the
+    same training step on the host cores.  Bounded sample: B = 8, 1 warm-up + 2 timed steps."""
+    from oracle import infodiff_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = O.dataset_cfg('celeba', a_dim=margs.a_dim, mmd_weight=0.1)
+    from infodiffusion_amd.models import InfoDiff
+    with torch.no_grad():
+        shapes = [(k, tuple(v.shape)) for k, v in InfoDiff(margs, 'cpu', cfg.shape).state_dict().items()]
+    sd = O.synth_state_dict(shapes)
+    params = []
+    for k, v in sd.items():
+        if not k.endswith('timembedding.0.weight'):
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
+    sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+    g = torch.Generator(device='cpu')
+    g.manual_seed(64)
+    B = 8
+    times = []
+    for it in range(3):
+        x = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+        t0 = time.time()
+        idx = torch.randint(0, 1000, (B,))
+        eps = torch.randn_like(x)
+        loss, _ = O.infodiff_loss(sd, cfg, x, idx, eps, sched, prior=torch.randn(B, cfg.a_dim), drop=O.Drop('torch'))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()
+        times.append(time.time() - t0)
+    t = sum(times[1:]) / len(times[1:])
+    return {'value': round(B / t, 3), 'unit': 'images/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
+                      '(fwd+bwd+clip+AdamW, dropout on) at B=8: 1 warm-up + 2 timed steps, %.1f s/step' % t}
+
+
+class ConvTimer:
+    """HIP-event timing of every launch of the dominant kernel (the implicit-GEMM conv:
+    forward + data-gradient launches) on the stream it is enqueued on, with the
+    algorithmic FLOPs / bytes of each launch."""
+
+    def __init__(self):
+        self.recs = []
+
+    def install(self):
+        from infodiffusion_amd import ops
+        self.ops = ops
+        self.orig = ops.conv_raw
+        timer = self
+
+        def timed(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_)
+            e1.record()
+            B, Cin, _, _ = x.shape
+            M = y.shape[0] * y.shape[2] * y.shape[3]
+            flops = 2.0 * M * Cout * taps * Cin
+            byt = (x.numel() + y.numel() + (residual.numel() if residual is not None else 0) + w_fwd.numel()) * x.element_size()
+            timer.recs.append((e0, e1, flops, byt))
+            return y
+        ops.conv_raw = timed
+
+    def remove(self):
+        self.ops.conv_raw = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.recs)
+        fl = sum(r[2] for r in self.recs)
+        by = sum(r[3] for r in self.recs)
+        n = len(self.recs)
+        return n, tot_ms, fl, by
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from infodiffusion_amd.models import InfoDiff
+    from infodiffusion_amd.dist import GradSync
+    margs = make_args(a)
+    torch.manual_seed(64 + rank)
+    model = InfoDiff(margs, dev, (3, 64, 64))
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, capturable=bool(a.graph))
+    sync = GradSync(model, world) if world > 1 else None
+    if sync is not None:
+        sync.broadcast_parameters()
+
+    g = torch.Generator(device='cpu')
+    g.manual_seed(64 + rank)
+    pool = [(torch.rand(a.batch, 3, 64, 64, generator=g) * 2 - 1).to(dev) for _ in range(8)]
+    xbuf = pool[0].clone()
+
+    def fwd_bwd():
+        loss = model.loss_fn(margs, xbuf)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def tail():
+        if sync is not None:
+            sync.all_reduce_grads()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+
+    def step_eager(i):
+        xbuf.copy_(pool[i % 8])
+        fwd_bwd()
+        tail()
+
+    graph = None
+    used_graph = False
+    # warm-up (eager) -- also builds allocator pools and weight shadows
+    for i in range(max(2, a.warmup if not a.graph else 3)):
+        step_eager(i)
+    torch.cuda.synchronize()
+    if a.graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step_eager(0)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+                if sync is None:
+                    tail()
+            used_graph = True
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print('graph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step(i):
+        if graph is not None:
+            xbuf.copy_(pool[i % 8])
+            graph.replay()
+            if sync is not None:
+                tail()
+        else:
+            step_eager(i)
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    imgs = a.batch * world * a.steps
+    out = {
+        'metric': 'training images/sec, CelebA 64x64 (InfoDiff loss_fn fwd+bwd+clip+AdamW)',
+        'value': round(imgs / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: CelebA 3x64x64 a_dim=%d mmd_weight=0.1 T=1000 dropout=0.1 '
+                               'train step, random-pixel batches, random-init weights' % a.a_dim,
+                   'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
+                   'parallelism': 'dp%d' % world, 'hipgraph': used_graph},
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel: conv_igemm (forward + data-gradient launches); HIP events per launch, eager
+        tm = ConvTimer()
+        tm.install()
+        nrep = 3
+        for i in range(nrep):
+            step_eager(i)
+        tm.remove()
+        n, tot_ms, fl, by = tm.summary()
+        ach = fl / (tot_ms * 1e-3) / 1e12
+        peak = 2500.0 if a.dtype == 'bf16' else 157.3
+        out['roofline'] = {'kernel': 'conv_igemm_kernel (implicit-GEMM conv fwd + dgrad)', 'bound': 'mfma',
+                           'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           'traffic': None, 'launches_per_step': n // nrep,
+                           'avg_launch_us': round(tot_ms * 1e3 / n, 2),
+                           'algorithmic_gflop_per_step': round(fl / nrep / 1e9, 1),
+                           'algorithmic_gbs': round(by / (tot_ms * 1e-3) / 1e9, 1)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0 and a.sampling and world == 1:
+        from infodiffusion_amd.sampling import DiffusionProcess
+        import copy
+        sargs = copy.copy(margs)
+        sargs.diffusion_steps = 100
+        sargs.deterministic = True
+        smodel = InfoDiff(sargs, dev, (3, 64, 64)).eval()
+        proc = DiffusionProcess(sargs, smodel, dev, (3, 64, 64))
+        proc.sampling(8)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        proc.sampling(a.sampling_batch)
+        torch.cuda.synchronize()
+        ds = time.time() - t0
+        out['sampling'] = {'metric': 'DDIM-100 sampling images/sec (B=%d, 100 network evaluations)' % a.sampling_batch,
+                           'value': round(a.sampling_batch / ds, 2), 'unit': 'images/s', 'seconds': round(ds, 3)}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(margs)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,61 @@
+"""world_size-2 gloo test (CPU) of the data-parallel gradient exchange."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from infodiffusion_amd.dist import GradSync, shard_range
+    torch.manual_seed(rank)          # different init per rank on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 4))
+    dead = torch.nn.Linear(3, 3)     # never used: grads stay None and must be skipped
+    model = torch.nn.ModuleDict({'net': net, 'dead': dead})
+    sync = GradSync(model, world, bucket_bytes=256)   # tiny buckets -> several collectives
+    sync.broadcast_parameters()
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 8)
+    net(x).square().mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    sync.all_reduce_grads()
+    res = {'params': [p.detach().clone() for p in net.parameters()],
+           'local': local, 'avg': [p.grad.clone() for p in net.parameters()],
+           'dead_none': all(p.grad is None for p in dead.parameters()),
+           'shard': shard_range(10, rank, world)}
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = got[0], got[1]
+    for pa, pb in zip(a['params'], b['params']):
+        assert torch.equal(pa, pb)                      # broadcast made replicas identical
+    for la, lb, ga, gb in zip(a['local'], b['local'], a['avg'], b['avg']):
+        want = (la + lb) / 2
+        assert torch.allclose(ga, want, atol=1e-7) and torch.equal(ga, gb)
+    assert a['dead_none'] and b['dead_none']
+    assert a['shard'] == (0, 5) and b['shard'] == (5, 10)

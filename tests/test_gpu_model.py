@@ -134,7 +134,7 @@ def test_train_forward_pieces_fp32():
     tab = model.backbone.time_embedding.timembedding[0].weight
     rows = s['table_rows_1000']
     assert torch.equal(tab[rows.to(DEV)].cpu(), O.sinusoid_table(1000, cfg.unets_channels)[rows])
-    assert rel(O.sinusoid_table(1000, 64)[rows], s['table_1000']) < 1e-6
+    assert rel(O.sinusoid_table(1000, 64)[rows], s['table_1000']) < 2e-4   # sin(999*f) moves with the host's last-bit rounding of f
     # timestep gather is exact
     from infodiffusion_amd import ops as _ops
     idx = torch.tensor([0, 1, 999, 500], device=DEV)

@@ -60,6 +60,12 @@ int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, 
                      const uint64_t* seed, uint32_t salt, float p_drop, int B, int Hs, int Ws, int Cin,
                      int Ho, int Wo, int Cout, int mode, int taps, int act, int dtype, void* stream);
 
+/* bf16 fast path of the 3x3 stride-1 weight gradient on an already-activated input `a`
+ * (halo tile in LDS, transposed LDS reads); also accumulates db[n] = sum dy when db != NULL.
+ * Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (use idf_conv2d_wgrad then). */
+int idf_conv3x3_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
+                           int Cout, void* stream);
+
 /* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
  * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */
 int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fwd, void* w_dgrad, int O, int I,
@@ -74,6 +80,10 @@ int idf_gn_workspace_floats(int B, int HW, int C);
 int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
                     const float* film_a, float eps, float* mean, float* rstd, float* sc, float* sh,
                     float* workspace, int B, int HW, int C, int dtype, void* stream);
+/* a = act(x*sc+sh) materialised once (act 1 affine, 2 SiLU + dropout): GroupNorm-apply + FiLM +
+ * SiLU + Dropout of modules.py:264-288, 312-319 as one read + one write */
+int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
+                 float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 /* Backward through act(GN/FiLM(x)) given dA (gradient w.r.t. the activated tensor):
  * dx (+ dres), dfilm_t/dfilm_a [B,2C], dgb [B][2][C] (per-sample dgamma, dbeta;
  * sum over B with idf_colsum), k1/k0 [B,32] scratch. */

@@ -208,12 +208,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     __syncthreads();
   }
 }
+// one wave per column
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= N) return;
   float s = 0.f;
-  for (int k = 0; k < nb; ++k) s += part[(size_t)k * N + c];
-  out[c] = s;
+  for (int k = threadIdx.x & 63; k < nb; k += 64) s += part[(size_t)k * N + c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) out[c] = s;
 }
 
 // ------------------------------------------------------------ 2x2 sum pool
@@ -363,7 +365,7 @@ extern "C" int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, 
 // workspace: nblk*N floats where nblk = idf_colsum_blocks(R)
 extern "C" int idf_colsum_blocks(long R) {
   long nb = (R + 255) / 256;
-  return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+  return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb));
 }
 extern "C" int idf_colsum(const void* in, float* out, float* workspace, long R, int N, int in_dtype, void* stream) {
   int nb = idf_colsum_blocks(R);
@@ -375,7 +377,7 @@ extern "C" int idf_colsum(const void* in, float* out, float* workspace, long R, 
   else
     hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nb), dim3(256), lds, ST, (const bf16_t*)in, workspace, R, N, rpb);
   IDF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, ST, workspace, nb, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 3) / 4), dim3(256), 0, ST, workspace, nb, N, out);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -255,6 +255,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const T* __restrict__ dA, co
   }
 }
 
+// elementwise: a = dropout(SiLU(x*sc + sh))  (act 2)  or  x*sc + sh  (act 1)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                       const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       int HW, int C, long nvec, int act, const uint64_t* seed,
+                                                       uint32_t salt, uint32_t thr, float dscale) {
+  constexpr int VE = Elem<T>::VE;
+  const int vpp = C / VE;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    long pix = i / vpp;
+    int v = (int)(i - pix * vpp);
+    int b = (int)(pix / HW);
+    size_t e0 = (size_t)i * VE;
+    float xv[VE];
+    Vec16<T>::load(x + e0, xv);
+    const float* scp = sc + (size_t)b * C + v * VE;
+    const float* shp = sh + (size_t)b * C + v * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float u = xv[e] * scp[e] + shp[e];
+      if (act == 2) {
+        u = silu_f(u);
+        if (seed) u = idf_keep(*seed, salt, e0 + e, thr) ? u * dscale : 0.f;
+      }
+      xv[e] = u;
+    }
+    Vec16<T>::store(out + e0, xv);
+  }
+}
+
 int pick_chunk(int B, int HW) {
   // aim for >= ~1024 blocks, chunks of at least 64 pixels
   int nchunk = idf_cdiv(1024, B);
@@ -329,6 +359,30 @@ extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, 
   else
     hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dA, (const bf16_t*)x,
                        (const bf16_t*)dres, (bf16_t*)dx, sc, sh, k1, k0, HW, C, nvec, act, sd, salt, thr, dscale);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// a = act(x*sc+sh): the GroupNorm-apply + FiLM + SiLU + dropout pass (one read, one write)
+extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed,
+                            uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
+  if (B == 0) return IDF_OK;
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (C % VE) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_apply: C=%d unsupported", C);
+  if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "gn_apply: act must be 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t thr = idf_drop_thresh(p_drop);
+  float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+  const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  long nvec = (long)B * HW * C / VE;
+  int blocks = (int)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, sc, sh, HW,
+                       C, nvec, act, sd, salt, thr, dscale);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, sc, sh,
+                       HW, C, nvec, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -1,0 +1,199 @@
+// 3x3 stride-1 weight gradient for bf16 activations on MFMA (gfx950):
+//   dW[n][tap][c] += sum_{pixels} dy[pix][n] * a[pix + tap][c]       (+ db[n] += sum dy[pix][n])
+// `a` is the already-activated conv input (idf_gn_apply output, or the raw input of
+// an un-normalised conv).  Both operands are pixel-major in HBM and the contraction
+// runs over pixels, so tiles are copied to LDS in their natural [pixel][channel]
+// layout (16-byte vectors in, ds_write_b128) and the MFMA fragments are fetched with
+// the gfx950 transposed read ds_read_b64_tr_b16 -- no scalar scatter, no per-tap
+// re-staging: one halo tile of R+2 rows serves all nine taps through address offsets.
+//
+// Block = 64 couts x 64 cins x all 9 taps; grid.y splits the (image, row-group)
+// tiles; partial sums are accumulated in registers across a block's tiles and
+// added to dW with fp32 atomics (64 contiguous bytes per row segment).
+// LDS pixel pitch is 80 bf16 (160 B): 8 consecutive pixels x 32 B then tile all
+// 64 banks, so the transposed reads are conflict-free.
+#include "idf_common.h"
+
+namespace {
+
+struct WgP {
+  const bf16_t* a;    // [B,H,W,Cin]
+  const bf16_t* dy;   // [B,H,W,Cout]
+  float* dW;          // [Cout][9][Cin]
+  float* db;          // [Cout] or null
+  int B, H, W, Cin, Cout;
+  int R;              // output rows per tile (R*W in {64,128})
+  int tiles;          // B*H/R
+  int tiles_per_blk;
+  int c_tiles;
+};
+
+constexpr int PITCH = 80;                 // elements per LDS pixel row
+constexpr int PITCHB = PITCH * 2;         // bytes
+
+__device__ __forceinline__ s16x4_t tr_read(const bf16_t* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(lds_ptr));
+}
+
+__device__ __forceinline__ bf16x8_t mkfrag(s16x4_t lo, s16x4_t hi) {
+  union { struct { s16x4_t a, b; } s; bf16x8_t v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = p.W, R = p.R, HW2 = W + 2;
+  const int npix_h = (R + 2) * HW2;       // halo pixels
+  const int KT = R * W;                   // contraction length per tile (64 or 128)
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Ds = Xs + (size_t)npix_h * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = (blockIdx.x % p.c_tiles) * 64, n0 = (blockIdx.x / p.c_tiles) * 64;
+  const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+  const int tiles_per_img = p.H / R;
+  const int t_beg = blockIdx.y * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
+
+  f32x4_t acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int v8 = tid & 7;                 // this thread's 8-channel vector slot (fixed)
+  float dbs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
+  const bool do_db = p.db != nullptr && c0 == 0;
+  const bool cvalid = (c0 + v8 * 8) < p.Cin, nvalid = (n0 + v8 * 8) < p.Cout;
+
+  // transposed-read lane geometry
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+
+  for (int t = t_beg; t < t_end; ++t) {
+    const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
+    // ---- stage the halo tile of the activated input
+    for (int idx = tid; idx < npix_h * 8; idx += 256) {
+      int pix = idx >> 3;
+      int hy = pix / HW2, hx = pix - hy * HW2;
+      int iy = oy0 - 1 + hy, ix = hx - 1;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (cvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+        val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.H + iy) * W + ix) * p.Cin + c0 + v8 * 8);
+      *reinterpret_cast<uint4*>(Xs + (size_t)pix * PITCH + v8 * 8) = val;
+    }
+    // ---- stage the dy tile
+    for (int idx = tid; idx < KT * 8; idx += 256) {
+      int pix = idx >> 3;
+      int oy = pix / W, ox = pix - oy * W;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (nvalid)
+        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0 + oy) * W + ox) * p.Cout + n0 + v8 * 8);
+      *reinterpret_cast<uint4*>(Ds + (size_t)pix * PITCH + v8 * 8) = val;
+      if (do_db) {
+        uint32_t w4[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dbs[2 * e] += __uint_as_float(w4[e] << 16);
+          dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the tile's pixels, 32 per step.  Logical k slot (g, j) maps to
+    // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
+    for (int ks = 0; ks < KT; ks += 32) {
+      bf16x8_t nf[2];
+      int pixA = ks + 4 * g + q, pixB = pixA + 16;
+      {
+        const bf16_t* d0 = Ds + (size_t)pixA * PITCH + wn0 + 4 * pp;
+        const bf16_t* d1 = Ds + (size_t)pixB * PITCH + wn0 + 4 * pp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
+      }
+      int oyA = pixA / W, oxA = pixA - oyA * W, oyB = pixB / W, oxB = pixB - oyB * W;
+      const bf16_t* x0 = Xs + (size_t)(oyA * HW2 + oxA) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x1 = Xs + (size_t)(oyB * HW2 + oxB) * PITCH + wc0 + 4 * pp;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * HW2 + (tap % 3)) * PITCH;
+        bf16x8_t cf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cf[j] = mkfrag(tr_read(x0 + toff + j * 16), tr_read(x1 + toff + j * 16));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf[j], acc[tap][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D: row = n (4 per lane), col = c (lane & 15)
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int c = c0 + wc0 + j * 16 + (lane & 15);
+        if (c >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
+          if (n < p.Cout) atomicAdd(p.dW + ((size_t)n * 9 + tap) * p.Cin + c, acc[tap][i][j][r]);
+        }
+      }
+    }
+
+  if (do_db) {
+    // reduce the 32 threads that share v8, then one atomic per cout
+    float* red = reinterpret_cast<float*>(smem);   // [32][64]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Cout) {
+      float s = 0.f;
+      for (int k = 0; k < 32; ++k) s += red[k * 64 + tid];
+      atomicAdd(p.db + n0 + tid, s);
+    }
+  }
+}
+
+}  // namespace
+
+// Returns IDF_ERR_UNSUPPORTED (without touching outputs) for shapes this kernel does
+// not cover; the caller then uses idf_conv2d_wgrad.  dW / db are zeroed inside.
+extern "C" int idf_conv3x3_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
+                                      int Cin, int Cout, void* stream) {
+  if ((Cin % 8) || (Cout % 8) || H <= 0 || W < 8 || (W & (W - 1)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad3x3_bf16: shape B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  int R = 128 / W;
+  if (R > H) R = H;
+  if (R < 1 || (H % R) || ((R * W) % 32)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad3x3_bf16: H%d W%d not tileable", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * 9 * Cin * sizeof(float), st);
+  if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
+  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad3x3_bf16: memset failed: %s", hipGetErrorString(e));
+  if (B == 0) return IDF_OK;
+  WgP p;
+  p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
+  p.tiles = B * (H / R);
+  p.c_tiles = idf_cdiv(Cin, 64);
+  int ct = p.c_tiles * idf_cdiv(Cout, 64);
+  int split = idf_cdiv(512, ct);
+  if (split > p.tiles) split = p.tiles;
+  p.tiles_per_blk = idf_cdiv(p.tiles, split);
+  split = idf_cdiv(p.tiles, p.tiles_per_blk);
+  size_t lds = ((size_t)(R + 2) * (W + 2) + (size_t)R * W) * PITCHB;
+  if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
+  hipLaunchKernelGGL(conv_wgrad3x3_bf16, dim3(ct, split), dim3(256), lds, st, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

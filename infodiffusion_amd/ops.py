@@ -153,11 +153,49 @@ def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, 
 
 
 # ------------------------------------------------------------- fused conv op
+def gn_apply_raw(x, sc, sh, seed, salt, p_drop, act):
+    """a = act(x*sc + sh) (+ dropout): one read + one write."""
+    B, C, H, W = x.shape
+    a = torch.empty_like(x, memory_format=CL)
+    call('idf_gn_apply', _p(x), _p(a), _p(sc), _p(sh), _p(seed), salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
+    return a
+
+
+def _fast_wgrad_ok(a, dy, mode, taps):
+    if a.dtype != torch.bfloat16 or taps != 9 or mode != S1:
+        return False
+    B, Cin, H, W = a.shape
+    Cout = dy.shape[1]
+    if Cin % 8 or Cout % 8 or W < 8 or (W & (W - 1)):
+        return False
+    R = min(H, 128 // W)
+    return R >= 1 and H % R == 0 and (R * W) % 32 == 0
+
+
+def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias):
+    """dW (fp32, logical [O,I,kh,kw], memory [O][taps][I]) and db for a conv whose
+    (already activated) input is `a`."""
+    B, Cin, Hs, Ws = a.shape
+    _, Cout, Ho, Wo = dy.shape
+    k = 3 if taps == 9 else 1
+    if _fast_wgrad_ok(a, dy, mode, taps):
+        dW = torch.empty((Cout, k, k, Cin), dtype=torch.float32, device=a.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=a.device) if want_bias else None
+        call('idf_conv3x3_wgrad_bf16', _p(a), _p(dy), _p(dW), _p(db), B, Hs, Ws, Cin, Cout, _st())
+        return dW.permute(0, 3, 1, 2), db
+    dW = conv_wgrad_raw(a, dy, None, None, None, 0, 0.0, mode, taps, 0)
+    db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)) if want_bias else None
+    return dW, db
+
+
 class _FusedConv(torch.autograd.Function):
     """y = conv(act(GN/FiLM(x))) + bias (+ residual);  act per `cfg`.
 
     cfg = dict(mode, taps, act, p_drop, salt, shadows) where shadows() returns the
-    (forward, data-gradient) weight shadows in the activation dtype.
+    (forward, data-gradient) weight shadows in the activation dtype.  The activated
+    tensor a = dropout(SiLU(GN/FiLM(x))) is materialised once by `idf_gn_apply`
+    (HBM-bound pass) and kept for the weight gradient; the conv itself is a plain
+    implicit GEMM on `a`.
     """
 
     @staticmethod
@@ -167,27 +205,32 @@ class _FusedConv(torch.autograd.Function):
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
         p_drop = cfg['p_drop'] if seed is not None else 0.0
         mean = rstd = sc = sh = None
+        a = x
         if act:
             mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
+            a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
         w_fwd = cfg['shadows'](x.dtype, False)[0]
-        y = conv_raw(x, w_fwd, bias, residual, sc, sh, seed, cfg['salt'], p_drop, mode, taps, act,
-                     weight.shape[0])
+        y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, weight.shape[0])
         ctx.cfg, ctx.p_drop = cfg, p_drop
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed)
+        ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
+                              seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
+        x, a, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
         cfg, p_drop = ctx.cfg, ctx.p_drop
         act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
+        if a is None:
+            a = x
         dy = _nhwc(dy.to(x.dtype))
         need = ctx.needs_input_grad
         dW = db = dx = dgw = dgb = dft = dfa = dres = None
+        want_b = bias is not None and need[2]
         if need[1]:
-            dW = conv_wgrad_raw(x, dy, sc, sh, seed, salt, p_drop, mode, taps, act)
-        if bias is not None and need[2]:
+            dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b)
+        elif want_b:
             B, Co, Ho, Wo = dy.shape
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
         if need[0] or (act and (need[3] or need[5] or need[6])):

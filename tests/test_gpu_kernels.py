@@ -186,3 +186,32 @@ def test_qsample_bit_exact_and_gather():
     assert torch.equal(out.cpu(), table[idx])
 
 
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 64, 64), (2, 128, 32, 32, 128), (3, 192, 16, 16, 64), (4, 128, 8, 8, 128),
+                                  (2, 256, 32, 32, 128), (2, 96, 16, 16, 32), (1, 64, 64, 64, 8)])
+def test_wgrad3x3_bf16_fast(case):
+    """Transposed-LDS-read weight-gradient kernel (+ fused bias gradient) vs PyTorch."""
+    B, Cin, H, W, Cout = case
+    a = rnd(1, B, Cin, H, W).bfloat16().float()
+    gy = rnd(2, B, Cout, H, W).bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    bb = torch.zeros(Cout, requires_grad=True)
+    F.conv2d(a, w, bb, padding=1).backward(gy)
+    ad = a.to(DEV).bfloat16().contiguous(memory_format=CL)
+    gd = gy.to(DEV).bfloat16().contiguous(memory_format=CL)
+    assert ops._fast_wgrad_ok(ad, gd, ops.S1, 9)
+    dW, db = ops.conv_wgrad_bias_raw(ad, gd, ops.S1, 9, True)
+    assert rel(dW, w.grad) < 1e-4
+    assert rel(db, bb.grad) < 1e-4
+
+
+def test_gn_apply():
+    B, C, H = 2, 64, 8
+    x = rnd(1, B, C, H, H)
+    sc, sh = rnd(2, B, C), rnd(3, B, C)
+    xd = x.to(DEV).contiguous(memory_format=CL)
+    a = ops.gn_apply_raw(xd, sc.to(DEV), sh.to(DEV), None, 0, 0.0, 2)
+    assert rel(a, F.silu(x * sc[:, :, None, None] + sh[:, :, None, None])) < 1e-5
+    a = ops.gn_apply_raw(xd.bfloat16(), sc.to(DEV), sh.to(DEV), None, 0, 0.0, 1)
+    assert rel(a, x.bfloat16().float() * sc[:, :, None, None] + sh[:, :, None, None]) < 1e-2

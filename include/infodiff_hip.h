@@ -60,11 +60,12 @@ int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, 
                      const uint64_t* seed, uint32_t salt, float p_drop, int B, int Hs, int Ws, int Cin,
                      int Ho, int Wo, int Cout, int mode, int taps, int act, int dtype, void* stream);
 
-/* bf16 fast path of the 3x3 stride-1 weight gradient on an already-activated input `a`
+/* bf16 fast path of the weight gradient (taps 9 or 1; mode S1, S2 or UP2; H, W = dy dims) on an
+ * already-activated input `a`
  * (halo tile in LDS, transposed LDS reads); also accumulates db[n] = sum dy when db != NULL.
  * Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (use idf_conv2d_wgrad then). */
-int idf_conv3x3_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
-                           int Cout, void* stream);
+int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
+                        int Cout, int taps, int mode, void* stream);
 
 /* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
  * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */

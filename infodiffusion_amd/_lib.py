@@ -23,7 +23,7 @@ SIGNATURES = {
     'idf_gn_workspace_floats': ([_i, _i, _i], C.c_int),
     'idf_gn_coef_fwd': ([_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_apply': ([_p, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_conv3x3_wgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_conv_wgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_coef_bwd': ([_p] * 18 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_bgemm': ([_p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
     'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),

@@ -1,15 +1,19 @@
-// 3x3 stride-1 weight gradient for bf16 activations on MFMA (gfx950):
+// Stride-1 weight gradient (3x3 and 1x1) for bf16 activations on MFMA (gfx950):
 //   dW[n][tap][c] += sum_{pixels} dy[pix][n] * a[pix + tap][c]       (+ db[n] += sum dy[pix][n])
 // `a` is the already-activated conv input (idf_gn_apply output, or the raw input of
 // an un-normalised conv).  Both operands are pixel-major in HBM and the contraction
 // runs over pixels, so tiles are copied to LDS in their natural [pixel][channel]
 // layout (16-byte vectors in, ds_write_b128) and the MFMA fragments are fetched with
 // the gfx950 transposed read ds_read_b64_tr_b16 -- no scalar scatter, no per-tap
-// re-staging: one halo tile of R+2 rows serves all nine taps through address offsets.
+// re-staging: one R-row input tile (with a one-pixel column halo) serves the three
+// taps of a kernel row through address offsets.
 //
-// Block = 64 couts x 64 cins x all 9 taps; grid.y splits the (image, row-group)
-// tiles; partial sums are accumulated in registers across a block's tiles and
-// added to dW with fp32 atomics (64 contiguous bytes per row segment).
+// Block = 64 couts x 64 cins x one kernel row (3 taps; 1 tap for 1x1).  grid.x =
+// (c-tiles x n-tiles x kernel rows), grid.y splits the (image, row-group) tiles.
+// Partial sums stay in registers across a block's tiles and are added to dW with
+// fp32 atomics (64 contiguous bytes per row segment).  Splitting the kernel rows
+// over blocks keeps the per-block partial small, so the whole chip is busy with
+// 3x fewer atomic bytes than a 9-tap block would need.
 // LDS pixel pitch is 80 bf16 (160 B): 8 consecutive pixels x 32 B then tile all
 // 64 banks, so the transposed reads are conflict-free.
 #include "idf_common.h"
@@ -19,15 +23,19 @@ namespace {
 struct WgP {
   const bf16_t* a;    // [B,H,W,Cin]
   const bf16_t* dy;   // [B,H,W,Cout]
-  float* dW;          // [Cout][9][Cin]
+  float* dW;          // [Cout][taps][Cin]
   float* db;          // [Cout] or null
-  int B, H, W, Cin, Cout;
-  int R;              // output rows per tile (R*W in {64,128})
+  int B, H, W, Cin, Cout;   // H, W: output (dy) dims
+  int Hs, Ws;               // source dims of `a` (S1: H,W; S2: 2H,2W; UP2: H/2,W/2)
+  int R;              // output rows per tile (R*W in {32,64,128})
   int tiles;          // B*H/R
   int tiles_per_blk;
-  int c_tiles;
+  int c_tiles, n_tiles;
 };
 
+#ifndef IDF_WGRAD_BLOCKS
+#define IDF_WGRAD_BLOCKS 320   // target grid size: ~1.25 blocks per CU keeps the atomic bytes low
+#endif
 constexpr int PITCH = 80;                 // elements per LDS pixel row
 constexpr int PITCHB = PITCH * 2;         // bytes
 
@@ -42,23 +50,33 @@ __device__ __forceinline__ bf16x8_t mkfrag(s16x4_t lo, s16x4_t hi) {
   return u.v;
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
+// KW = taps per block along x (3 for a 3x3 kernel row, 1 for 1x1).
+// MODE 0: stride 1; 1: stride 2 (DownSample); 2: nearest-x2-upsampled input (UpSample):
+// only the staging differs -- the LDS tile always holds the pixels the taps address.
+template <int KW, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int W = p.W, R = p.R, HW2 = W + 2;
-  const int npix_h = (R + 2) * HW2;       // halo pixels
-  const int KT = R * W;                   // contraction length per tile (64 or 128)
+  constexpr int HALO = KW / 2;
+  constexpr int SX = (MODE == 1) ? 2 : 1;
+  const int W = p.W, R = p.R, WH = SX * W + 2 * HALO;
+  const int npix_h = R * WH;              // staged input pixels
+  const int KT = R * W;                   // contraction length per tile
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Ds = Xs + (size_t)npix_h * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = (blockIdx.x % p.c_tiles) * 64, n0 = (blockIdx.x / p.c_tiles) * 64;
+  int bx = blockIdx.x;
+  const int ky = (KW == 3) ? bx % 3 : 0;
+  if (KW == 3) bx /= 3;
+  const int c0 = (bx % p.c_tiles) * 64, n0 = (bx / p.c_tiles) * 64;
   const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
   const int tiles_per_img = p.H / R;
   const int t_beg = blockIdx.y * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
+  const int ntaps = KW * KW;
 
-  f32x4_t acc[9][2][2];
+  f32x4_t acc[KW][2][2];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < KW; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -68,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
   float dbs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
-  const bool do_db = p.db != nullptr && c0 == 0;
+  const bool do_db = p.db != nullptr && c0 == 0 && ky == HALO;
   const bool cvalid = (c0 + v8 * 8) < p.Cin, nvalid = (n0 + v8 * 8) < p.Cout;
 
   // transposed-read lane geometry
@@ -76,23 +94,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
 
   for (int t = t_beg; t < t_end; ++t) {
     const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
-    // ---- stage the halo tile of the activated input
+    // ---- stage the input rows this kernel row touches (zero outside the image)
     for (int idx = tid; idx < npix_h * 8; idx += 256) {
       int pix = idx >> 3;
-      int hy = pix / HW2, hx = pix - hy * HW2;
-      int iy = oy0 - 1 + hy, ix = hx - 1;
+      int hy = pix / WH, hx = pix - hy * WH;
+      int iy = SX * (oy0 + hy) + ky - HALO, ix = hx - HALO;
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (cvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
-        val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.H + iy) * W + ix) * p.Cin + c0 + v8 * 8);
+      if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
+        if (MODE == 2) { iy >>= 1; ix >>= 1; }
+        val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + v8 * 8);
+      }
       *reinterpret_cast<uint4*>(Xs + (size_t)pix * PITCH + v8 * 8) = val;
     }
     // ---- stage the dy tile
     for (int idx = tid; idx < KT * 8; idx += 256) {
       int pix = idx >> 3;
-      int oy = pix / W, ox = pix - oy * W;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (nvalid)
-        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0 + oy) * W + ox) * p.Cout + n0 + v8 * 8);
+        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + pix) * p.Cout + n0 + v8 * 8);
       *reinterpret_cast<uint4*>(Ds + (size_t)pix * PITCH + v8 * 8) = val;
       if (do_db) {
         uint32_t w4[4] = {val.x, val.y, val.z, val.w};
@@ -116,19 +135,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
         for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
       }
       int oyA = pixA / W, oxA = pixA - oyA * W, oyB = pixB / W, oxB = pixB - oyB * W;
-      const bf16_t* x0 = Xs + (size_t)(oyA * HW2 + oxA) * PITCH + wc0 + 4 * pp;
-      const bf16_t* x1 = Xs + (size_t)(oyB * HW2 + oxB) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x0 = Xs + (size_t)(oyA * WH + SX * oxA) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x1 = Xs + (size_t)(oyB * WH + SX * oxB) * PITCH + wc0 + 4 * pp;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = ((tap / 3) * HW2 + (tap % 3)) * PITCH;
+      for (int kx = 0; kx < KW; ++kx) {
         bf16x8_t cf[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cf[j] = mkfrag(tr_read(x0 + toff + j * 16), tr_read(x1 + toff + j * 16));
+        for (int j = 0; j < 2; ++j) cf[j] = mkfrag(tr_read(x0 + kx * PITCH + j * 16), tr_read(x1 + kx * PITCH + j * 16));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf[j], acc[tap][i][j], 0, 0, 0);
+            acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf[j], acc[kx][i][j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
 
   // D: row = n (4 per lane), col = c (lane & 15)
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
-          if (n < p.Cout) atomicAdd(p.dW + ((size_t)n * 9 + tap) * p.Cin + c, acc[tap][i][j][r]);
+          if (n < p.Cout) atomicAdd(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cin + c, acc[kx][i][j][r]);
         }
       }
     }
@@ -167,33 +185,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const WgP p) {
 
 }  // namespace
 
-// Returns IDF_ERR_UNSUPPORTED (without touching outputs) for shapes this kernel does
-// not cover; the caller then uses idf_conv2d_wgrad.  dW / db are zeroed inside.
-extern "C" int idf_conv3x3_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
-                                      int Cin, int Cout, void* stream) {
-  if ((Cin % 8) || (Cout % 8) || H <= 0 || W < 8 || (W & (W - 1)))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad3x3_bf16: shape B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
-  int R = 128 / W;
+// taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
+// (3x3 only).  H, W are the OUTPUT (dy) dims.  Returns IDF_ERR_UNSUPPORTED (without touching
+// outputs) for shapes this kernel does not cover; the caller then uses idf_conv2d_wgrad.
+// dW / db are zeroed inside.
+extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
+                                   int Cin, int Cout, int taps, int mode, void* stream) {
+  if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
+      mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
+             Cout, taps, mode);
+  int R = (mode == 1 ? 64 : 128) / W;
   if (R > H) R = H;
-  if (R < 1 || (H % R) || ((R * W) % 32)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad3x3_bf16: H%d W%d not tileable", H, W);
+  if (R < 1 || (H % R) || ((R * W) % 32)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * 9 * Cin * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * taps * Cin * sizeof(float), st);
   if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
-  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad3x3_bf16: memset failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: memset failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
   WgP p;
   p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
+  p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
+  p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
   p.tiles = B * (H / R);
   p.c_tiles = idf_cdiv(Cin, 64);
-  int ct = p.c_tiles * idf_cdiv(Cout, 64);
-  int split = idf_cdiv(512, ct);
+  p.n_tiles = idf_cdiv(Cout, 64);
+  const int kh = taps == 9 ? 3 : 1;
+  int gx = p.c_tiles * p.n_tiles * kh;
+  int split = idf_cdiv(IDF_WGRAD_BLOCKS, gx);
   if (split > p.tiles) split = p.tiles;
   p.tiles_per_blk = idf_cdiv(p.tiles, split);
   split = idf_cdiv(p.tiles, p.tiles_per_blk);
-  size_t lds = ((size_t)(R + 2) * (W + 2) + (size_t)R * W) * PITCHB;
+  const int sx = mode == 1 ? 2 : 1;
+  size_t lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
   if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
-  hipLaunchKernelGGL(conv_wgrad3x3_bf16, dim3(ct, split), dim3(256), lds, st, p);
+  dim3 g(gx, split);
+  if (kh == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<1, 0>), g, dim3(256), lds, st, p);
+  else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 0>), g, dim3(256), lds, st, p);
+  else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 1>), g, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 2>), g, dim3(256), lds, st, p);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

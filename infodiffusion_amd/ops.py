@@ -161,28 +161,46 @@ def gn_apply_raw(x, sc, sh, seed, salt, p_drop, act):
     return a
 
 
-def _fast_wgrad_ok(a, dy, mode, taps):
-    if a.dtype != torch.bfloat16 or taps != 9 or mode != S1:
+def _fast_wgrad_ok(Cin, Cout, Ho, Wo, dtype, mode, taps):
+    if dtype != torch.bfloat16 or mode not in (S1, S2, UP2) or (mode != S1 and taps != 9):
         return False
-    B, Cin, H, W = a.shape
-    Cout = dy.shape[1]
-    if Cin % 8 or Cout % 8 or W < 8 or (W & (W - 1)):
+    if Cin % 8 or Cout % 8 or Wo < 4 or (Wo & (Wo - 1)):
         return False
-    R = min(H, 128 // W)
-    return R >= 1 and H % R == 0 and (R * W) % 32 == 0
+    R = min(Ho, (64 if mode == S2 else 128) // Wo)
+    return R >= 1 and Ho % R == 0 and (R * Wo) % 32 == 0
+
+
+def _pad_channels(t, mult=8):
+    """Zero-pad the channel dim of an NHWC-dense tensor to a multiple of `mult`."""
+    C = t.shape[1]
+    Cp = -(-C // mult) * mult
+    if Cp == C:
+        return t
+    out = torch.zeros((t.shape[0], Cp, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device).contiguous(
+        memory_format=CL)
+    out[:, :C] = t
+    return out
 
 
 def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias):
     """dW (fp32, logical [O,I,kh,kw], memory [O][taps][I]) and db for a conv whose
-    (already activated) input is `a`."""
+    (already activated) input is `a`.  Channel counts that are not multiples of 8
+    (image input, epsilon output) are zero-padded so the MFMA kernel covers them."""
     B, Cin, Hs, Ws = a.shape
     _, Cout, Ho, Wo = dy.shape
     k = 3 if taps == 9 else 1
-    if _fast_wgrad_ok(a, dy, mode, taps):
-        dW = torch.empty((Cout, k, k, Cin), dtype=torch.float32, device=a.device)
-        db = torch.empty((Cout,), dtype=torch.float32, device=a.device) if want_bias else None
-        call('idf_conv3x3_wgrad_bf16', _p(a), _p(dy), _p(dW), _p(db), B, Hs, Ws, Cin, Cout, _st())
-        return dW.permute(0, 3, 1, 2), db
+    if a.dtype == torch.bfloat16:
+        ap, dyp = _pad_channels(a), _pad_channels(dy)
+        Cip, Cop = ap.shape[1], dyp.shape[1]
+        if _fast_wgrad_ok(Cip, Cop, Ho, Wo, a.dtype, mode, taps):
+            dW = torch.empty((Cop, k, k, Cip), dtype=torch.float32, device=a.device)
+            db = torch.empty((Cop,), dtype=torch.float32, device=a.device) if want_bias else None
+            call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, _st())
+            dW = dW.permute(0, 3, 1, 2)
+            if Cip != Cin or Cop != Cout:
+                dW = dW[:Cout, :Cin]
+                db = db[:Cout] if db is not None else None
+            return dW, db
     dW = conv_wgrad_raw(a, dy, None, None, None, 0, 0.0, mode, taps, 0)
     db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)) if want_bias else None
     return dW, db

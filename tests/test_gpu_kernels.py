@@ -188,20 +188,29 @@ def test_qsample_bit_exact_and_gather():
 
 
 
+@pytest.mark.parametrize('k,mode', [(3, ops.S1), (1, ops.S1), (3, ops.S2), (3, ops.UP2)])
 @pytest.mark.parametrize('case', [(2, 64, 64, 64, 64), (2, 128, 32, 32, 128), (3, 192, 16, 16, 64), (4, 128, 8, 8, 128),
-                                  (2, 256, 32, 32, 128), (2, 96, 16, 16, 32), (1, 64, 64, 64, 8)])
-def test_wgrad3x3_bf16_fast(case):
-    """Transposed-LDS-read weight-gradient kernel (+ fused bias gradient) vs PyTorch."""
+                                  (2, 256, 32, 32, 128), (2, 96, 16, 16, 32), (1, 64, 64, 64, 8), (8, 64, 8, 4, 128),
+                                  (3, 128, 16, 16, 384), (2, 3, 32, 32, 64), (2, 64, 32, 32, 3), (2, 64, 16, 16, 1)])
+def test_wgrad_bf16_fast(case, k, mode):
+    """Transposed-LDS-read weight-gradient kernel (+ fused bias gradient) vs PyTorch.
+    (B, Cin, Ho, Wo, Cout): Ho, Wo are the OUTPUT dims."""
     B, Cin, H, W, Cout = case
-    a = rnd(1, B, Cin, H, W).bfloat16().float()
+    Hs, Ws = (2 * H, 2 * W) if mode == ops.S2 else ((H // 2, W // 2) if mode == ops.UP2 else (H, W))
+    a = rnd(1, B, Cin, Hs, Ws).bfloat16().float()
     gy = rnd(2, B, Cout, H, W).bfloat16().float()
-    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
     bb = torch.zeros(Cout, requires_grad=True)
-    F.conv2d(a, w, bb, padding=1).backward(gy)
+    ain = F.interpolate(a, scale_factor=2.0, mode='nearest') if mode == ops.UP2 else a
+    F.conv2d(ain, w, bb, stride=2 if mode == ops.S2 else 1, padding=k // 2).backward(gy)
     ad = a.to(DEV).bfloat16().contiguous(memory_format=CL)
     gd = gy.to(DEV).bfloat16().contiguous(memory_format=CL)
-    assert ops._fast_wgrad_ok(ad, gd, ops.S1, 9)
-    dW, db = ops.conv_wgrad_bias_raw(ad, gd, ops.S1, 9, True)
+    pad8 = lambda c: -(-c // 8) * 8
+    if mode == ops.S2 and (H * W) % 32 and W * min(H, 64 // W) % 32:
+        pytest.skip('not tileable')
+    assert ops._fast_wgrad_ok(pad8(Cin), pad8(Cout), H, W, torch.bfloat16, mode, k * k)
+    dW, db = ops.conv_wgrad_bias_raw(ad, gd, mode, k * k, True)
+    assert dW.shape == w.shape and db.shape == bb.shape
     assert rel(dW, w.grad) < 1e-4
     assert rel(db, bb.grad) < 1e-4
 

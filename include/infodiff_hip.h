@@ -54,6 +54,12 @@ int idf_conv2d_fwd(const void* x, const void* w, const float* bias, const void* 
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int mode, int taps, int act,
                    int dtype, void* stream);
 
+/* bf16 halo-tile form of the 3x3 conv (mode S1 / UP2 / T2, no prologue; H, W = output dims): one
+ * input read per 32-channel chunk instead of one per tap.  IDF_ERR_UNSUPPORTED for shapes it does
+ * not cover (Cin % 32, W not a power of two in 4..128): use idf_conv2d_fwd then. */
+int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B, int H,
+                     int W, int Cin, int Cout, int mode, void* stream);
+
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */
 int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, const float* sh,

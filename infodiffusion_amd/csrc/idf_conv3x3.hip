@@ -1,0 +1,234 @@
+// 3x3 convolution for bf16 NHWC activations on MFMA (gfx950), halo-tile form.
+// Forward and data-gradient of every stride-1-shaped 3x3 conv on the path:
+//   MODE 0  plain stride-1 conv (also the data gradient of one, with the flipped shadow)
+//   MODE 2  nearest-x2 upsample fused into the read (UpSample, modules.py:89-92)
+//   MODE 3  zero-stuffed x2 input = transposed stride-2 (data gradient of DownSample)
+//
+//   y[pix][n] = sum_{tap, c} v[pix + tap][c] * w[n][tap][c] + bias[n] (+ res[pix][n])
+// where v is the (virtual) input image the mode defines.  A block owns R output rows
+// x W columns of one image (R*W = 64 or 128 pixels) x BN couts.  Per 32-channel chunk
+// it stages ONE halo tile of (R+2) x (W+2) pixels plus the [9][BN][32] weight slab
+// into LDS and runs all nine taps from LDS through shifted fragment addresses: the
+// input is read from HBM/L2 once per chunk instead of once per tap, and one barrier
+// pair covers 9 x the MFMA work of a per-tap implicit GEMM.  Next chunk's global
+// loads are issued before the MFMAs and land in LDS after them.
+// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-ed with
+// 2*((row>>2)&1), which makes ds_read_b128 of any 16 consecutive rows conflict-free.
+#include "idf_common.h"
+
+namespace {
+
+struct C3P {
+  const bf16_t* x;      // source activations [B, Hs, Ws, Cin]
+  const bf16_t* w;      // [Cout][9][Cin]
+  const float* bias;    // [Cout] or null
+  const bf16_t* res;    // [B, H, W, Cout] or null
+  bf16_t* y;            // [B, H, W, Cout]
+  int B, H, W, Hs, Ws, Cin, Cout;
+  int R, tiles_per_img, n_tiles, wshift;
+};
+
+constexpr int HV = 5;     // max halo vectors per thread  ((R+2)*(W+2)*4 <= 1280)
+constexpr int CK = 32;
+
+__device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
+
+template <int MODE, int TM, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
+  constexpr int TN = BN / 32;                 // cout 16-tiles per wave (2 x 2 waves)
+  constexpr int WV = (BN * 36 + 255) / 256;   // weight vectors per thread per chunk
+  constexpr int BM = TM * 32;                 // pixels per block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = p.W, R = p.R, WH = W + 2;
+  const int npix_h = (R + 2) * WH;
+  const int KT = R * W;                       // valid pixels of the tile (<= BM)
+  unsigned char* Xs = smem;                   // [npix_h][64 B]
+  unsigned char* Ws = smem + (size_t)npix_h * 64;   // [9][BN][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
+  const int wm0 = (wave & 1) * (BM / 2), wn0 = (wave >> 1) * (BN / 2);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // per-lane fragment bases
+  int hbase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+    if (pl >= KT) pl = 0;
+    int oy = pl >> p.wshift, ox = pl & (W - 1);
+    hbase[i] = oy * WH + ox;
+  }
+  int wbase[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    int n = wn0 + a * 16 + fr;
+    wbase[a] = n * 64 + swz(n, fq) * 16;
+  }
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 hreg[HV], wreg[WV];
+  const int nchunks = p.Cin / CK;
+
+  auto load_chunk = [&](int ck) {
+    const int c0 = ck * CK;
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      int idx = tid + k * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < npix_h * 4) {
+        int pix = idx >> 2, ch = idx & 3;
+        int hy = pix / WH, hx = pix - hy * WH;
+        int iy = oy0 + hy - 1, ix = hx - 1;
+        bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+        if (MODE == 3) ok = ok && !((iy | ix) & 1);
+        if (MODE != 0) { iy >>= 1; ix >>= 1; }
+        if (ok) v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + ch * 8);
+      }
+      hreg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      int idx = tid + k * 256;            // over [BN][9][4]
+      int ch = idx & 3, r = idx >> 2;
+      int tap = r % 9, n = r / 9;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < BN * 36 && n0 + n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)(n0 + n) * 9 + tap) * p.Cin + c0 + ch * 8);
+      wreg[k] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      int idx = tid + k * 256;
+      if (idx < npix_h * 4) {
+        int pix = idx >> 2, ch = idx & 3;
+        *reinterpret_cast<uint4*>(Xs + pix * 64 + swz(pix, ch) * 16) = hreg[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      int idx = tid + k * 256;
+      int ch = idx & 3, r = idx >> 2;
+      int tap = r % 9, n = r / 9;
+      if (idx < BN * 36) *reinterpret_cast<uint4*>(Ws + (tap * BN + n) * 64 + swz(n, ch) * 16) = wreg[k];
+    }
+  };
+
+  load_chunk(0);
+  for (int ck = 0; ck < nchunks; ++ck) {
+    store_chunk();
+    __syncthreads();
+    if (ck + 1 < nchunks) load_chunk(ck + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * WH + (tap % 3);
+      bf16x8_t wf[TN], xf[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Ws + tap * BN * 64 + wbase[a]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int h = hbase[i] + toff;
+        xf[i] = *reinterpret_cast<const bf16x8_t*>(Xs + h * 64 + swz(h, fq) * 16);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds couts n..n+3 of pixel pl
+  const bool vec_ok = (p.Cout & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+    if (pl >= KT) continue;
+    size_t m = (size_t)(b * p.H + oy0) * W + pl;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      int n = n0 + wn0 + a * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      float o[4] = {acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]};
+      size_t e = m * p.Cout + n;
+      if (vec_ok) {
+        if (p.bias) {
+          float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+        }
+        if (p.res) {
+          uint2 rv = *reinterpret_cast<const uint2*>(p.res + e);
+          o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+          o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+        }
+        uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>(p.y + e) = make_uint2(lo, hi);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Cout) {
+            float v = o[r] + (p.bias ? p.bias[n + r] : 0.f) + (p.res ? bf16_to_f32(p.res[e + r]) : 0.f);
+            p.y[e + r] = f32_to_bf16(v);
+          }
+      }
+    }
+  }
+}
+
+template <int MODE, int TM, int BN>
+void launch(const C3P& p, hipStream_t st) {
+  size_t lds = ((size_t)(p.R + 2) * (p.W + 2) + 9 * BN) * 64;
+  hipLaunchKernelGGL((conv3x3_halo_bf16<MODE, TM, BN>), dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+// mode: 0 stride 1, 2 nearest-x2-upsampled input, 3 zero-stuffed x2 input (transposed stride 2).
+// H, W = OUTPUT dims.  Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (the
+// caller falls back to idf_conv2d_fwd).
+extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
+                                int H, int W, int Cin, int Cout, int mode, void* stream) {
+  if ((mode != 0 && mode != 2 && mode != 3) || (Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 ||
+      (mode != 0 && ((H | W) & 1)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: B%d H%d W%d Cin%d Cout%d mode%d not covered", B, H, W, Cin, Cout, mode);
+  if (B == 0) return IDF_OK;
+  C3P p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Hs = mode ? H / 2 : H; p.Ws = mode ? W / 2 : W;
+  int ws = 0;
+  while ((1 << ws) < W) ++ws;
+  p.wshift = ws;
+  // 128-pixel tiles when the problem is big enough to still fill the chip, else 64
+  long M = (long)B * H * W;
+  int BM = (M * Cout >= (long)128 * 64 * 512 && H * W >= 128) ? 128 : 64;
+  int R = BM / W;
+  if (R < 1) R = 1;
+  if (R > H) R = H;
+  while (H % R) --R;
+  if ((R + 2) * (W + 2) * 4 > HV * 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
+  p.R = R; p.tiles_per_img = H / R;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bn32 = Cout <= 32;
+  p.n_tiles = idf_cdiv(Cout, bn32 ? 32 : 64);
+#define IDF_C3_LAUNCH(MODE)                                              \
+  do {                                                                   \
+    if (bn32) { if (BM == 128) launch<MODE, 4, 32>(p, st); else launch<MODE, 2, 32>(p, st); } \
+    else { if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); }      \
+  } while (0)
+  if (mode == 0) IDF_C3_LAUNCH(0);
+  else if (mode == 2) IDF_C3_LAUNCH(2);
+  else IDF_C3_LAUNCH(3);
+#undef IDF_C3_LAUNCH
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

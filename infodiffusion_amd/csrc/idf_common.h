@@ -89,10 +89,12 @@ template <> struct Vec16<bf16_t> {
   }
 };
 
-__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// sigmoid via v_exp + v_rcp (1 ulp each): no IEEE division sequence in the HBM-bound passes
+__device__ __forceinline__ float sigmoid_f(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_f(float u) { return u * sigmoid_f(u); }
 // d/du [u * sigmoid(u)]
 __device__ __forceinline__ float dsilu_f(float u) {
-  float s = 1.0f / (1.0f + __expf(-u));
+  float s = sigmoid_f(u);
   return s * (1.0f + u * (1.0f - s));
 }
 

@@ -216,35 +216,36 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict_
   }
 }
 
-// elementwise: dx = sc*du + k1*x + k0 (+ dres)
+// elementwise: dx = sc*du + k1*x + k0 (+ dres).  grid (nchunk, B): a thread keeps one
+// 16-byte channel slot for its whole pixel loop, so the per-(b,c) coefficients live in
+// registers and the loop has no integer division.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply(const T* __restrict__ dA, const T* __restrict__ x,
                                                     const T* __restrict__ dres, T* __restrict__ dx,
                                                     const float* __restrict__ sc, const float* __restrict__ sh,
                                                     const float* __restrict__ k1, const float* __restrict__ k0,
-                                                    int HW, int C, long nvec, int act, const uint64_t* seed,
+                                                    int HW, int C, int chunk, int act, const uint64_t* seed,
                                                     uint32_t salt, uint32_t thr, float dscale) {
   constexpr int VE = Elem<T>::VE;
-  const int vpp = C / VE, cpg = C / G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    long pix = i / vpp;
-    int v = (int)(i - pix * vpp);
-    int b = (int)(pix / HW);
-    size_t e0 = (size_t)i * VE;
-    float xv[VE], dav[VE], du[VE], scv[VE], shv[VE], o[VE];
+  const int vpp = C / VE, lanes = 256 / vpp, cpg = C / G, tid = threadIdx.x;
+  const int b = blockIdx.y, v = tid % vpp, pl = tid / vpp;
+  if (pl >= lanes) return;
+  float scv[VE], shv[VE], k1v[VE], k0v[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    int c = v * VE + e, g = c / cpg;
+    scv[e] = sc[(size_t)b * C + c]; shv[e] = sh[(size_t)b * C + c];
+    k1v[e] = k1[b * G + g]; k0v[e] = k0[b * G + g];
+  }
+  const int pend = min(HW, (int)(blockIdx.x + 1) * chunk);
+  for (int p = blockIdx.x * chunk + pl; p < pend; p += lanes) {
+    size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+    float xv[VE], dav[VE], du[VE], o[VE];
     Vec16<T>::load(x + e0, xv);
     Vec16<T>::load(dA + e0, dav);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      scv[e] = sc[(size_t)b * C + v * VE + e];
-      shv[e] = sh[(size_t)b * C + v * VE + e];
-    }
     du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      int g = (v * VE + e) / cpg;
-      o[e] = scv[e] * du[e] + k1[b * G + g] * xv[e] + k0[b * G + g];
-    }
+    for (int e = 0; e < VE; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
     if (dres) {
       float rv[VE];
       Vec16<T>::load(dres + e0, rv);
@@ -255,26 +256,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const T* __restrict__ dA, co
   }
 }
 
-// elementwise: a = dropout(SiLU(x*sc + sh))  (act 2)  or  x*sc + sh  (act 1)
+// elementwise: a = dropout(SiLU(x*sc + sh))  (act 2)  or  x*sc + sh  (act 1); same geometry
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                        const float* __restrict__ sc, const float* __restrict__ sh,
-                                                       int HW, int C, long nvec, int act, const uint64_t* seed,
+                                                       int HW, int C, int chunk, int act, const uint64_t* seed,
                                                        uint32_t salt, uint32_t thr, float dscale) {
   constexpr int VE = Elem<T>::VE;
-  const int vpp = C / VE;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    long pix = i / vpp;
-    int v = (int)(i - pix * vpp);
-    int b = (int)(pix / HW);
-    size_t e0 = (size_t)i * VE;
+  const int vpp = C / VE, lanes = 256 / vpp, tid = threadIdx.x;
+  const int b = blockIdx.y, v = tid % vpp, pl = tid / vpp;
+  if (pl >= lanes) return;
+  float scv[VE], shv[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    scv[e] = sc[(size_t)b * C + v * VE + e];
+    shv[e] = sh[(size_t)b * C + v * VE + e];
+  }
+  const int pend = min(HW, (int)(blockIdx.x + 1) * chunk);
+  for (int p = blockIdx.x * chunk + pl; p < pend; p += lanes) {
+    size_t e0 = ((size_t)b * HW + p) * C + v * VE;
     float xv[VE];
     Vec16<T>::load(x + e0, xv);
-    const float* scp = sc + (size_t)b * C + v * VE;
-    const float* shp = sh + (size_t)b * C + v * VE;
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      float u = xv[e] * scp[e] + shp[e];
+      float u = xv[e] * scv[e] + shv[e];
       if (act == 2) {
         u = silu_f(u);
         if (seed) u = idf_keep(*seed, salt, e0 + e, thr) ? u * dscale : 0.f;
@@ -290,6 +295,15 @@ int pick_chunk(int B, int HW) {
   int nchunk = idf_cdiv(1024, B);
   int chunk = idf_cdiv(HW, nchunk);
   if (chunk < 64) chunk = 64;
+  if (chunk > HW) chunk = HW;
+  return chunk;
+}
+
+// elementwise passes: more, smaller blocks (no partial buffers to pay for)
+int pick_chunk_ew(int B, int HW) {
+  int nchunk = idf_cdiv(4096, B);
+  int chunk = idf_cdiv(HW, nchunk);
+  if (chunk < 32) chunk = 32;
   if (chunk > HW) chunk = HW;
   return chunk;
 }
@@ -350,15 +364,14 @@ extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, 
   hipLaunchKernelGGL(gn_bwd_finalize, dim3(B), dim3(256), 2 * C * sizeof(float), st, (const float2*)workspace, nchunk,
                      HW, C, gamma, beta, film_t, film_a, mean, rstd, k1, k0, dfilm_t, dfilm_a, dgb);
   IDF_CHECK_LAUNCH();
-  long nvec = (long)B * HW * C / VE;
-  int blocks = (int)((nvec + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
+  int achunk = pick_chunk_ew(B, HW);
+  dim3 ga(idf_cdiv(HW, achunk), B);
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_bwd_apply<float>, dim3(blocks), dim3(256), 0, st, (const float*)dA, (const float*)x,
-                       (const float*)dres, (float*)dx, sc, sh, k1, k0, HW, C, nvec, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_bwd_apply<float>, ga, dim3(256), 0, st, (const float*)dA, (const float*)x,
+                       (const float*)dres, (float*)dx, sc, sh, k1, k0, HW, C, achunk, act, sd, salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dA, (const bf16_t*)x,
-                       (const bf16_t*)dres, (bf16_t*)dx, sc, sh, k1, k0, HW, C, nvec, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_bwd_apply<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dA, (const bf16_t*)x,
+                       (const bf16_t*)dres, (bf16_t*)dx, sc, sh, k1, k0, HW, C, achunk, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -374,15 +387,15 @@ extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const flo
   uint32_t thr = idf_drop_thresh(p_drop);
   float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
   const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
-  long nvec = (long)B * HW * C / VE;
-  int blocks = (int)((nvec + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
+  if (C / VE > 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_apply: C=%d unsupported", C);
+  int achunk = pick_chunk_ew(B, HW);
+  dim3 ga(idf_cdiv(HW, achunk), B);
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, sc, sh, HW,
-                       C, nvec, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)x, (float*)out, sc, sh, HW, C,
+                       achunk, act, sd, salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, sc, sh,
-                       HW, C, nvec, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, sc, sh, HW, C,
+                       achunk, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

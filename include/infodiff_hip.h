@@ -82,10 +82,11 @@ int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fw
  * Writes mean/rstd [B,32] and the per-(b,c) affine sc/sh [B,C]:
  *   sc = rstd*gamma*(1+s_t)*(1+s_a),  sh = ((beta-mean*rstd*gamma)*(1+s_t)+b_t)*(1+s_a)+b_a
  * film_t / film_a: [B,2C] (scale = first half, shift = second half; torch.chunk order,
- * modules.py:314,317) or NULL.  workspace: idf_gn_workspace_floats(B,HW,C) floats. */
+ * modules.py:314,317) or NULL; ld_t / ld_a = their row strides in floats (0 = dense 2C) so a slice
+ * of one batched FiLM projection can be consumed in place.  workspace: idf_gn_workspace_floats(B,HW,C) floats. */
 int idf_gn_workspace_floats(int B, int HW, int C);
 int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
-                    const float* film_a, float eps, float* mean, float* rstd, float* sc, float* sh,
+                    const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc, float* sh,
                     float* workspace, int B, int HW, int C, int dtype, void* stream);
 /* a = act(x*sc+sh) materialised once (act 1 affine, 2 SiLU + dropout): GroupNorm-apply + FiLM +
  * SiLU + Dropout of modules.py:264-288, 312-319 as one read + one write */
@@ -95,8 +96,8 @@ int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, con
  * dx (+ dres), dfilm_t/dfilm_a [B,2C], dgb [B][2][C] (per-sample dgamma, dbeta;
  * sum over B with idf_colsum), k1/k0 [B,32] scratch. */
 int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
-                    const float* beta, const float* film_t, const float* film_a, const float* mean,
-                    const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
+                    const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
+                    const float* mean, const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
                     float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed, uint32_t salt,
                     float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 

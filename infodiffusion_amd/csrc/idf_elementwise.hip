@@ -208,6 +208,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     __syncthreads();
   }
 }
+// few rows (per-sample partials, linear biases): one thread per column, no second pass
+template <typename T>
+__global__ void colsum_small_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int N) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += Elem<T>::ld(in + (size_t)r * N + c);
+  out[c] = s;
+}
+
 // one wave per column
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out) {
   int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -368,6 +378,14 @@ extern "C" int idf_colsum_blocks(long R) {
   return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb));
 }
 extern "C" int idf_colsum(const void* in, float* out, float* workspace, long R, int N, int in_dtype, void* stream) {
+  if (R <= 512) {
+    if (in_dtype == IDF_F32)
+      hipLaunchKernelGGL(colsum_small_kernel<float>, dim3((N + 63) / 64), dim3(64), 0, ST, (const float*)in, out, (int)R, N);
+    else
+      hipLaunchKernelGGL(colsum_small_kernel<bf16_t>, dim3((N + 63) / 64), dim3(64), 0, ST, (const bf16_t*)in, out, (int)R, N);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+  }
   int nb = idf_colsum_blocks(R);
   long rpb = (R + nb - 1) / nb;
   int ncol = N < 256 ? N : 256;

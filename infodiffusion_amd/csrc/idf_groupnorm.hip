@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const T* __restrict__ x,
 __global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ part, int nchunk, int HW, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ film_t, const float* __restrict__ film_a,
-                                                   float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                   int ld_t, int ld_a, float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ sc, float* __restrict__ sh) {
   __shared__ float sm[G], sr[G];
   const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
@@ -90,12 +90,12 @@ __global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ pa
     float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     float a = sr[g] * ga, d = be - sm[g] * a;
     if (film_t) {
-      float f = 1.f + film_t[(size_t)b * 2 * C + c];
-      a *= f; d = d * f + film_t[(size_t)b * 2 * C + C + c];
+      float f = 1.f + film_t[(size_t)b * ld_t + c];
+      a *= f; d = d * f + film_t[(size_t)b * ld_t + C + c];
     }
     if (film_a) {
-      float f = 1.f + film_a[(size_t)b * 2 * C + c];
-      a *= f; d = d * f + film_a[(size_t)b * 2 * C + C + c];
+      float f = 1.f + film_a[(size_t)b * ld_a + c];
+      a *= f; d = d * f + film_a[(size_t)b * ld_a + C + c];
     }
     sc[(size_t)b * C + c] = a; sh[(size_t)b * C + c] = d;
   }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial(const T* __restrict__ dA, 
 __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict__ part, int nchunk, int HW, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ film_t, const float* __restrict__ film_a,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int ld_t, int ld_a, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        float* __restrict__ k1, float* __restrict__ k0,
                                                        float* __restrict__ dfilm_t, float* __restrict__ dfilm_a,
                                                        float* __restrict__ dgb) {
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict_
     float D1 = S1, D2 = r * (S2 - mu * S1);
     float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     float st = 0.f, bt = 0.f, sa = 0.f;
-    if (film_t) { st = film_t[(size_t)b * 2 * C + c]; bt = film_t[(size_t)b * 2 * C + C + c]; }
-    if (film_a) { sa = film_a[(size_t)b * 2 * C + c]; }
+    if (film_t) { st = film_t[(size_t)b * ld_t + c]; bt = film_t[(size_t)b * ld_t + C + c]; }
+    if (film_a) { sa = film_a[(size_t)b * ld_a + c]; }
     float f = (1.f + st) * (1.f + sa);
     float Gf = ga * D2 + be * D1, Ge = D1;
     if (dfilm_t) {
@@ -317,7 +317,7 @@ extern "C" int idf_gn_workspace_floats(int B, int HW, int C) {
 }
 
 extern "C" int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
-                               const float* film_a, float eps, float* mean, float* rstd, float* sc, float* sh,
+                               const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc, float* sh,
                                float* workspace, int B, int HW, int C, int dtype, void* stream) {
   if (B == 0) return IDF_OK;
   int VE = dtype == IDF_F32 ? 4 : 8;
@@ -333,14 +333,14 @@ extern "C" int idf_gn_coef_fwd(const void* x, const float* gamma, const float* b
     hipLaunchKernelGGL(gn_stats_partial<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)x, (float2*)workspace, HW, C, chunk);
   IDF_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_finalize, dim3(B), dim3(256), 0, st, (const float2*)workspace, nchunk, HW, C, gamma, beta,
-                     film_t, film_a, eps, mean, rstd, sc, sh);
+                     film_t, film_a, ld_t ? ld_t : 2 * C, ld_a ? ld_a : 2 * C, eps, mean, rstd, sc, sh);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
 
 extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
-                               const float* beta, const float* film_t, const float* film_a, const float* mean,
-                               const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
+                               const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
+                               const float* mean, const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
                                float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed,
                                uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
   if (B == 0) return IDF_OK;
@@ -362,7 +362,8 @@ extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, 
                        (float2*)workspace, HW, C, chunk, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_finalize, dim3(B), dim3(256), 2 * C * sizeof(float), st, (const float2*)workspace, nchunk,
-                     HW, C, gamma, beta, film_t, film_a, mean, rstd, k1, k0, dfilm_t, dfilm_a, dgb);
+                     HW, C, gamma, beta, film_t, film_a, ld_t ? ld_t : 2 * C, ld_a ? ld_a : 2 * C, mean, rstd, k1, k0,
+                     dfilm_t, dfilm_a, dgb);
   IDF_CHECK_LAUNCH();
   int achunk = pick_chunk_ew(B, HW);
   dim3 ga(idf_cdiv(HW, achunk), B);

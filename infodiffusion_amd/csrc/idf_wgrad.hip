@@ -199,8 +199,13 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
   if (R > H) R = H;
   if (R < 1 || (H % R) || ((R * W) % 32)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * taps * Cin * sizeof(float), st);
-  if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
+  const size_t nW = (size_t)Cout * taps * Cin;
+  hipError_t e;
+  if (db == dW + nW) e = hipMemsetAsync(dW, 0, (nW + Cout) * sizeof(float), st);   // caller packed dW | db
+  else {
+    e = hipMemsetAsync(dW, 0, nW * sizeof(float), st);
+    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
+  }
   if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: memset failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
   WgP p;

@@ -11,7 +11,7 @@ from torch.nn import init
 
 from . import ops
 from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
-                      _Shadows, _cfg, _ACT_NONE, _ACT_SILU, bind_context, timestep_embedding)
+                      _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, timestep_embedding)
 from .utils import compute_mmd, gaussian_mixture, swiss_roll
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
@@ -65,6 +65,10 @@ class _UNetSkeleton(nn.Module):
         self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)
         self._cfg_tail = _cfg(_Shadows(self.tail[-1]), ops.S1, 9, _ACT_SILU)
 
+    def _res_blocks(self):
+        return [m for m in list(self.downblocks) + list(self.middleblocks) + list(self.upblocks)
+                if not isinstance(m, (DownSample, UpSample))]
+
     def _prep(self, x):
         if not x.is_cuda:
             raise RuntimeError('infodiffusion_amd runs on the GPU only: the HIP kernels have no CPU fallback')
@@ -110,6 +114,7 @@ class UNet(_UNetSkeleton):
     def forward(self, x, t):
         x = self._prep(x)
         temb = self.time_embedding(t)
+        batched_film(self._res_blocks(), temb, 't')
         return self._run(x, lambda blk, h: blk(h, temb))
 
 
@@ -138,6 +143,9 @@ class AuxiliaryUNet(_UNetSkeleton):
         x = self._prep(x)
         aemb = ops.linear(a, self.fc_a.weight, self.fc_a.bias)
         temb = self.time_embedding(t)
+        blocks = self._res_blocks()
+        batched_film(blocks, temb, 't')
+        batched_film(blocks, aemb, 'a')
         return self._run(x, lambda blk, h: blk(h, temb, aemb))
 
 

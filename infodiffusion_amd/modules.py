@@ -57,8 +57,10 @@ class _Shadows:
         if key != self.key:
             self.key, self.val = key, [None, None]
         if self.val[0] is None or (need_dgrad and self.val[1] is None):
+            # when gradients are being recorded the data-gradient shadow will be needed too: one launch
+            want_d = (need_dgrad or torch.is_grad_enabled()) and self.val[1] is None
             with torch.no_grad():
-                wf, wd = ops.pack_weight(self.weight(), dtype, self.val[0] is None, need_dgrad)
+                wf, wd = ops.pack_weight(self.weight(), dtype, self.val[0] is None, want_d)
             if wf is not None:
                 self.val[0] = wf
             if wd is not None:
@@ -199,6 +201,7 @@ class _ResBase(nn.Module):
         self.attn = AttnBlock(out_ch) if attn else nn.Identity()
 
     def _setup(self, dropout):
+        self._film = {}      # FiLM pairs the parent network projected in one batched GEMM (consumed per call)
         self.ctx = RunCtx()
         self.salt = 0
         self.p_drop = dropout
@@ -237,7 +240,9 @@ class ResBlock(_ResBase):
 
     def forward(self, x, temb):
         h = self._gn_conv('block1', x)
-        ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
+        ft = self._film.pop('t', None) if self._film else None
+        if ft is None:
+            ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
         h = self._gn_conv('block2', h, film_t=ft, drop_site=1)
         h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
         return self.attn(h)
@@ -261,8 +266,12 @@ class AuxResBlock(_ResBase):
 
     def forward(self, x, temb, aemb=None):
         h = self._gn_conv('block1', x)
-        ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
-        fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
+        ft = self._film.pop('t', None) if self._film else None
+        fa = self._film.pop('a', None) if self._film else None
+        if ft is None:
+            ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
+        if fa is None:
+            fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
         h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1)
         h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
         h = self.attn(h)
@@ -294,3 +303,16 @@ def bind_context(net, ctx):
         if isinstance(m, _ResBase):
             m.ctx = ctx
             m.salt = 4 * i
+
+
+def batched_film(blocks, emb, which):
+    """All blocks' FiLM projections Linear(SiLU(emb)) (modules.py:269-276, 312, 316) as ONE
+    GEMM over the concatenated weights; each block then reads its [B, 2C] column slice in
+    place (row stride = total width).  `which`: 't' (temb_proj) or 'a' (aemb_proj)."""
+    name = 'temb_proj' if which == 't' else 'aemb_proj'
+    lins = [getattr(b, name)[1] for b in blocks]
+    W = torch.cat([l.weight for l in lins], dim=0)
+    bias = torch.cat([l.bias for l in lins], dim=0)
+    out = ops.linear(emb, W, bias, silu_in=True)
+    for blk, chunk in zip(blocks, out.split([l.weight.shape[0] for l in lins], dim=1)):
+        blk._film[which] = chunk

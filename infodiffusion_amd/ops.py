@@ -44,6 +44,14 @@ def _f32c(t):
     return None if t is None else t.contiguous().float()
 
 
+def _ld(film):
+    """Row stride (floats) of a [B, 2C] FiLM tensor that may be a column slice of a batched projection."""
+    if film is None:
+        return 0
+    assert film.dtype == torch.float32 and film.stride(1) == 1
+    return film.stride(0)
+
+
 def empty_nhwc(B, C, H, W, dtype, device):
     return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=CL)
 
@@ -137,7 +145,8 @@ def gn_coef_fwd_raw(x, gamma, beta, film_t, film_a):
     sc = torch.empty((B, C), dtype=torch.float32, device=dev)
     sh = torch.empty((B, C), dtype=torch.float32, device=dev)
     ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
-    call('idf_gn_coef_fwd', _p(x), _p(gamma), _p(beta), _p(film_t), _p(film_a), GN_EPS, _p(mean), _p(rstd),
+    call('idf_gn_coef_fwd', _p(x), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS,
+         _p(mean), _p(rstd),
          _p(sc), _p(sh), _p(ws), B, H * W, C, _dt(x), _st())
     return mean, rstd, sc, sh
 
@@ -146,14 +155,14 @@ def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh
     B, C, H, W = x.shape
     dev = x.device
     dx = torch.empty_like(x, memory_format=CL)
-    dft = torch.empty_like(film_t) if film_t is not None else None
-    dfa = torch.empty_like(film_a) if film_a is not None else None
+    dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
+    dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
     k1 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     k0 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
     call('idf_gn_coef_bwd', _p(dA), _p(x), _p(dres), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a),
-         _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(k1), _p(k0), _p(ws), _p(seed),
+         _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(k1), _p(k0), _p(ws), _p(seed),
          salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
@@ -206,8 +215,10 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias):
         ap, dyp = _pad_channels(a), _pad_channels(dy)
         Cip, Cop = ap.shape[1], dyp.shape[1]
         if _fast_wgrad_ok(Cip, Cop, Ho, Wo, a.dtype, mode, taps):
-            dW = torch.empty((Cop, k, k, Cip), dtype=torch.float32, device=a.device)
-            db = torch.empty((Cop,), dtype=torch.float32, device=a.device) if want_bias else None
+            nW = Cop * k * k * Cip
+            buf = torch.empty((nW + Cop,), dtype=torch.float32, device=a.device)   # dW | db: one memset
+            dW = buf[:nW].view(Cop, k, k, Cip)
+            db = buf[nW:] if want_bias else None
             call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, _st())
             dW = dW.permute(0, 3, 1, 2)
             if Cip != Cin or Cop != Cout:

@@ -92,37 +92,63 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
   // transposed-read lane geometry
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 
-  for (int t = t_beg; t < t_end; ++t) {
+  // register double-buffering: tile t+1 is fetched while tile t is in the MFMAs
+  constexpr int XV = 5, DV = 4;           // 16-byte vectors per thread (input rows / dy)
+  uint4 xreg[XV], dreg[DV];
+  auto load_tile = [&](int t) {
     const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
-    // ---- stage the input rows this kernel row touches (zero outside the image)
-    for (int idx = tid; idx < npix_h * 8; idx += 256) {
-      int pix = idx >> 3;
-      int hy = pix / WH, hx = pix - hy * WH;
-      int iy = SX * (oy0 + hy) + ky - HALO, ix = hx - HALO;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
-        if (MODE == 2) { iy >>= 1; ix >>= 1; }
-        val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + v8 * 8);
-      }
-      *reinterpret_cast<uint4*>(Xs + (size_t)pix * PITCH + v8 * 8) = val;
-    }
-    // ---- stage the dy tile
-    for (int idx = tid; idx < KT * 8; idx += 256) {
-      int pix = idx >> 3;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (nvalid)
-        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + pix) * p.Cout + n0 + v8 * 8);
-      *reinterpret_cast<uint4*>(Ds + (size_t)pix * PITCH + v8 * 8) = val;
-      if (do_db) {
-        uint32_t w4[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dbs[2 * e] += __uint_as_float(w4[e] << 16);
-          dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+    for (int k = 0; k < XV; ++k) {
+      int idx = tid + k * 256;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (idx < npix_h * 8) {
+        int pix = idx >> 3;
+        int hy = pix / WH, hx = pix - hy * WH;
+        int iy = SX * (oy0 + hy) + ky - HALO, ix = hx - HALO;
+        if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
+          if (MODE == 2) { iy >>= 1; ix >>= 1; }
+          val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + v8 * 8);
+        }
+      }
+      xreg[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      int idx = tid + k * 256;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (idx < KT * 8 && nvalid)
+        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + (idx >> 3)) * p.Cout + n0 + v8 * 8);
+      dreg[k] = val;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      int idx = tid + k * 256;
+      if (idx < npix_h * 8) *reinterpret_cast<uint4*>(Xs + (size_t)(idx >> 3) * PITCH + v8 * 8) = xreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      int idx = tid + k * 256;
+      if (idx < KT * 8) {
+        *reinterpret_cast<uint4*>(Ds + (size_t)(idx >> 3) * PITCH + v8 * 8) = dreg[k];
+        if (do_db) {
+          uint32_t w4[4] = {dreg[k].x, dreg[k].y, dreg[k].z, dreg[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dbs[2 * e] += __uint_as_float(w4[e] << 16);
+            dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+          }
         }
       }
     }
+  };
+
+  if (t_beg < t_end) load_tile(t_beg);
+  for (int t = t_beg; t < t_end; ++t) {
+    store_tile();
     __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);
     // ---- MFMA over the tile's pixels, 32 per step.  Logical k slot (g, j) maps to
     // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
     for (int ks = 0; ks < KT; ks += 32) {
@@ -197,7 +223,8 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
              Cout, taps, mode);
   int R = (mode == 1 ? 64 : 128) / W;
   if (R > H) R = H;
-  if (R < 1 || (H % R) || ((R * W) % 32)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
+  if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
   hipStream_t st = (hipStream_t)stream;
   const size_t nW = (size_t)Cout * taps * Cin;
   hipError_t e;

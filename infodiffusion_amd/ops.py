@@ -189,7 +189,7 @@ def _fast_wgrad_ok(Cin, Cout, Ho, Wo, dtype, mode, taps):
     if Cin % 8 or Cout % 8 or Wo < 4 or (Wo & (Wo - 1)):
         return False
     R = min(Ho, (64 if mode == S2 else 128) // Wo)
-    return R >= 1 and Ho % R == 0 and (R * Wo) % 32 == 0
+    return R >= 1 and Ho % R == 0 and (R * Wo) % 32 == 0 and R * ((2 if mode == S2 else 1) * Wo + 2) <= 160
 
 
 def _pad_channels(t, mult=8):

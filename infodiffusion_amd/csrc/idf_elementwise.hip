@@ -213,9 +213,16 @@ template <typename T>
 __global__ void colsum_small_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int N) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += Elem<T>::ld(in + (size_t)r * N + c);
-  out[c] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // independent chains keep 4+ loads in flight
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {
+    s0 += Elem<T>::ld(in + (size_t)r * N + c);
+    s1 += Elem<T>::ld(in + (size_t)(r + 1) * N + c);
+    s2 += Elem<T>::ld(in + (size_t)(r + 2) * N + c);
+    s3 += Elem<T>::ld(in + (size_t)(r + 3) * N + c);
+  }
+  for (; r < R; ++r) s0 += Elem<T>::ld(in + (size_t)r * N + c);
+  out[c] = (s0 + s1) + (s2 + s3);
 }
 
 // one wave per column

@@ -57,8 +57,7 @@ class _Shadows:
         if key != self.key:
             self.key, self.val = key, [None, None]
         if self.val[0] is None or (need_dgrad and self.val[1] is None):
-            # when gradients are being recorded the data-gradient shadow will be needed too: one launch
-            want_d = (need_dgrad or torch.is_grad_enabled()) and self.val[1] is None
+            want_d = need_dgrad and self.val[1] is None
             with torch.no_grad():
                 wf, wd = ops.pack_weight(self.weight(), dtype, self.val[0] is None, want_d)
             if wf is not None:

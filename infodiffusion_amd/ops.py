@@ -241,7 +241,7 @@ class _FusedConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg):
+    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False):
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
@@ -251,7 +251,7 @@ class _FusedConv(torch.autograd.Function):
         if act:
             mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
             a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
-        w_fwd = cfg['shadows'](x.dtype, False)[0]
+        w_fwd = cfg['shadows'](x.dtype, train)[0]
         y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, weight.shape[0])
         ctx.cfg, ctx.p_drop = cfg, p_drop
         ctx.has_res = residual is not None
@@ -285,11 +285,12 @@ class _FusedConv(torch.autograd.Function):
                 dx = dA
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None
 
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None):
-    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg)
+    train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
+    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train)
 
 
 # ------------------------------------------------------------------ attention
@@ -366,8 +367,12 @@ class _Linear(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = dW = db = None
         if need[0]:
-            dxs = torch.empty_like(x)
-            bgemm_raw(dy, 0, w, 0, dxs, 0, None, 1, 0, 0, 0, N, K, K, Bn, K, N, 0, 1, dtype=F32)
+            # few output tiles but a long contraction (batched FiLM: N ~ 5k): split K over blocks
+            tiles = -(-Bn // 64) * -(-K // 64)
+            sk = max(1, min(32, N // 256)) if tiles < 64 else 1
+            dxs = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
+            bgemm_raw(dy, 0, w, 0, dxs, 0, None, 1, 0, 0, 0, N, K, K, Bn, K, N, 0, 1, out_f32=True, splitk=sk,
+                      dtype=F32)
             if ctx.silu_in:
                 dx = torch.empty_like(x)
                 call('idf_silu_bwd', _p(x), _p(dxs), _p(dx), x.numel(), _st())

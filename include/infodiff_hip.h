@@ -139,6 +139,13 @@ int idf_colsum_blocks(long R);
 int idf_colsum(const void* in, float* out, float* workspace, long R, int N, int in_dtype, void* stream);
 /* 2x2 sum pool [B,2Ho,2Wo,C] -> [B,Ho,Wo,C]: data gradient of the fused nearest upsample */
 int idf_pool2_sum(const void* in, void* out, int B, int Ho, int Wo, int C, int dtype, void* stream);
+/* latent denoiser row kernel (MLPLNAct, models.py:147-163): y = Dropout(SiLU(LayerNorm(lin*(1+cond))*g+b));
+ * stats [R][2] = (mean, rstd); backward writes dlin, dcond and per-row dg|db contributions dgb [R][2W] */
+int idf_ln_silu_fwd(const float* lin, const float* cond, const float* g, const float* b, float* y, float* stats,
+                    int R, int Wd, float eps, const uint64_t* seed, uint32_t salt, float p_drop, void* stream);
+int idf_ln_silu_bwd(const float* lin, const float* cond, const float* g, const float* b, const float* stats,
+                    const float* dy, float* dlin, float* dcond, float* dgb, int R, int Wd, const uint64_t* seed,
+                    uint32_t salt, float p_drop, void* stream);
 /* test hook: the dropout keep-mask (scaled) a call site would apply */
 int idf_dropout_mask(const uint64_t* seed, uint32_t salt, float p_drop, float* mask, long n, void* stream);
 

@@ -41,6 +41,8 @@ SIGNATURES = {
     'idf_colsum_blocks': ([_l], C.c_int),
     'idf_colsum': ([_p, _p, _p, _l, _i, _i, _p], C.c_int),
     'idf_pool2_sum': ([_p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_ln_silu_fwd': ([_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _u32, _f, _p], C.c_int),
+    'idf_ln_silu_bwd': ([_p] * 9 + [_i, _i, _p, _u32, _f, _p], C.c_int),
     'idf_dropout_mask': ([_p, _u32, _f, _p, _l, _p], C.c_int),
 }
 

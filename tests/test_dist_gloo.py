@@ -31,8 +31,9 @@ def _worker(rank, world, port, q):
     net(x).square().mean().backward()
     local = [p.grad.clone() for p in net.parameters()]
     sync.all_reduce_grads()
-    res = {'params': [p.detach().clone() for p in net.parameters()],
-           'local': local, 'avg': [p.grad.clone() for p in net.parameters()],
+    # plain lists: tensors in an mp.Queue travel by fd and die with the worker
+    res = {'params': [p.detach().tolist() for p in net.parameters()],
+           'local': [t.tolist() for t in local], 'avg': [p.grad.tolist() for p in net.parameters()],
            'dead_none': all(p.grad is None for p in dead.parameters()),
            'shard': shard_range(10, rank, world)}
     q.put((rank, res))
@@ -52,9 +53,11 @@ def test_grad_allreduce_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     a, b = got[0], got[1]
+    T = torch.tensor
     for pa, pb in zip(a['params'], b['params']):
-        assert torch.equal(pa, pb)                      # broadcast made replicas identical
+        assert torch.equal(T(pa), T(pb))                # broadcast made replicas identical
     for la, lb, ga, gb in zip(a['local'], b['local'], a['avg'], b['avg']):
+        la, lb, ga, gb = T(la), T(lb), T(ga), T(gb)
         want = (la + lb) / 2
         assert torch.allclose(ga, want, atol=1e-7) and torch.equal(ga, gb)
     assert a['dead_none'] and b['dead_none']

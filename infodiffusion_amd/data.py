@@ -1,0 +1,60 @@
+"""Dataset configuration (reference data.py:63-102, reproduced verbatim in behaviour: it
+mutates `args` and returns `shape`) and the batch sources available in this image.
+torchvision is not installed here, so the real loaders (data.py:105-243) are replaced by
+random-pixel batches in the reference's normalisation range ([-1, 1], data.py:170-171) or
+by a user-supplied `.npy` array of images under `--data_dir`."""
+import os
+
+import numpy as np
+import torch
+
+_CFG = {   # dataset: (input_channels, unets/encoder channels, input_size)
+    'fmnist': (1, 32, 32), 'mnist': (1, 32, 32), 'dsprites': (1, 32, 32), 'celeba': (3, 64, 64),
+    'cifar10': (3, 64, 32), 'chairs': (3, 32, 64), 'ffhq': (3, 64, 64),
+}
+
+
+def get_dataset_config(args):
+    c, ch, size = _CFG[args.dataset]
+    args.input_channels = c
+    args.unets_channels = ch
+    args.encoder_channels = ch
+    args.input_size = size
+    return (args.input_channels, args.input_size, args.input_size)
+
+
+class _Batches:
+    """Iterable of `(images,)` tuples (the reference loops unpack `data[0]`, run.py:191-193)."""
+
+    def __init__(self, args, shape, n_batches, device, rank=0, world=1):
+        self.shape, self.n, self.bs, self.device = shape, n_batches, args.batch_size, device
+        self.rank, self.world = rank, world
+        self.array = None
+        path = os.path.join(getattr(args, 'data_dir', './data'), '%s.npy' % args.dataset)
+        if os.path.exists(path):
+            arr = np.load(path, mmap_mode='r')       # uint8 NHWC or float NCHW in [0, 1]
+            self.array = arr
+            self.n = len(arr) // (self.bs * world)
+        self.seed = getattr(args, 'r_seed', 0)
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator(device='cpu')
+        g.manual_seed(self.seed + self.rank)
+        for i in range(self.n):
+            if self.array is None:
+                x = torch.rand(self.bs, *self.shape, generator=g) * 2 - 1
+            else:
+                lo = (i * self.world + self.rank) * self.bs
+                a = torch.from_numpy(np.ascontiguousarray(self.array[lo:lo + self.bs]))
+                if a.dtype == torch.uint8:
+                    a = a.permute(0, 3, 1, 2).float() / 255.0
+                x = (a.float() - 0.5) / 0.5
+            yield (x, torch.zeros(self.bs, dtype=torch.long))
+
+
+def get_dataset(args, shape=None, device='cpu', rank=0, world=1):
+    shape = shape or (args.input_channels, args.input_size, args.input_size)
+    return _Batches(args, shape, getattr(args, 'steps_per_epoch', 100), device, rank, world)

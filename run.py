@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""CLI with the reference's flags (reference run.py:25-97) driving the MI355X-native hot path.
+
+    python run.py --model diff --mode train --mmd_weight 0.1 --a_dim 32 --epochs 50 --dataset celeba \
+        --batch_size 32 --save_epochs 5 --deterministic --prior regular --r_seed 64        # reference run.sh:3
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run.py ... (data parallel)
+
+Modes on the hot path: train, eval, eval_fid, save_latent, train_latent_ddim.  The analysis modes
+(disentangle / interpolate / latent_quality / plot_latent / save_original_img) are outside it
+(SURVEY.md 2, row 7).  Extra flags: --act_dtype {fp32,bf16}, --steps_per_epoch N (synthetic data).
+Images are written as .npy (torchvision is not available in this image).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from infodiffusion_amd.data import get_dataset, get_dataset_config
+from infodiffusion_amd.dist import GradSync, shard_range
+from infodiffusion_amd.models import Diff, InfoDiff
+from infodiffusion_amd.sampling import DiffusionProcess, LatentDiffusionProcess, TwoPhaseDiffusionProcess
+from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter,
+                                     generate_exp_string, seed_everything)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--r_seed', type=int, default=0)
+    p.add_argument('--img_id', type=int, default=0)
+    p.add_argument('--model', required=True, choices=['diff', 'vae', 'vanilla'])
+    p.add_argument('--mode', required=True,
+                   choices=['train', 'eval', 'eval_fid', 'save_latent', 'disentangle', 'interpolate',
+                            'save_original_img', 'latent_quality', 'train_latent_ddim', 'plot_latent'])
+    p.add_argument('--prior', required=True, choices=['regular', '10mix', 'roll'])
+    p.add_argument('--kld_weight', type=float, default=0)
+    p.add_argument('--mmd_weight', type=float, default=0.1)
+    p.add_argument('--use_C', action='store_true', default=False)
+    p.add_argument('--C_max', type=float, default=25)
+    p.add_argument('--dataset', required=True,
+                   choices=['fmnist', 'mnist', 'celeba', 'cifar10', 'dsprites', 'chairs', 'ffhq'])
+    p.add_argument('--img_folder', default='./imgs')
+    p.add_argument('--log_folder', default='./logs')
+    p.add_argument('-e', '--epochs', type=int, default=20)
+    p.add_argument('--save_epochs', type=int, default=5)
+    p.add_argument('--batch_size', type=int, default=64)
+    p.add_argument('--learning_rate', type=float, default=0.0001)
+    p.add_argument('--optimizer', default='adam', choices=['adam'])
+    p.add_argument('--model_folder', default='./models')
+    p.add_argument('--deterministic', action='store_true', default=False)
+    p.add_argument('--input_channels', type=int, default=1)
+    p.add_argument('--unets_channels', type=int, default=64)
+    p.add_argument('--encoder_channels', type=int, default=64)
+    p.add_argument('--input_size', type=int, default=32)
+    p.add_argument('--a_dim', type=int, default=32, required=True)
+    p.add_argument('--beta1', type=float, default=1e-5)
+    p.add_argument('--betaT', type=float, default=1e-2)
+    p.add_argument('--diffusion_steps', type=int, default=1000)
+    p.add_argument('--split_step', type=int, default=500)
+    p.add_argument('--sampling_number', type=int, default=16)
+    p.add_argument('--data_dir', type=str, default='./data')
+    p.add_argument('--tb_logger', action='store_true')
+    p.add_argument('--is_latent', action='store_true')
+    p.add_argument('--is_bottleneck', action='store_true')
+    # extras
+    p.add_argument('--act_dtype', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--steps_per_epoch', type=int, default=100)
+    return p.parse_args(argv)
+
+
+def _dist_setup():
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise RuntimeError('run.py needs an MI355X: the HIP kernels have no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=dev)
+    return world, rank, dev
+
+
+def _model_root(args, latent=False):
+    root = args.model_folder
+    if args.model == 'vanilla':
+        root = os.path.join(root, 'diff')
+    root = os.path.join(root, generate_exp_string(args))
+    return root + '_latent' if latent else root
+
+
+def save_model(args, epoch, model, latent=False):
+    root = _model_root(args, latent)
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, 'model-%d.pth' % epoch)
+    torch.save(model.state_dict(), path)       # reference format: state_dict only (run.py:145-158)
+    print('Saved PyTorch model state to %s' % path)
+
+
+def _fit(args, model, batches, world, rank, latent=False):
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, weight_decay=1e-5)
+    cosine = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=args.epochs, eta_min=0, last_epoch=-1)
+    warm = GradualWarmupScheduler(optimizer=opt, multiplier=2., warm_epoch=1, after_scheduler=cosine)
+    sync = GradSync(model, world) if world > 1 else None
+    if sync is not None:
+        sync.broadcast_parameters()
+    losses = AverageMeter('Loss', ':.4f')
+    progress = ProgressMeter(args.epochs, [losses], prefix='Epoch ')
+    for epoch in range(args.epochs):
+        total, n = torch.zeros((), device=model.device), 0      # accumulated on the device: no per-step host sync
+        for data in batches:
+            x = data[0] if isinstance(data, (tuple, list)) else data
+            x = x.to(device=model.device)
+            loss = model.loss_fn(args=args, x=x, curr_epoch=epoch)
+            opt.zero_grad()
+            loss.backward()
+            if sync is not None:
+                sync.all_reduce_grads()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
+            opt.step()
+            total += loss.detach()
+            n += 1
+        losses.update(float(total) / max(n - 1, 1))   # reference divides by the last index (run.py:205)
+        if rank == 0:
+            progress.display(epoch)
+        warm.step()
+        losses.reset()
+        if (epoch + 1) % args.save_epochs == 0 and rank == 0:
+            save_model(args, epoch + 1, model, latent)
+
+
+def train(args):
+    world, rank, dev = _dist_setup()
+    seed_everything(args.r_seed + rank)
+    shape = get_dataset_config(args)
+    model = (InfoDiff if args.model == 'diff' else Diff)(args, dev, shape)
+    model.train()
+    _fit(args, model, get_dataset(args, shape, dev, rank, world), world, rank)
+
+
+def _load(model, path, dev, strict):
+    print('Loading model from %s' % path)
+    model.load_state_dict(torch.load(path, map_location=dev), strict=strict)
+
+
+def evaluate(args):
+    world, rank, dev = _dist_setup()
+    if args.mode == 'train_latent_ddim':
+        seed_everything(args.r_seed + rank)
+        ds = LatentDataset('%s_%s_latent.npz' % (args.model, generate_exp_string(args).replace('.', '_')))
+        loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=True)
+        model = Diff(args, dev, (1, args.a_dim, args.a_dim))
+        model.train()
+        _fit(args, model, loader, world, rank, latent=True)
+        return
+    seed_everything(args.r_seed + rank)
+    shape = get_dataset_config(args)
+    model = (InfoDiff if args.model == 'diff' else Diff)(args, dev, shape)
+    _load(model, os.path.join(_model_root(args), 'model-%d.pth' % args.epochs), dev, strict=False)
+    model.eval()
+    out_root = os.path.join(args.img_folder, generate_exp_string(args))
+    if args.mode == 'eval':
+        proc = DiffusionProcess(args, model, dev, shape)
+        os.makedirs(os.path.join(out_root, 'eval'), exist_ok=True)
+        for n in range(0, args.sampling_number, args.batch_size):
+            sample = proc.sampling(sampling_number=16)     # reference hard-codes 16 (run.py:259)
+            np.save(os.path.join(out_root, 'eval', 'sample%05d.npy' % n), sample.float().cpu().numpy())
+    elif args.mode == 'eval_fid':
+        sub = 'eval-fid-latent' if args.is_latent else 'eval-fid-fast'
+        os.makedirs(os.path.join(out_root, sub), exist_ok=True)
+        proc = DiffusionProcess(args, model, dev, shape)
+        if args.is_latent:
+            model2 = Diff(args, dev, (1, args.a_dim, args.a_dim))
+            _load(model2, os.path.join(_model_root(args, latent=True), 'model-%d.pth' % args.epochs), dev, True)
+            model2.eval()
+            proc_latent = LatentDiffusionProcess(args, model2, dev)
+        else:
+            model2 = Diff(args, dev, shape)
+            _load(model2, './models/diff/%s_%dd/model-%d.pth' % (args.dataset, args.a_dim, args.epochs), dev, True)
+            model2.eval()
+            proc = TwoPhaseDiffusionProcess(args, model, model2, dev, shape)
+        lo, hi = shard_range(args.sampling_number, rank, world)     # shard the images, no collective
+        for n in range(lo, hi, args.batch_size):
+            bs = min(args.batch_size, hi - n)
+            if args.is_latent:
+                batch = proc.sampling(sampling_number=bs, a=proc_latent.sampling(sampling_number=bs))
+            else:
+                batch = proc.sampling(sampling_number=bs)
+            img = (torch.clip(batch.float(), min=-1, max=1) + 1) / 2
+            np.save(os.path.join(out_root, sub, 'sample-%06d.npy' % n), img.cpu().numpy())
+        print('DONE')
+    elif args.mode == 'save_latent':
+        all_a = []
+        for data in get_dataset(args, shape, dev, rank, world):
+            with torch.no_grad():
+                a, _, mu, _ = model.encoder(data[0].to(dev))
+            all_a.append((mu if args.kld_weight != 0 else a).cpu().numpy())
+        np.savez('%s_%s_latent' % (args.model, generate_exp_string(args).replace('.', '_')),
+                 all_a=np.concatenate(all_a), all_attr=np.zeros(len(all_a)))
+    else:
+        raise NotImplementedError('mode %s is analysis tooling outside the hot path (SURVEY.md 2, row 7)' % args.mode)
+
+
+if __name__ == '__main__':
+    args = parse_args()
+    if args.model == 'vae':
+        raise NotImplementedError('--model vae is a baseline outside the hot path (SURVEY.md 2, row 3)')
+    if args.mode == 'train':
+        train(args)
+    else:
+        if args.mode in ('disentangle', 'latent_quality'):
+            args.batch_size = 1
+        elif args.mode == 'interpolate':
+            args.batch_size = 2
+        evaluate(args)
+    if dist.is_initialized():
+        dist.destroy_process_group()

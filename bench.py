@@ -91,6 +91,19 @@ def cpu_baseline(margs):
                       '(fwd+bwd+clip+AdamW, dropout on) at B=8: 1 warm-up + 2 timed steps, %.1f s/step' % t}
 
 
+def pmc_traffic(prefix):
+    """Average HBM bytes per launch of the kernels named `prefix*`, from the committed rocprofv3 PMC
+    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            d = json.load(f)
+        ks = [v for k, v in d.items() if k.startswith(prefix)]
+        n = sum(v['launches'] for v in ks)
+        return round(sum(v['launches'] * v['hbm_bytes_avg'] for v in ks) / n) if n else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 class ConvTimer:
     """HIP-event timing of every launch of the dominant kernel (the implicit-GEMM conv:
     forward + data-gradient launches) on the stream it is enqueued on, with the
@@ -106,12 +119,15 @@ class ConvTimer:
         timer = self
 
         def timed(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
+            B, Cin, Hs, Ws = x.shape
+            Ho, Wo = out_hw_ if out_hw_ is not None else ops.out_hw(mode, Hs, Ws)
+            if not ops.uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
+                return timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             y = timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_)
             e1.record()
-            B, Cin, _, _ = x.shape
             M = y.shape[0] * y.shape[2] * y.shape[3]
             flops = 2.0 * M * Cout * taps * Cin
             byt = (x.numel() + y.numel() + (residual.numel() if residual is not None else 0) + w_fwd.numel()) * x.element_size()
@@ -248,11 +264,12 @@ def main():
         n, tot_ms, fl, by = tm.summary()
         ach = fl / (tot_ms * 1e-3) / 1e12
         peak = 2500.0 if a.dtype == 'bf16' else 157.3
-        out['roofline'] = {'kernel': 'conv_igemm_kernel (implicit-GEMM conv fwd + dgrad)', 'bound': 'mfma',
+        out['roofline'] = {'kernel': 'conv3x3_halo_bf16 (3x3 conv forward + data-gradient launches)', 'bound': 'mfma',
                            'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           'traffic': None, 'launches_per_step': n // nrep,
+                           'traffic': pmc_traffic('conv3x3_halo_bf16'), 'launches_per_step': n // nrep,
                            'avg_launch_us': round(tot_ms * 1e3 / n, 2),
                            'algorithmic_gflop_per_step': round(fl / nrep / 1e9, 1),
+                           'algorithmic_bytes_per_launch': round(by / n),
                            'algorithmic_gbs': round(by / (tot_ms * 1e-3) / 1e9, 1)}
     if world > 1:
         dist.barrier()

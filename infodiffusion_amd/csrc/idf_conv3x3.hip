@@ -210,7 +210,7 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   p.wshift = ws;
   // 128-pixel tiles when the problem is big enough to still fill the chip, else 64
   long M = (long)B * H * W;
-  int BM = (M * Cout >= (long)128 * 64 * 512 && H * W >= 128) ? 128 : 64;
+  int BM = ((M / 128) * idf_cdiv(Cout, 64) >= 256 && H * W >= 128) ? 128 : 64;
   int R = BM / W;
   if (R < 1) R = 1;
   if (R > H) R = H;

@@ -81,11 +81,17 @@ def out_hw(mode, H, W):
 
 
 def _halo_fits(H, W, B, Cout):
-    BM = 128 if (B * H * W * Cout >= 128 * 64 * 512 and H * W >= 128) else 64
+    BM = 128 if (B * H * W // 128 * -(-Cout // 64) >= 256 and H * W >= 128) else 64
     R = max(1, min(H, BM // W))
     while H % R:
         R -= 1
     return (R + 2) * (W + 2) * 4 <= 1280
+
+
+def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
+    """True when conv_raw routes to conv3x3_halo_bf16 (idf_conv3x3.hip)."""
+    return (dtype == torch.bfloat16 and taps == 9 and act == 0 and mode != S2 and Cin % 32 == 0
+            and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _halo_fits(Ho, Wo, B, Cout))
 
 
 def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
@@ -93,8 +99,7 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
     B, Cin, Hs, Ws = x.shape
     Ho, Wo = out_hw_ if out_hw_ is not None else out_hw(mode, Hs, Ws)
     y = empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
-    if (x.dtype == torch.bfloat16 and taps == 9 and act == 0 and mode != S2 and Cin % 32 == 0
-            and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _halo_fits(Ho, Wo, B, Cout)):
+    if uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
         call('idf_conv3x3_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout,
              {S1: 0, UP2: 2, T2: 3}[mode], _st())
         return y

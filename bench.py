@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--a_dim', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
+    ap.add_argument('--fused-opt', type=int, default=1, help='fused clip+AdamW kernel (0: clip_grad_norm_ + torch AdamW)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--sampling', action='store_true', help='also time DDIM-100 sampling (B=256)')
@@ -162,7 +163,11 @@ def main():
     torch.manual_seed(64 + rank)
     model = InfoDiff(margs, dev, (3, 64, 64))
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, capturable=bool(a.graph))
+    if a.fused_opt:
+        from infodiffusion_amd.optim import FusedClipAdamW
+        opt = FusedClipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, max_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, capturable=bool(a.graph))
     sync = GradSync(model, world) if world > 1 else None
     if sync is not None:
         sync.broadcast_parameters()
@@ -181,8 +186,9 @@ def main():
     def tail():
         if sync is not None:
             sync.all_reduce_grads()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()
+        if not a.fused_opt:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()      # FusedClipAdamW: global-norm clip (1.0) + AdamW in three launches
 
     def step_eager(i):
         xbuf.copy_(pool[i % 8])
@@ -250,7 +256,8 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: CelebA 3x64x64 a_dim=%d mmd_weight=0.1 T=1000 dropout=0.1 '
                                'train step, random-pixel batches, random-init weights' % a.a_dim,
                    'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
-                   'parallelism': 'dp%d' % world, 'hipgraph': used_graph},
+                   'parallelism': 'dp%d' % world, 'hipgraph': used_graph,
+                   'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW'},
     }
 
     if rank == 0 and not a.no_roofline:

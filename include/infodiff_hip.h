@@ -146,6 +146,12 @@ int idf_ln_silu_fwd(const float* lin, const float* cond, const float* g, const f
 int idf_ln_silu_bwd(const float* lin, const float* cond, const float* g, const float* b, const float* stats,
                     const float* dy, float* dlin, float* dcond, float* dgb, int R, int Wd, const uint64_t* seed,
                     uint32_t salt, float p_drop, void* stream);
+/* fused optimizer tail (run.py:177,199-200): global grad-norm clip + AdamW (decoupled decay) over all
+ * tensors.  table: nchunks x {float* p, float* g, float* m, float* v, long n} (device memory);
+ * partial: nchunks floats; state: 8 floats, state[0] = step count (persistent), [4] = pre-clip norm;
+ * lr: device float. */
+int idf_clip_adamw(const void* table, int nchunks, float* partial, float* state, const float* lr, float max_norm,
+                   float b1, float b2, float eps, float wd, int write_clipped_grads, void* stream);
 /* test hook: the dropout keep-mask (scaled) a call site would apply */
 int idf_dropout_mask(const uint64_t* seed, uint32_t salt, float p_drop, float* mask, long n, void* stream);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     'idf_pool2_sum': ([_p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_ln_silu_fwd': ([_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _u32, _f, _p], C.c_int),
     'idf_ln_silu_bwd': ([_p] * 9 + [_i, _i, _p, _u32, _f, _p], C.c_int),
+    'idf_clip_adamw': ([_p, _i, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p], C.c_int),
     'idf_dropout_mask': ([_p, _u32, _f, _p, _l, _p], C.c_int),
 }
 

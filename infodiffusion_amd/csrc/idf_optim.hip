@@ -1,0 +1,91 @@
+// Fused optimizer tail: global grad-norm clip (torch.nn.utils.clip_grad_norm_, run.py:199) +
+// AdamW with decoupled weight decay (torch.optim.AdamW, run.py:177,200) over ALL parameter
+// tensors in three launches, driven by a device-side chunk table (one block per chunk of
+// <= 65536 contiguous elements).  The reference path issues ~745 vector-norm calls plus a
+// dozen multi-tensor foreach launches per step; this reads g once for the norm and
+// p, g, m, v once for the update (HBM-bound, ~28 B / parameter).
+#include "idf_common.h"
+
+namespace {
+
+struct Chunk {
+  float* p;
+  float* g;
+  float* m;
+  float* v;
+  long n;
+};
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const Chunk* __restrict__ tab, float* __restrict__ partial) {
+  const Chunk c = tab[blockIdx.x];
+  float s = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(c.g);
+  const bool al = (((uintptr_t)c.g) & 15) == 0;
+  long n4 = al ? c.n / 4 : 0;
+  for (long i = threadIdx.x; i < n4; i += 256) {
+    float4 v = g4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = n4 * 4 + threadIdx.x; i < c.n; i += 256) s += c.g[i] * c.g[i];
+  __shared__ float sm[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// state: [0] step count (float), [1] clip coef, [2] 1-b1^t, [3] 1-b2^t, [4] total grad norm
+__global__ void opt_scalars_kernel(const float* __restrict__ partial, int n, float max_norm, float b1, float b2,
+                                   float* __restrict__ state) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  float t = wave_sum((float)s);
+  if (threadIdx.x == 0) {
+    float total = sqrtf(t);
+    float coef = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
+    float step = state[0] + 1.0f;
+    state[0] = step;
+    state[1] = coef;
+    state[2] = 1.0f - powf(b1, step);
+    state[3] = 1.0f - powf(b2, step);
+    state[4] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const Chunk* __restrict__ tab, const float* __restrict__ state,
+                                                    const float* __restrict__ lr_p, float b1, float b2, float eps,
+                                                    float wd, int write_g) {
+  const Chunk c = tab[blockIdx.x];
+  const float coef = state[1], bc1 = state[2], bc2s = sqrtf(state[3]), lr = *lr_p;
+  const float decay = 1.0f - lr * wd, step_size = lr / bc1;
+  for (long i = threadIdx.x; i < c.n; i += 256) {
+    float g = c.g[i] * coef;
+    float p = c.p[i] * decay;
+    float m = b1 * c.m[i] + (1.0f - b1) * g;
+    float v = b2 * c.v[i] + (1.0f - b2) * g * g;
+    float denom = sqrtf(v) / bc2s + eps;
+    c.p[i] = p - step_size * (m / denom);
+    c.m[i] = m;
+    c.v[i] = v;
+    if (write_g) c.g[i] = g;
+  }
+}
+
+}  // namespace
+
+// table: nchunks x {p*, g*, m*, v*, long n} in device memory; partial: nchunks floats; state: 8 floats
+// (state[0] = step count, persistent across calls); lr: device float (so a captured graph follows LR schedules).
+extern "C" int idf_clip_adamw(const void* table, int nchunks, float* partial, float* state, const float* lr,
+                              float max_norm, float b1, float b2, float eps, float wd, int write_clipped_grads,
+                              void* stream) {
+  if (nchunks <= 0) return IDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const Chunk* tab = reinterpret_cast<const Chunk*>(table);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, tab, partial);
+  IDF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(64), 0, st, partial, nchunks, max_norm, b1, b2, state);
+  IDF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, st, tab, state, lr, b1, b2, eps, wd, write_clipped_grads);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

@@ -60,6 +60,11 @@ class _UNetSkeleton(nn.Module):
         init.zeros_(self.tail[-1].bias)
 
     def _post(self):
+        # 3x3 master weights live in [O][kh][kw][I] memory (logical OIHW shape kept): the weight-gradient
+        # kernel writes that layout, so gradients and optimizer state are element-aligned with no copy
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         self.ctx = RunCtx()
         bind_context(self, self.ctx)
         self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)

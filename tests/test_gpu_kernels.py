@@ -224,3 +224,30 @@ def test_gn_apply():
     assert rel(a, F.silu(x * sc[:, :, None, None] + sh[:, :, None, None])) < 1e-5
     a = ops.gn_apply_raw(xd.bfloat16(), sc.to(DEV), sh.to(DEV), None, 0, 0.0, 1)
     assert rel(a, x.bfloat16().float() * sc[:, :, None, None] + sh[:, :, None, None]) < 1e-2
+
+
+def test_fused_clip_adamw_matches_torch():
+    """Fused clip + AdamW (3 launches) vs clip_grad_norm_ + torch.optim.AdamW, 4 steps, mixed layouts."""
+    from infodiffusion_amd.optim import FusedClipAdamW
+    shapes = [(64, 64, 3, 3), (128,), (256, 64), (70000,), (3, 5)]
+    ps_a = [torch.nn.Parameter(rnd(i, *s).to(DEV)) for i, s in enumerate(shapes)]
+    ps_a[0].data = ps_a[0].data.contiguous(memory_format=CL)
+    ps_b = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in ps_a]
+    dead = torch.nn.Parameter(torch.zeros(4, device=DEV))        # never gets a grad
+    oa = FusedClipAdamW(ps_a + [dead], lr=1e-2, weight_decay=1e-2, max_norm=1.0)
+    ob = torch.optim.AdamW(ps_b, lr=1e-2, weight_decay=1e-2)
+    for step in range(4):
+        for i, (pa, pb) in enumerate(zip(ps_a, ps_b)):
+            g = rnd(100 * step + i, *pa.shape).to(DEV) * (3.0 if step % 2 else 0.01)
+            if i == 0:
+                g = g.contiguous(memory_format=CL)
+            pa.grad = g.clone(memory_format=torch.preserve_format)
+            pb.grad = g.clone(memory_format=torch.preserve_format)
+        tn = torch.nn.utils.clip_grad_norm_(ps_b, 1.0)
+        ob.step()
+        oa.step()
+        assert abs(float(oa.total_norm()) - float(tn)) / float(tn) < 1e-5
+        for pa, pb in zip(ps_a, ps_b):
+            assert rel(pa, pb) < 2e-6
+            assert rel(pa.grad, pb.grad) < 2e-6      # clipped grads written back like clip_grad_norm_
+    assert dead.grad is None

@@ -78,6 +78,11 @@ int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int
 int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fwd, void* w_dgrad, int O, int I,
                          int taps, int dtype, void* stream);
 
+/* the same for every conv of a network in one launch.  table (device): nrows x
+ * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long e0, n}
+ * -- one block per row; Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow. */
+int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream);
+
 /* ---- GroupNorm(32) + AdaGN/FiLM fold (modules.py:132, 214-228, 312-318; nn.GroupNorm eps 1e-5)
  * Writes mean/rstd [B,32] and the per-(b,c) affine sc/sh [B,C]:
  *   sc = rstd*gamma*(1+s_t)*(1+s_a),  sh = ((beta-mean*rstd*gamma)*(1+s_t)+b_t)*(1+s_a)+b_a

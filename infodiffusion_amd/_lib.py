@@ -21,6 +21,7 @@ SIGNATURES = {
     'idf_conv3x3_bf16': ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_conv2d_wgrad': ([_p, _p, _p, _p, _p, _p, _u32, _f] + [_i] * 11 + [_p], C.c_int),
     'idf_pack_conv_weight': ([_p, _l, _l, _l, _p, _p, _i, _i, _i, _i, _p], C.c_int),
+    'idf_pack_conv_weights_batched': ([_p, _i, _i, _p], C.c_int),
     'idf_gn_workspace_floats': ([_i, _i, _i], C.c_int),
     'idf_gn_coef_fwd': ([_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_apply': ([_p, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),

@@ -270,6 +270,31 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, long so, long 
   }
 }
 
+// all convs of a network in ONE launch: one block per (conv, 16384-element chunk) table row
+struct PackDesc {
+  const float* src; void* wf; void* wd;
+  long so, si, st;        // master strides of (o, i, tap)
+  int O, I, taps;         // this source tensor
+  int Ototal, o0;         // rows of the (possibly concatenated) shadow and this tensor's first row
+  long e0;                // first flat element (o, tap, i order) this block handles
+  long n;                 // elements in this block
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __restrict__ tab) {
+  const PackDesc d = tab[blockIdx.x];
+  T* wf = reinterpret_cast<T*>(d.wf);
+  T* wd = reinterpret_cast<T*>(d.wd);
+  for (long k = d.e0 + threadIdx.x; k < d.e0 + d.n; k += 256) {
+    int i = (int)(k % d.I);
+    long r = k / d.I;
+    int tap = (int)(r % d.taps);
+    int o = (int)(r / d.taps);
+    float v = d.src[o * d.so + i * d.si + tap * d.st];
+    if (wf) Elem<T>::st(wf + ((size_t)(d.o0 + o) * d.taps + tap) * d.I + i, v);
+    if (wd) Elem<T>::st(wd + ((size_t)i * d.taps + (d.taps - 1 - tap)) * d.Ototal + d.o0 + o, v);
+  }
+}
+
 // dropout mask export (tests): mask[i] = keep ? scale : 0
 __global__ void drop_mask_kernel(const uint64_t* seed, uint32_t salt, uint32_t thr, float scale, float* mask, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -428,6 +453,17 @@ extern "C" int idf_pack_conv_weight(const float* src, long so, long si, long st,
   else
     hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, ST, src, so, si, st,
                        (bf16_t*)w_fwd, (bf16_t*)w_dgrad, O, I, taps);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// table: nrows x PackDesc {src*, wf*, wd*, long so, si, st, int O, I, taps, Ototal, o0, long e0, n} (device)
+extern "C" int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream) {
+  if (nrows <= 0) return IDF_OK;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(nrows), dim3(256), 0, ST, (const PackDesc*)table);
+  else
+    hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(nrows), dim3(256), 0, ST, (const PackDesc*)table);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

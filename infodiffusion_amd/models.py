@@ -11,7 +11,7 @@ from torch.nn import init
 
 from . import ops
 from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
-                      _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, timestep_embedding)
+                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, timestep_embedding)
 from .utils import compute_mmd, gaussian_mixture, swiss_roll
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
@@ -69,6 +69,7 @@ class _UNetSkeleton(nn.Module):
         bind_context(self, self.ctx)
         self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)
         self._cfg_tail = _cfg(_Shadows(self.tail[-1]), ops.S1, 9, _ACT_SILU)
+        self._shadow_set = ShadowSet(self)
 
     def _res_blocks(self):
         return [m for m in list(self.downblocks) + list(self.middleblocks) + list(self.upblocks)
@@ -77,6 +78,7 @@ class _UNetSkeleton(nn.Module):
     def _prep(self, x):
         if not x.is_cuda:
             raise RuntimeError('infodiffusion_amd runs on the GPU only: the HIP kernels have no CPU fallback')
+        self._shadow_set.refresh(self.ctx.act_dtype, torch.is_grad_enabled())
         self.ctx.seed = None
         if self.training:
             self.ctx.seed = torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64)

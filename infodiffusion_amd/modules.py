@@ -34,8 +34,9 @@ class RunCtx(types.SimpleNamespace):
 
 
 class _Shadows:
-    """Cached kernel-layout copies of conv weights, rebuilt when a master weight
-    changes (optimizer step / load_state_dict bump `_version`)."""
+    """Kernel-layout copies of conv weights in persistent buffers (fixed addresses, so captured
+    graphs stay valid), refreshed when a master weight changes (optimizer step / load_state_dict
+    bump `_version`) -- normally by the owning network's ONE batched launch (`ShadowSet.refresh`)."""
 
     def __init__(self, *convs):
         self.convs = convs
@@ -52,19 +53,112 @@ class _Shadows:
             return self.convs[0].bias
         return torch.cat([c.bias for c in self.convs], dim=0)
 
+    def current_key(self, dtype):
+        return tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
+
+    def ensure_buffers(self, dtype, need_dgrad):
+        O = sum(c.weight.shape[0] for c in self.convs)
+        _, I, kh, kw = self.convs[0].weight.shape
+        dev = self.convs[0].weight.device
+        for j, shape in enumerate(((O, kh * kw, I), (I, kh * kw, O))):
+            if j == 1 and not need_dgrad:
+                continue
+            v = self.val[j]
+            if v is None or v.dtype != dtype or v.device != dev:
+                self.val[j] = torch.empty(shape, dtype=dtype, device=dev)
+                self.key = None
+
+    def stale(self, dtype, need_dgrad):
+        return (self.key != self.current_key(dtype) or self.val[0] is None or self.val[0].dtype != dtype
+                or (need_dgrad and self.val[1] is None))
+
     def __call__(self, dtype, need_dgrad):
-        key = tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
-        if key != self.key:
-            self.key, self.val = key, [None, None]
-        if self.val[0] is None or (need_dgrad and self.val[1] is None):
-            want_d = need_dgrad and self.val[1] is None
+        if self.stale(dtype, need_dgrad):        # stand-alone use (block tests): individual pack
+            self.ensure_buffers(dtype, need_dgrad)
             with torch.no_grad():
-                wf, wd = ops.pack_weight(self.weight(), dtype, self.val[0] is None, want_d)
-            if wf is not None:
-                self.val[0] = wf
-            if wd is not None:
-                self.val[1] = wd
+                wf, wd = ops.pack_weight(self.weight(), dtype, True, self.val[1] is not None)
+                self.val[0].copy_(wf)
+                if wd is not None:
+                    self.val[1].copy_(wd)
+            self.key = self.current_key(dtype)
         return self.val
+
+
+_PACK_DT = None
+
+
+def _pack_dtype():
+    global _PACK_DT
+    if _PACK_DT is None:
+        import numpy as np
+        _PACK_DT = np.dtype([('src', '<i8'), ('wf', '<i8'), ('wd', '<i8'), ('so', '<i8'), ('si', '<i8'), ('st', '<i8'),
+                             ('O', '<i4'), ('I', '<i4'), ('taps', '<i4'), ('Ototal', '<i4'), ('o0', '<i4'),
+                             ('e0', '<i8'), ('n', '<i8')], align=True)
+        assert _PACK_DT.itemsize == 88
+    return _PACK_DT
+
+
+class ShadowSet:
+    """Every conv shadow of a network, re-packed by ONE kernel launch per optimizer step
+    (`idf_pack_conv_weights_batched`) instead of one launch per conv."""
+
+    ROW = 16384
+
+    def __init__(self, net):
+        seen, self.items = set(), []
+        for m in net.modules():
+            for v in vars(m).values():
+                sh = v.get('shadows') if isinstance(v, dict) else v
+                if isinstance(sh, _Shadows) and id(sh) not in seen:
+                    seen.add(id(sh))
+                    self.items.append(sh)
+        self.tkey = None
+        self.table = None
+        self.pinned = None
+
+    def refresh(self, dtype, need_dgrad):
+        if not any(s.stale(dtype, need_dgrad) for s in self.items):
+            return
+        import numpy as np
+        for s in self.items:
+            s.ensure_buffers(dtype, need_dgrad)
+        tkey = (dtype, tuple((c.weight.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0)
+                             for s in self.items for c in s.convs))
+        if tkey != self.tkey:
+            rows = []
+            for s in self.items:
+                Ot, o0 = sum(c.weight.shape[0] for c in s.convs), 0
+                for c in s.convs:
+                    w = c.weight
+                    O, I, kh, kw = w.shape
+                    taps = kh * kw
+                    if taps > 1 and w.stride(2) != kw * w.stride(3):
+                        raise RuntimeError('conv weight layout not packable in place')
+                    st = w.stride(3) if taps > 1 else 0
+                    n = O * I * taps
+                    for e0 in range(0, n, self.ROW):
+                        rows.append((w.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0,
+                                     w.stride(0), w.stride(1), st, O, I, taps, Ot, o0, e0, min(self.ROW, n - e0)))
+                    o0 += O
+            host = torch.from_numpy(np.array(rows, dtype=_pack_dtype()).view(np.uint8).reshape(len(rows), -1).copy())
+            dev = self.items[0].val[0].device
+            capturing = torch.cuda.is_current_stream_capturing()
+            if self.table is None or self.table.shape != host.shape:
+                if capturing:
+                    raise RuntimeError('ShadowSet: run one eager forward before graph capture')
+                self.table = torch.empty(host.shape, dtype=torch.uint8, device=dev)
+                self.pinned = torch.empty(host.shape, dtype=torch.uint8).pin_memory()
+            if capturing:
+                self.pinned.copy_(host)
+                self.table.copy_(self.pinned, non_blocking=True)
+            else:
+                self.table.copy_(host.to(dev))
+            self.tkey = tkey
+        from ._lib import call, F32, BF16
+        call('idf_pack_conv_weights_batched', self.table.data_ptr(), self.table.shape[0],
+             F32 if dtype == torch.float32 else BF16, torch.cuda.current_stream().cuda_stream)
+        for s in self.items:
+            s.key = s.current_key(dtype)
 
 
 def _cfg(shadows, mode, taps, act, p_drop=0.0, salt=0):

@@ -77,6 +77,9 @@ class FusedClipAdamW(torch.optim.Optimizer):
         call('idf_clip_adamw', ops._p(self._table), self._table.shape[0], ops._p(self._partial), ops._p(self._state),
              ops._p(self._lr), float(grp['max_norm']), float(grp['betas'][0]), float(grp['betas'][1]),
              float(grp['eps']), float(grp['weight_decay']), 1, ops._st())
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so every
+        # consumer that caches derived data (conv weight shadows) sees the update
+        torch.autograd.graph.increment_version([p for p, _, _, _ in items])
         return None
 
     def total_norm(self):

@@ -387,3 +387,63 @@ def test_vanilla_unet_and_twophase():
     fin = proc.sampling(2, xT=g['xT'].to(DEV), a=g['a'].to(DEV))
     assert calls == ['f2'] * 3
     assert rel(fin, g['final']) < 2e-4
+
+
+def _train_losses(fused, graph, steps=4, dtype='fp32'):
+    """Loss trajectory of a tiny fmnist model (eval mode: no dropout) under identical draws."""
+    from infodiffusion_amd.optim import FusedClipAdamW
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    model, args, sd = make_infodiff(cfg, DEV, dtype, 'manifest_fmnist')
+    model.eval()
+    if fused:
+        opt = FusedClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=graph)
+    g = gold('model_fmnist')
+    x = g['x'].to(DEV)
+    idx, eps, prior = g['idx'].to(DEV), g['eps'].to(DEV), g['prior'].to(DEV)
+    from infodiffusion_amd import ops
+    from infodiffusion_amd.utils import compute_mmd
+    lossbuf = torch.zeros((), device=DEV)
+
+    def step():
+        xt = ops.q_sample(x, eps, idx, model._qs_tables, model.act_dtype)
+        a, _, _, _ = model.encoder(x)
+        out = model.backbone(xt, idx, a)
+        t = ops.diff_loss(out, eps, x, model._rec_c0, model._rec_c1, 1.0 / cfg.diffusion_steps)
+        loss = t[0] + t[1] + cfg.mmd_weight * compute_mmd(prior, a)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if not fused:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        lossbuf.copy_(loss.detach())
+    losses = []
+    if not graph:
+        for _ in range(steps):
+            step()
+            losses.append(float(lossbuf))
+        return losses
+    step()
+    losses.append(float(lossbuf))          # eager warm-up step = trajectory step 0
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    for _ in range(steps - 1):
+        gr.replay()
+        losses.append(float(lossbuf))
+    return losses
+
+
+def test_fused_optimizer_and_graph_replay_track_the_reference_optimizer():
+    """The weight shadows must follow the fused optimizer's in-place updates (eagerly and inside a
+    captured hipGraph): the loss trajectory equals clip_grad_norm_ + torch AdamW's."""
+    ref = _train_losses(fused=False, graph=False)
+    eager = _train_losses(fused=True, graph=False)
+    graph = _train_losses(fused=True, graph=True)
+    assert ref[0] > ref[-1] * 1.001 or abs(ref[0] - ref[-1]) > 1e-4      # the weights do move
+    for a, b in zip(eager, ref):
+        assert abs(a - b) / abs(b) < 2e-4, (eager, ref)
+    for a, b in zip(graph, ref):
+        assert abs(a - b) / abs(b) < 2e-4, (graph, ref)

@@ -106,6 +106,19 @@ int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, c
                     float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed, uint32_t salt,
                     float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 
+/* One-launch forms for samples that fit one 1024-thread workgroup (HW*C <= 64 Ki bf16 elements: the
+ * 16x16 and 8x8 levels): statistics + fold + apply, and the whole backward.  IDF_ERR_UNSUPPORTED
+ * otherwise (use the three-launch forms above). */
+int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
+                     const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc,
+                     float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C,
+                     int dtype, void* stream);
+int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma, const float* beta,
+                     const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
+                     const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,
+                     const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype,
+                     void* stream);
+
 /* ---- dense contractions: attention bmm's (modules.py:152-159), linears
  * (modules.py:22-27, 269-276; models.py:244, 470-472, LatentUNet 147-163) and gradients.
  * C[b][m][n] = alpha * sum_k opA[m][k]*opB[n][k] (+bias[n]); ta/tb = 1 when the operand

@@ -290,6 +290,211 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// ------------------------------------------------- one-launch forms for small samples
+// When a sample's tensor fits one workgroup's registers (HW*C <= 64 Ki elements in bf16: every
+// 16x16 and 8x8 level) the whole GroupNorm-FiLM-SiLU-dropout pass -- statistics, coefficient fold
+// and apply -- is ONE launch with one block of 1024 threads per sample, x read once and held in
+// registers; likewise its backward (S1/S2 sums, k1/k0, FiLM / gamma / beta gradients, dx).
+constexpr int SNV = 8;        // 16-byte vectors per thread
+
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
+  o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, float* o) {
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+template <int VE>
+__device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], float* red, int vpp, int C, int v) {
+  // lanes of a wave that share the channel slot v sit vpp apart
+  for (int off = 32; off >= vpp; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { s[e] += __shfl_xor(s[e], off, 64); q[e] += __shfl_xor(q[e], off, 64); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < vpp || vpp > 64) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[(wave * C + v * VE + e) * 2] = s[e];
+      red[(wave * C + v * VE + e) * 2 + 1] = q[e];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T* __restrict__ out,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ film_t, const float* __restrict__ film_a,
+                                                     int ld_t, int ld_a, float eps, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, float* __restrict__ sc,
+                                                     float* __restrict__ sh, int HW, int C, int act,
+                                                     const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                       // [16 waves][C][2]
+  float* chs = red + 16 * C * 2;         // [C][2]
+  float* gst = chs + C * 2;              // [G][2] mean, rstd
+  float* cof = gst + G * 2;              // [C][2] sc, sh
+  const int vpp = C / VE, lanes = 1024 / vpp, tid = threadIdx.x, cpg = C / G;
+  const int b = blockIdx.x, v = tid % vpp, pl = tid / vpp;
+  float xv[SNV][VE], s[VE], q[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < SNV; ++k) {
+    int p = pl + k * lanes;
+    if (p < HW) {
+      Vec16<T>::load(x + ((size_t)b * HW + p) * C + v * VE, xv[k]);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { s[e] += xv[k][e]; q[e] += xv[k][e] * xv[k][e]; }
+    }
+  }
+  small_reduce<VE>(s, q, red, vpp, C, v);
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f, d = 0.f;
+    for (int w = 0; w < 16; ++w) { a += red[(w * C + tid) * 2]; d += red[(w * C + tid) * 2 + 1]; }
+    chs[tid * 2] = a; chs[tid * 2 + 1] = d;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, d = 0.0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[c * 2]; d += chs[c * 2 + 1]; }
+    double n = (double)HW * cpg, mu = a / n, var = d / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    float r = (float)(1.0 / sqrt(var + (double)eps));
+    gst[tid * 2] = (float)mu; gst[tid * 2 + 1] = r;
+    mean[b * G + tid] = (float)mu; rstd[b * G + tid] = r;
+  }
+  __syncthreads();
+  if (tid < C) {
+    int g = tid / cpg;
+    float ga = gamma ? gamma[tid] : 1.f, be = beta ? beta[tid] : 0.f;
+    float a = gst[g * 2 + 1] * ga, d = be - gst[g * 2] * a;
+    if (film_t) { float f = 1.f + film_t[(size_t)b * ld_t + tid]; a *= f; d = d * f + film_t[(size_t)b * ld_t + C + tid]; }
+    if (film_a) { float f = 1.f + film_a[(size_t)b * ld_a + tid]; a *= f; d = d * f + film_a[(size_t)b * ld_a + C + tid]; }
+    cof[tid * 2] = a; cof[tid * 2 + 1] = d;
+    sc[(size_t)b * C + tid] = a; sh[(size_t)b * C + tid] = d;
+  }
+  __syncthreads();
+  float scv[VE], shv[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { scv[e] = cof[(v * VE + e) * 2]; shv[e] = cof[(v * VE + e) * 2 + 1]; }
+#pragma unroll
+  for (int k = 0; k < SNV; ++k) {
+    int p = pl + k * lanes;
+    if (p < HW) {
+      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float u = xv[k][e] * scv[e] + shv[e];
+        if (act == 2) {
+          u = silu_f(u);
+          if (seed) u = idf_keep(*seed, salt, e0 + e, thr) ? u * dscale : 0.f;
+        }
+        xv[k][e] = u;
+      }
+      Vec16<T>::store(out + e0, xv[k]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x, T* __restrict__ dx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ film_t, const float* __restrict__ film_a,
+                                                     int ld_t, int ld_a, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ sc,
+                                                     const float* __restrict__ sh, float* __restrict__ dfilm_t,
+                                                     float* __restrict__ dfilm_a, float* __restrict__ dgb, int HW, int C,
+                                                     int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
+                                                     float dscale) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                       // [16][C][2]
+  float* pc = red + 16 * C * 2;          // [C][2]  ga*f*D1, ga*f*D2
+  float* kk = pc + C * 2;                // [G][2]  k1, k0
+  const int vpp = C / VE, lanes = 1024 / vpp, tid = threadIdx.x, cpg = C / G;
+  const int b = blockIdx.x, v = tid % vpp, pl = tid / vpp;
+  float scv[VE], shv[VE], s1[VE], s2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    scv[e] = sc[(size_t)b * C + v * VE + e]; shv[e] = sh[(size_t)b * C + v * VE + e];
+    s1[e] = s2[e] = 0.f;
+  }
+  uint4 xr[SNV];                // packed x stays in registers; dA is re-read (L2-hot) in the apply pass
+#pragma unroll
+  for (int k = 0; k < SNV; ++k) {
+    int p = pl + k * lanes;
+    if (p < HW) {
+      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      xr[k] = *reinterpret_cast<const uint4*>(x + e0);
+      float xv[VE], dav[VE], du[VE];
+      unpack16<T>(xr[k], xv);
+      Vec16<T>::load(dA + e0, dav);
+      du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { s1[e] += du[e]; s2[e] += du[e] * xv[e]; }
+    }
+  }
+  small_reduce<VE>(s1, s2, red, vpp, C, v);
+  __syncthreads();
+  if (tid < C) {
+    const int c = tid, g = c / cpg;
+    float S1 = 0.f, S2 = 0.f;
+    for (int w = 0; w < 16; ++w) { S1 += red[(w * C + c) * 2]; S2 += red[(w * C + c) * 2 + 1]; }
+    float mu = mean[b * G + g], r = rstd[b * G + g];
+    float D1 = S1, D2 = r * (S2 - mu * S1);
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float st = 0.f, bt = 0.f, sa = 0.f;
+    if (film_t) { st = film_t[(size_t)b * ld_t + c]; bt = film_t[(size_t)b * ld_t + C + c]; }
+    if (film_a) { sa = film_a[(size_t)b * ld_a + c]; }
+    float f = (1.f + st) * (1.f + sa);
+    float Gf = ga * D2 + be * D1, Ge = D1;
+    if (dfilm_t) { dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
+    if (dfilm_a) { dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
+    dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
+    dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    pc[c * 2] = ga * f * D1; pc[c * 2 + 1] = ga * f * D2;
+  }
+  __syncthreads();
+  if (tid < G) {
+    float P1 = 0.f, P2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { P1 += pc[c * 2]; P2 += pc[c * 2 + 1]; }
+    float mu = mean[b * G + tid], r = rstd[b * G + tid];
+    float invN = 1.f / ((float)HW * cpg);
+    kk[tid * 2] = -r * r * P2 * invN;
+    kk[tid * 2 + 1] = (-r * P1 + r * r * mu * P2) * invN;
+  }
+  __syncthreads();
+  float k1v[VE], k0v[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { int g = (v * VE + e) / cpg; k1v[e] = kk[g * 2]; k0v[e] = kk[g * 2 + 1]; }
+#pragma unroll
+  for (int k = 0; k < SNV; ++k) {
+    int p = pl + k * lanes;
+    if (p < HW) {
+      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      float xv[VE], dav[VE], du[VE], o[VE];
+      unpack16<T>(xr[k], xv);
+      Vec16<T>::load(dA + e0, dav);
+      du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
+      Vec16<T>::store(dx + e0, o);
+    }
+  }
+}
+
+bool small_ok(int HW, int C, int VE) {
+  int vpp = C / VE;
+  return C % G == 0 && C % VE == 0 && vpp >= 1 && vpp <= 64 && (vpp & (vpp - 1)) == 0 && C <= 1024 &&
+         (long)HW * vpp <= 1024L * SNV;
+}
+
 int pick_chunk(int B, int HW) {
   // aim for >= ~1024 blocks, chunks of at least 64 pixels
   int nchunk = idf_cdiv(1024, B);
@@ -397,6 +602,58 @@ extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const flo
   else
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, sc, sh, HW, C,
                        achunk, act, sd, salt, thr, dscale);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// One-launch GroupNorm + FiLM fold + apply for small samples (statistics, sc/sh, a = act(x*sc+sh)).
+// IDF_ERR_UNSUPPORTED when a sample does not fit one workgroup: use idf_gn_coef_fwd + idf_gn_apply.
+extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
+                                const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd,
+                                float* sc, float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act,
+                                int B, int HW, int C, int dtype, void* stream) {
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (!small_ok(HW, C, VE)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_fwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "gn_fused_fwd: act must be 1 or 2");
+  if (B == 0) return IDF_OK;
+  uint32_t thr = idf_drop_thresh(p_drop);
+  float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+  const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  size_t lds = ((size_t)16 * C * 2 + C * 2 + G * 2 + C * 2) * sizeof(float);
+  ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B), dim3(1024), lds, st, (const float*)x, (float*)out, gamma, beta, film_t,
+                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, act, sd, salt, thr, dscale);
+  else
+    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B), dim3(1024), lds, st, (const bf16_t*)x, (bf16_t*)out, gamma, beta,
+                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, act, sd, salt, thr, dscale);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma, const float* beta,
+                                const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
+                                const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
+                                float* dgb, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW,
+                                int C, int dtype, void* stream) {
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (!small_ok(HW, C, VE)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_bwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  if (B == 0) return IDF_OK;
+  uint32_t thr = idf_drop_thresh(p_drop);
+  float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+  const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  size_t lds = ((size_t)16 * C * 2 + C * 2 + G * 2) * sizeof(float);
+  ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B), dim3(1024), lds, st, (const float*)dA, (const float*)x, (float*)dx,
+                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW, C, act, sd,
+                       salt, thr, dscale);
+  else
+    hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B), dim3(1024), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
+                       (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW,
+                       C, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

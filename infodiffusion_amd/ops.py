@@ -180,6 +180,43 @@ def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, 
 
 
 # ------------------------------------------------------------- fused conv op
+def gn_small_ok(x):
+    """A sample fits one 1024-thread workgroup: the one-launch GroupNorm kernels apply."""
+    B, C, H, W = x.shape
+    VE = 4 if x.dtype == torch.float32 else 8
+    vpp = C // VE
+    return (C % 32 == 0 and C % VE == 0 and 1 <= vpp <= 64 and not (vpp & (vpp - 1)) and C <= 1024
+            and H * W * vpp <= 8192)
+
+
+def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act):
+    """statistics + FiLM fold + apply in one launch -> (a, mean, rstd, sc, sh)."""
+    B, C, H, W = x.shape
+    dev = x.device
+    mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    sc = torch.empty((B, C), dtype=torch.float32, device=dev)
+    sh = torch.empty((B, C), dtype=torch.float32, device=dev)
+    a = torch.empty_like(x, memory_format=CL)
+    call('idf_gn_fused_fwd', _p(x), _p(a), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
+         GN_EPS, _p(mean), _p(rstd), _p(sc), _p(sh), _p(seed), salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
+    return a, mean, rstd, sc, sh
+
+
+def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act):
+    B, C, H, W = x.shape
+    dev = x.device
+    dx = torch.empty_like(x, memory_format=CL)
+    dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
+    dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
+         _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(seed), salt, float(p_drop),
+         act, B, H * W, C, _dt(x), _st())
+    dgam = colsum_raw(dgb)
+    return dx, dgam[:C], dgam[C:], dft, dfa
+
+
 def gn_apply_raw(x, sc, sh, seed, salt, p_drop, act):
     """a = act(x*sc + sh) (+ dropout): one read + one write."""
     B, C, H, W = x.shape
@@ -253,7 +290,9 @@ class _FusedConv(torch.autograd.Function):
         p_drop = cfg['p_drop'] if seed is not None else 0.0
         mean = rstd = sc = sh = None
         a = x
-        if act:
+        if act and gn_small_ok(x):
+            a, mean, rstd, sc, sh = gn_fused_fwd_raw(x, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act)
+        elif act:
             mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
             a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
         w_fwd = cfg['shadows'](x.dtype, train)[0]
@@ -283,7 +322,10 @@ class _FusedConv(torch.autograd.Function):
         if need[0] or (act and (need[3] or need[5] or need[6])):
             w_dgrad = cfg['shadows'](x.dtype, True)[1]
             dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
-            if act:
+            if act and gn_small_ok(x):
+                dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
+                                                          seed, salt, p_drop, act)
+            elif act:
                 dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, None, gn_w, gn_b, film_t, film_a, mean, rstd,
                                                          sc, sh, seed, salt, p_drop, act)
             else:

@@ -251,3 +251,35 @@ def test_fused_clip_adamw_matches_torch():
             assert rel(pa, pb) < 2e-6
             assert rel(pa.grad, pb.grad) < 2e-6      # clipped grads written back like clip_grad_norm_
     assert dead.grad is None
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,H', [(128, 16), (256, 16), (128, 8), (256, 8), (32, 8), (64, 4)])
+def test_gn_one_launch_small(C, H, dtype):
+    """One-launch GroupNorm(+FiLM+SiLU) forward and backward vs the three-launch path and PyTorch."""
+    B = 3
+    x = (rnd(1, B, C, H, H) * 1.5 + 0.3).to(dtype).float()
+    gam, bet = 1 + 0.1 * rnd(2, C), 0.1 * rnd(3, C)
+    ft, fa = 0.3 * rnd(4, B, 2 * C), 0.3 * rnd(5, B, 2 * C)
+    xr, gr, br, ftr, far = [t.clone().requires_grad_(True) for t in (x, gam, bet, ft, fa)]
+    h = F.group_norm(xr, 32, gr, br, 1e-5)
+    st, bt = torch.chunk(ftr[:, :, None, None], 2, dim=1)
+    sa, ba = torch.chunk(far[:, :, None, None], 2, dim=1)
+    ref = F.silu((h * (1 + st) + bt) * (1 + sa) + ba)
+    gy = rnd(7, *ref.shape).to(dtype).float()
+    ref.backward(gy)
+    g = lambda t: t.to(DEV).contiguous()
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=CL)
+    if not ops.gn_small_ok(xd):
+        pytest.skip('sample does not fit one workgroup in this dtype')
+    a, mean, rstd, sc, sh = ops.gn_fused_fwd_raw(xd, g(gam), g(bet), g(ft), g(fa), None, 0, 0.0, 2)
+    tol = TOL[dtype]
+    assert rel(a, ref) < tol
+    m2, r2, sc2, sh2 = ops.gn_coef_fwd_raw(xd, g(gam), g(bet), g(ft), g(fa))
+    assert rel(mean, m2) < 1e-5 and rel(rstd, r2) < 1e-5 and rel(sc, sc2) < 1e-5 and rel(sh, sh2) < 1e-5
+    dA = gy.to(DEV).to(dtype).contiguous(memory_format=CL)
+    dx, dgam, dbet, dft, dfa = ops.gn_fused_bwd_raw(dA, xd, g(gam), g(bet), g(ft), g(fa), mean, rstd, sc, sh, None, 0,
+                                                   0.0, 2)
+    btol = 3e-4 if dtype == torch.float32 else 4e-2
+    for got, want in ((dx, xr.grad), (dgam, gr.grad), (dbet, br.grad), (dft, ftr.grad), (dfa, far.grad)):
+        assert rel(got, want) < btol

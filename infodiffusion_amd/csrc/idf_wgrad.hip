@@ -17,6 +17,7 @@
 // LDS pixel pitch is 80 bf16 (160 B): 8 consecutive pixels x 32 B then tile all
 // 64 banks, so the transposed reads are conflict-free.
 #include "idf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -245,7 +246,16 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
   p.n_tiles = idf_cdiv(Cout, 64);
   const int kh = taps == 9 ? 3 : 1;
   int gx = p.c_tiles * p.n_tiles * kh;
-  int split = idf_cdiv(IDF_WGRAD_BLOCKS, gx);
+  // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
+  // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
+  // per atomic byte (profiles/r01_wgrad_grid_sweep.txt)
+  static const int forced = getenv("IDF_WGRAD_BLOCKS") ? atoi(getenv("IDF_WGRAD_BLOCKS")) : 0;
+  const long M = (long)B * H * W, cc = (long)Cin * Cout;
+  int target_blocks = 512;
+  if (cc <= 64 * 64 || (M <= 32768 && cc <= 128 * 128)) target_blocks = 256;
+  else if (M >= 131072 && cc >= 128 * 128) target_blocks = 768;
+  if (forced > 0) target_blocks = forced;
+  int split = idf_cdiv(target_blocks, gx);
   if (split > p.tiles) split = p.tiles;
   p.tiles_per_blk = idf_cdiv(p.tiles, split);
   split = idf_cdiv(p.tiles, p.tiles_per_blk);

@@ -195,8 +195,14 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    force_sync = os.environ.get('IDF_FORCE_SYNC') == '1'      # exercise the DP code path on one GPU
+    if world > 1 or force_sync:
+        if force_sync and world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     from infodiffusion_amd.models import InfoDiff
     from infodiffusion_amd.dist import GradSync
     margs = make_args(a)
@@ -208,7 +214,7 @@ def main():
         opt = FusedClipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, max_norm=1.0)
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, capturable=bool(a.graph))
-    sync = GradSync(model, world) if world > 1 else None
+    sync = GradSync(model, world, force=force_sync) if (world > 1 or force_sync) else None
     if sync is not None:
         sync.broadcast_parameters()
 
@@ -342,7 +348,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(margs)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

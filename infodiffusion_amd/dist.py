@@ -4,24 +4,40 @@ backend "nccl"); gloo on CPU for tests.  The reference has no distributed code
 one sum-all-reduce of the gradients per step, averaged over ranks, then the
 *global* grad-norm clip and an identical AdamW step on every rank.
 
-Gradients are packed into a few large flat buckets (xGMI is point-to-point:
-fewer, larger collectives) in reverse registration order -- the order backward
-produces them -- and each bucket's all-reduce is issued on a side stream as soon
-as it is packed, so packing bucket k+1 overlaps the wire time of bucket k.
-Parameters that never receive a gradient (the dead `crossattn.*` weights,
-`encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are skipped.
+Gradients are packed into a few large persistent flat buckets (xGMI is
+point-to-point: fewer, larger collectives) in reverse registration order -- the
+order backward produces them.  Packing / unpacking a bucket is ONE multi-tensor
+copy each (bucket views carry the gradients' own strides, so channels-last conv
+gradients move as dense memory), and each bucket's all-reduce is issued on a side
+stream as soon as it is packed, so packing bucket k+1 overlaps the wire time of
+bucket k.  Parameters that never receive a gradient (the dead `crossattn.*`
+weights, `encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are
+skipped.
 """
 import torch
 import torch.distributed as dist
 
 
+def _dense(t):
+    """Non-overlapping and dense: some permutation of the dims is contiguous."""
+    expect = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz != 1), key=lambda x: x[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 class GradSync:
-    def __init__(self, model, world_size=None, bucket_bytes=32 << 20):
+    def __init__(self, model, world_size=None, bucket_bytes=32 << 20, force=False):
+        self.force = force      # run the exchange even at world size 1 (single-GPU validation of the DP path)
         self.world = world_size if world_size is not None else dist.get_world_size()
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.model = model
         self.bucket_bytes = bucket_bytes
         self._side = None
+        self._plan_key = None
+        self._plan = None       # [(flat buffer, [views shaped/strided like the grads], [grad indices])]
 
     @torch.no_grad()
     def broadcast_parameters(self, src=0):
@@ -48,37 +64,53 @@ class GradSync:
             out.append(cur)
         return out
 
+    def _make_plan(self, grads):
+        key = tuple((tuple(g.shape), tuple(g.stride()), g.dtype) for g in grads)
+        if key == self._plan_key:
+            return self._plan
+        plan = []
+        for group in self._buckets(grads):
+            n = sum(g.numel() for g in group)
+            flat = torch.empty((n,), dtype=group[0].dtype, device=group[0].device)
+            views, off = [], 0
+            for g in group:
+                seg = flat[off:off + g.numel()]
+                views.append(seg.as_strided(g.shape, g.stride()) if _dense(g) else seg.view(g.shape))
+                off += g.numel()
+            plan.append((flat, views, len(group)))
+        self._plan_key, self._plan = key, plan
+        return plan
+
     @torch.no_grad()
     def all_reduce_grads(self):
         """Average the gradients over all ranks (in place)."""
         grads = [p.grad for p in reversed(self.params) if p.grad is not None]
-        if not grads or self.world == 1:
+        if not grads or (self.world == 1 and not self.force):
             return
+        plan = self._make_plan(grads)
         use_side = grads[0].is_cuda
         cur = torch.cuda.current_stream() if use_side else None
         if use_side and self._side is None:
             self._side = torch.cuda.Stream()
-        work = []
-        for group in self._buckets(grads):
-            flat = torch.cat([g.reshape(-1) for g in group])
+        i = 0
+        for flat, views, n in plan:
+            group = grads[i:i + n]
+            i += n
+            torch._foreach_copy_(views, group)             # pack: one multi-tensor launch
             if use_side:
                 self._side.wait_stream(cur)
                 with torch.cuda.stream(self._side):
                     dist.all_reduce(flat)
                     flat.div_(self.world)
-                flat.record_stream(self._side)
             else:
                 dist.all_reduce(flat)
                 flat.div_(self.world)
-            work.append((flat, group))
         if use_side:
             cur.wait_stream(self._side)
-        for flat, group in work:
-            off = 0
-            for g in group:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+        i = 0
+        for flat, views, n in plan:
+            torch._foreach_copy_(grads[i:i + n], views)    # unpack
+            i += n
 
 
 def shard_range(total, rank, world):

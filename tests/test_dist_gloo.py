@@ -22,6 +22,8 @@ def _worker(rank, world, port, q):
     from infodiffusion_amd.dist import GradSync, shard_range
     torch.manual_seed(rank)          # different init per rank on purpose
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 4))
+    # one parameter with permuted (channels-last-like) strides, as the conv weight gradients have
+    net[0].weight.data = net[0].weight.data.t().contiguous().t()
     dead = torch.nn.Linear(3, 3)     # never used: grads stay None and must be skipped
     model = torch.nn.ModuleDict({'net': net, 'dead': dead})
     sync = GradSync(model, world, bucket_bytes=256)   # tiny buckets -> several collectives
@@ -29,6 +31,7 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)
     x = torch.randn(5, 8)
     net(x).square().mean().backward()
+    net[0].weight.grad = net[0].weight.grad.t().contiguous().t()      # strided like its parameter
     local = [p.grad.clone() for p in net.parameters()]
     sync.all_reduce_grads()
     # plain lists: tensors in an mp.Queue travel by fd and die with the worker

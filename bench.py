@@ -257,7 +257,8 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL's watchdog thread keeps querying events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 fwd_bwd()
                 if sync is None:
                     tail()

@@ -68,3 +68,38 @@ def test_state_dict_matches_reference_manifest():
     assert [k for k, _ in man] == list(sd.keys())
     assert all(tuple(s) == tuple(sd[k].shape) for k, s in man)
     assert len(sd) == 969
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/models.py'), reason='reference tree only exists in the build container')
+def test_checkpoint_interchange_with_reference():
+    """state_dicts load strictly in both directions and seeded init is bit-identical."""
+    import sys
+    import types
+    import torch
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, '/root/reference')
+    try:
+        import models as R
+    finally:
+        sys.path.remove('/root/reference')
+    from infodiffusion_amd.models import InfoDiff
+    args = types.SimpleNamespace(beta1=1e-5, betaT=1e-2, diffusion_steps=100, input_size=32, is_bottleneck=False,
+                                 unets_channels=32, encoder_channels=32, a_dim=16, mmd_weight=0.1, kld_weight=0.0)
+    torch.manual_seed(3)
+    ours = InfoDiff(args, 'cpu', (1, 32, 32))
+    torch.manual_seed(3)
+    ref = R.InfoDiff(args, 'cpu', (1, 32, 32))
+    so, sr = ours.state_dict(), ref.state_dict()
+    assert list(so) == list(sr)
+    assert all(torch.equal(so[k], sr[k]) for k in so)          # same seed -> same weights
+    import io
+    buf = io.BytesIO()
+    torch.save(so, buf)                                       # run.py:157 format
+    buf.seek(0)
+    ref.load_state_dict(torch.load(buf), strict=True)
+    for p in ref.parameters():
+        p.data.add_(1.0)
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    assert all(torch.equal(ours.state_dict()[k], ref.state_dict()[k]) for k in so)
+    # conv masters keep their channels-last memory after loading
+    assert ours.backbone.downblocks[0].block1[2].weight.stride()[1] == 1

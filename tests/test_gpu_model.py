@@ -447,3 +447,35 @@ def test_fused_optimizer_and_graph_replay_track_the_reference_optimizer():
         assert abs(a - b) / abs(b) < 2e-4, (eager, ref)
     for a, b in zip(graph, ref):
         assert abs(a - b) / abs(b) < 2e-4, (graph, ref)
+
+
+@pytest.mark.parametrize('ds,a_dim,B', [('celeba', 256, 2), ('cifar10', 32, 3)])
+def test_other_configs_vs_oracle(ds, a_dim, B):
+    """BASELINE configs[3] (CelebA a_dim=256 train step) and configs[4] (CIFAR-10 32x32 shape):
+    loss + gradient norm of a train step and a sampling-path epsilon vs the CPU oracle."""
+    cfg = O.dataset_cfg(ds, a_dim=a_dim, mmd_weight=0.1)
+    model, args, sd = make_infodiff(cfg, DEV, 'fp32')
+    model.eval()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(11)
+    x = torch.rand(B, *cfg.shape, generator=g) * 2 - 1
+    idx = torch.randint(0, 1000, (B,), generator=g)
+    eps = torch.randn(B, *cfg.shape, generator=g)
+    prior = torch.randn(B, a_dim, generator=g)
+    fix = {'x': x, 'idx': idx, 'eps': eps, 'reparam': torch.zeros(B, a_dim), 'prior': prior}
+    loss = _replay(model, cfg, fix, 0)
+    loss.backward()
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith('timembedding.0.weight'))
+           for k, v in sd.items()}
+    sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+    lo, terms = O.infodiff_loss(sdr, cfg, x, idx, eps, sched, prior=prior, reparam_noise=torch.zeros(B, a_dim))
+    lo.backward()
+    assert rel(loss, lo) < 1e-4
+    gn_ref = sum(float(v.grad.double().pow(2).sum()) for v in sdr.values() if v.grad is not None) ** 0.5
+    gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters() if p.grad is not None) ** 0.5
+    assert abs(gn - gn_ref) / gn_ref < 1e-3
+    a_in = torch.randn(B, a_dim, generator=g)
+    with torch.no_grad():
+        e = model(eps.to(DEV), 5, a_in.to(DEV))
+        ref = O.infodiff_eps(sd, cfg, eps, 5, a_in)
+    assert rel(e, ref) < 1e-4

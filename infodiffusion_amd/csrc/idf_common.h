@@ -98,19 +98,25 @@ __device__ __forceinline__ float dsilu_f(float u) {
   return s * (1.0f + u * (1.0f - s));
 }
 
-// Counter-based dropout: keep decision for element `idx` of call site `salt`
-// under step seed `seed`.  16 random bits per element (two elements per hash).
+// Counter-based dropout: keep decision for element `idx` of call site `salt` under step seed
+// `seed`.  One well-mixed 32-bit hash per aligned group of 8 elements (= one 16-byte bf16 vector),
+// from which the 8 per-element 16-bit draws are derived by one multiply-add each -- the mask costs
+// ~4 VALU ops per element instead of ~9, which is what keeps the GroupNorm passes HBM-bound.
 __device__ __forceinline__ uint32_t idf_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+__device__ __forceinline__ uint32_t idf_vec_hash(uint64_t seed, uint32_t salt, uint64_t vec) {
+  uint32_t h = idf_hash32((uint32_t)vec ^ (uint32_t)seed);
+  return idf_hash32(h + salt * 0x9E3779B9u + (uint32_t)(seed >> 32) + (uint32_t)(vec >> 32) * 0x85ebca6bU);
+}
+__device__ __forceinline__ bool idf_keep_h(uint32_t h, int lane, uint32_t thresh16) {
+  constexpr uint32_t A[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu,
+                             0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+  return ((h * A[lane & 7] + (A[lane & 7] >> 5)) >> 16) >= thresh16;
+}
 __device__ __forceinline__ bool idf_keep(uint64_t seed, uint32_t salt, uint64_t idx, uint32_t thresh16) {
-  uint32_t pair = (uint32_t)(idx >> 1);
-  uint32_t hi = (uint32_t)(idx >> 33);
-  uint32_t h = idf_hash32(pair ^ (uint32_t)seed);
-  h = idf_hash32(h + salt * 0x9E3779B9u + (uint32_t)(seed >> 32) + hi * 0x85ebca6bU);
-  uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
-  return r >= thresh16;
+  return idf_keep_h(idf_vec_hash(seed, salt, idx >> 3), (int)(idx & 7), thresh16);
 }
 __host__ __device__ __forceinline__ uint32_t idf_drop_thresh(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);

@@ -107,13 +107,15 @@ __device__ __forceinline__ void du_vec(const float* dav, const float* xv, const 
                                        int act, const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale,
                                        size_t e0, float* du) {
   constexpr int VE = Elem<T>::VE;
+  const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;   // one hash per vector
+  const int l0 = (int)(e0 & 7);
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
     float d = dav[e];
     if (act == 2) {
       float u = xv[e] * scv[e] + shv[e];
       d *= dsilu_f(u);
-      if (seed) d = idf_keep(*seed, salt, e0 + e, thr) ? d * dscale : 0.f;
+      if (seed) d = idf_keep_h(h, l0 + e, thr) ? d * dscale : 0.f;
     }
     du[e] = d;
   }
@@ -277,12 +279,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     size_t e0 = ((size_t)b * HW + p) * C + v * VE;
     float xv[VE];
     Vec16<T>::load(x + e0, xv);
+    const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
+    const int l0 = (int)(e0 & 7);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       float u = xv[e] * scv[e] + shv[e];
       if (act == 2) {
         u = silu_f(u);
-        if (seed) u = idf_keep(*seed, salt, e0 + e, thr) ? u * dscale : 0.f;
+        if (seed) u = idf_keep_h(h, l0 + e, thr) ? u * dscale : 0.f;
       }
       xv[e] = u;
     }
@@ -388,12 +392,14 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
     int p = pl + k * lanes;
     if (p < HW) {
       size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
+      const int l0 = (int)(e0 & 7);
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         float u = xv[k][e] * scv[e] + shv[e];
         if (act == 2) {
           u = silu_f(u);
-          if (seed) u = idf_keep(*seed, salt, e0 + e, thr) ? u * dscale : 0.f;
+          if (seed) u = idf_keep_h(h, l0 + e, thr) ? u * dscale : 0.f;
         }
         xv[k][e] = u;
       }

@@ -76,49 +76,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
   uint4 hreg[HV], wreg[WV];
   const int nchunks = p.Cin / CK;
 
+  // chunk-invariant staging plan: global element offsets (-1 = zero fill) and LDS byte offsets
+  // (-1 = no slot), computed once so the chunk loop is loads + stores only
+  long hoff[HV], woff[WV];
+  int hlds[HV], wlds[WV];
+#pragma unroll
+  for (int k = 0; k < HV; ++k) {
+    int idx = tid + k * 256;
+    hoff[k] = -1; hlds[k] = -1;
+    if (idx < npix_h * 4) {
+      int pix = idx >> 2, ch = idx & 3;
+      int hy = pix / WH, hx = pix - hy * WH;
+      int iy = oy0 + hy - 1, ix = hx - 1;
+      bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+      if (MODE == 3) ok = ok && !((iy | ix) & 1);
+      if (MODE != 0) { iy >>= 1; ix >>= 1; }
+      if (ok) hoff[k] = ((long)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
+      hlds[k] = pix * 64 + swz(pix, ch) * 16;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WV; ++k) {
+    int idx = tid + k * 256;            // over [BN][9][4]
+    int ch = idx & 3, r = idx >> 2;
+    int tap = r % 9, n = r / 9;
+    woff[k] = -1; wlds[k] = -1;
+    if (idx < BN * 36) {
+      if (n0 + n < p.Cout) woff[k] = ((long)(n0 + n) * 9 + tap) * p.Cin + ch * 8;
+      wlds[k] = (tap * BN + n) * 64 + swz(n, ch) * 16;
+    }
+  }
+
   auto load_chunk = [&](int ck) {
     const int c0 = ck * CK;
 #pragma unroll
-    for (int k = 0; k < HV; ++k) {
-      int idx = tid + k * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < npix_h * 4) {
-        int pix = idx >> 2, ch = idx & 3;
-        int hy = pix / WH, hx = pix - hy * WH;
-        int iy = oy0 + hy - 1, ix = hx - 1;
-        bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
-        if (MODE == 3) ok = ok && !((iy | ix) & 1);
-        if (MODE != 0) { iy >>= 1; ix >>= 1; }
-        if (ok) v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + ch * 8);
-      }
-      hreg[k] = v;
-    }
+    for (int k = 0; k < HV; ++k)
+      hreg[k] = hoff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.x + hoff[k] + c0) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < WV; ++k) {
-      int idx = tid + k * 256;            // over [BN][9][4]
-      int ch = idx & 3, r = idx >> 2;
-      int tap = r % 9, n = r / 9;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < BN * 36 && n0 + n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)(n0 + n) * 9 + tap) * p.Cin + c0 + ch * 8);
-      wreg[k] = v;
-    }
+    for (int k = 0; k < WV; ++k)
+      wreg[k] = woff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.w + woff[k] + c0) : make_uint4(0, 0, 0, 0);
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int k = 0; k < HV; ++k) {
-      int idx = tid + k * 256;
-      if (idx < npix_h * 4) {
-        int pix = idx >> 2, ch = idx & 3;
-        *reinterpret_cast<uint4*>(Xs + pix * 64 + swz(pix, ch) * 16) = hreg[k];
-      }
-    }
+    for (int k = 0; k < HV; ++k)
+      if (hlds[k] >= 0) *reinterpret_cast<uint4*>(Xs + hlds[k]) = hreg[k];
 #pragma unroll
-    for (int k = 0; k < WV; ++k) {
-      int idx = tid + k * 256;
-      int ch = idx & 3, r = idx >> 2;
-      int tap = r % 9, n = r / 9;
-      if (idx < BN * 36) *reinterpret_cast<uint4*>(Ws + (tap * BN + n) * 64 + swz(n, ch) * 16) = wreg[k];
-    }
+    for (int k = 0; k < WV; ++k)
+      if (wlds[k] >= 0) *reinterpret_cast<uint4*>(Ws + wlds[k]) = wreg[k];
   };
 
   load_chunk(0);
@@ -146,8 +150,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
     __syncthreads();
   }
 
-  // epilogue: lane holds couts n..n+3 of pixel pl
-  const bool vec_ok = (p.Cout & 3) == 0;
+  // epilogue.  A lane holds couts n..n+3 of one pixel, i.e. 8-byte pieces scattered over 16 pixel
+  // rows per store instruction.  When the cout tile is vector-aligned the fp32 tile goes through LDS
+  // (the staging buffers are free now) and is written back as whole 16-byte chunks, consecutive lanes
+  // covering one pixel's contiguous couts: full-line HBM writes, coalesced bias/residual reads.
+  const int ncols = min(BN, p.Cout - n0);          // valid couts of this tile
+  if ((p.Cout & 7) == 0) {
+    constexpr int PF = BN + 4;                       // fp32 row pitch (floats)
+    float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]; fits: BM*(BN+4)*4 <= (halo + weights) bytes
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int pl = wm0 + i * 16 + fr;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        int nl = wn0 + a * 16 + fq * 4;
+        *reinterpret_cast<float4*>(Os + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                      // 16-byte output chunks per pixel row
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
+      if (pl >= KT || cc >= ncols) continue;
+      float o[8];
+      float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc);
+      float4 v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
+      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+      size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
+      if (p.bias) {
+        float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
+        float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
+        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+      }
+      if (p.res) {
+        float r[8];
+        Vec16<bf16_t>::load(p.res + e, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] += r[k];
+      }
+      Vec16<bf16_t>::store(p.y + e, o);
+    }
+    return;
+  }
+  // ragged cout counts (epsilon / latent heads): direct per-lane stores
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int pl = wm0 + i * 16 + fr;
@@ -157,29 +202,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
     for (int a = 0; a < TN; ++a) {
       int n = n0 + wn0 + a * 16 + fq * 4;
       if (n >= p.Cout) continue;
-      float o[4] = {acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]};
       size_t e = m * p.Cout + n;
-      if (vec_ok) {
-        if (p.bias) {
-          float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-        }
-        if (p.res) {
-          uint2 rv = *reinterpret_cast<const uint2*>(p.res + e);
-          o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
-          o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-        uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-        uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-        *reinterpret_cast<uint2*>(p.y + e) = make_uint2(lo, hi);
-      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.Cout) {
-            float v = o[r] + (p.bias ? p.bias[n + r] : 0.f) + (p.res ? bf16_to_f32(p.res[e + r]) : 0.f);
-            p.y[e + r] = f32_to_bf16(v);
-          }
-      }
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.Cout) {
+          float v = acc[a][i][r] + (p.bias ? p.bias[n + r] : 0.f) + (p.res ? bf16_to_f32(p.res[e + r]) : 0.f);
+          p.y[e + r] = f32_to_bf16(v);
+        }
     }
   }
 }
@@ -187,6 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
 template <int MODE, int TM, int BN>
 void launch(const C3P& p, hipStream_t st) {
   size_t lds = ((size_t)(p.R + 2) * (p.W + 2) + 9 * BN) * 64;
+  size_t olds = (size_t)TM * 32 * (BN + 4) * sizeof(float);      // epilogue tile
+  if (olds > lds) lds = olds;
   hipLaunchKernelGGL((conv3x3_halo_bf16<MODE, TM, BN>), dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(256), lds, st, p);
 }
 

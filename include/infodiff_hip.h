@@ -79,8 +79,9 @@ int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fw
                          int taps, int dtype, void* stream);
 
 /* the same for every conv of a network in one launch.  table (device): nrows x
- * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long e0, n}
- * -- one block per row; Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow. */
+ * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long tile, pad}
+ * -- one block per row = one (tap, 32-cout, 64-cin) tile, tile = tap | cout_tile << 8 | cin_tile << 32;
+ * Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow. */
 int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream);
 
 /* ---- GroupNorm(32) + AdaGN/FiLM fold (modules.py:132, 214-228, 312-318; nn.GroupNorm eps 1e-5)

@@ -270,28 +270,43 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, long so, long 
   }
 }
 
-// all convs of a network in ONE launch: one block per (conv, 16384-element chunk) table row
+// all convs of a network in ONE launch: one block per table row = (conv, tap, 32-cout x 64-cin tile).
+// The tile is read along cin (the master's contiguous axis for channels-last weights), written to the
+// forward shadow in the same order, and transposed through LDS so the data-gradient shadow
+// [cin][tap flipped][cout] is written along ITS contiguous axis too.
 struct PackDesc {
   const float* src; void* wf; void* wd;
   long so, si, st;        // master strides of (o, i, tap)
   int O, I, taps;         // this source tensor
   int Ototal, o0;         // rows of the (possibly concatenated) shadow and this tensor's first row
-  long e0;                // first flat element (o, tap, i order) this block handles
-  long n;                 // elements in this block
+  long e0;                // packed tile origin: tap | ot << 8 | it << 32
+  long n;                 // unused
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __restrict__ tab) {
   const PackDesc d = tab[blockIdx.x];
+  __shared__ float tile[32][65];
   T* wf = reinterpret_cast<T*>(d.wf);
   T* wd = reinterpret_cast<T*>(d.wd);
-  for (long k = d.e0 + threadIdx.x; k < d.e0 + d.n; k += 256) {
-    int i = (int)(k % d.I);
-    long r = k / d.I;
-    int tap = (int)(r % d.taps);
-    int o = (int)(r / d.taps);
-    float v = d.src[o * d.so + i * d.si + tap * d.st];
-    if (wf) Elem<T>::st(wf + ((size_t)(d.o0 + o) * d.taps + tap) * d.I + i, v);
-    if (wd) Elem<T>::st(wd + ((size_t)i * d.taps + (d.taps - 1 - tap)) * d.Ototal + d.o0 + o, v);
+  const int tap = (int)(d.e0 & 0xff), ob = (int)((d.e0 >> 8) & 0xffffff) * 32, ib = (int)(d.e0 >> 32) * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int o = ob + (tid >> 6) + k * 4, i = ib + (tid & 63);
+    float v = 0.f;
+    if (o < d.O && i < d.I) {
+      v = d.src[o * d.so + i * d.si + tap * d.st];
+      if (wf) Elem<T>::st(wf + ((size_t)(d.o0 + o) * d.taps + tap) * d.I + i, v);
+    }
+    tile[(tid >> 6) + k * 4][tid & 63] = v;
+  }
+  if (!wd) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int i = ib + (tid >> 5) + k * 8, o = ob + (tid & 31);
+    if (o < d.O && i < d.I)
+      Elem<T>::st(wd + ((size_t)i * d.taps + (d.taps - 1 - tap)) * d.Ototal + d.o0 + o, tile[tid & 31][(tid >> 5) + k * 8]);
   }
 }
 
@@ -457,7 +472,8 @@ extern "C" int idf_pack_conv_weight(const float* src, long so, long si, long st,
   return IDF_OK;
 }
 
-// table: nrows x PackDesc {src*, wf*, wd*, long so, si, st, int O, I, taps, Ototal, o0, long e0, n} (device)
+// table: nrows x PackDesc {src*, wf*, wd*, long so, si, st, int O, I, taps, Ototal, o0, long tile, -} (device);
+// tile = tap | (cout_tile32 << 8) | (cin_tile64 << 32)
 extern "C" int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream) {
   if (nrows <= 0) return IDF_OK;
   if (dtype == IDF_F32)

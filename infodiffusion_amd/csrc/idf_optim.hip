@@ -58,7 +58,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(const Chunk* __restrict__ ta
   const Chunk c = tab[blockIdx.x];
   const float coef = state[1], bc1 = state[2], bc2s = sqrtf(state[3]), lr = *lr_p;
   const float decay = 1.0f - lr * wd, step_size = lr / bc1;
-  for (long i = threadIdx.x; i < c.n; i += 256) {
+  // chunk bases are 16-byte aligned for all but ragged tensors: 4 parameters per lane per access
+  const bool al = ((((uintptr_t)c.p) | ((uintptr_t)c.g) | ((uintptr_t)c.m) | ((uintptr_t)c.v)) & 15) == 0;
+  const long n4 = al ? c.n / 4 : 0;
+  for (long i = threadIdx.x; i < n4; i += 256) {
+    float4 g4 = reinterpret_cast<float4*>(c.g)[i], p4 = reinterpret_cast<float4*>(c.p)[i];
+    float4 m4 = reinterpret_cast<float4*>(c.m)[i], v4 = reinterpret_cast<float4*>(c.v)[i];
+    float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+    float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gg[k] *= coef;
+      mm[k] = b1 * mm[k] + (1.0f - b1) * gg[k];
+      vv[k] = b2 * vv[k] + (1.0f - b2) * gg[k] * gg[k];
+      pp[k] = pp[k] * decay - step_size * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
+    }
+    reinterpret_cast<float4*>(c.p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(c.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(c.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (write_g) reinterpret_cast<float4*>(c.g)[i] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+  }
+  for (long i = n4 * 4 + threadIdx.x; i < c.n; i += 256) {
     float g = c.g[i] * coef;
     float p = c.p[i] * decay;
     float m = b1 * c.m[i] + (1.0f - b1) * g;

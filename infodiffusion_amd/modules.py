@@ -135,10 +135,13 @@ class ShadowSet:
                     if taps > 1 and w.stride(2) != kw * w.stride(3):
                         raise RuntimeError('conv weight layout not packable in place')
                     st = w.stride(3) if taps > 1 else 0
-                    n = O * I * taps
-                    for e0 in range(0, n, self.ROW):
-                        rows.append((w.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0,
-                                     w.stride(0), w.stride(1), st, O, I, taps, Ot, o0, e0, min(self.ROW, n - e0)))
+                    for tap in range(taps):
+                        for ot in range(-(-O // 32)):
+                            for it in range(-(-I // 64)):
+                                rows.append((w.data_ptr(), s.val[0].data_ptr(),
+                                             s.val[1].data_ptr() if s.val[1] is not None else 0,
+                                             w.stride(0), w.stride(1), st, O, I, taps, Ot, o0,
+                                             tap | (ot << 8) | (it << 32), 0))
                     o0 += O
             host = torch.from_numpy(np.array(rows, dtype=_pack_dtype()).view(np.uint8).reshape(len(rows), -1).copy())
             dev = self.items[0].val[0].device

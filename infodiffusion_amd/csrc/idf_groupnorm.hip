@@ -70,13 +70,22 @@ __global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ pa
                                                    int ld_t, int ld_a, float eps, float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ sc, float* __restrict__ sh) {
   __shared__ float sm[G], sr[G];
+  __shared__ double pa[8][G], pq[8][G];
   const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
-  if (tid < G) {
+  {   // all 256 threads: 8 interleaved chunk subsets per group, so the partial loads overlap
+    const int g = tid & (G - 1), kq = tid >> 5;
     double a = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      float2 v = part[((size_t)b * nchunk + k) * G + tid];
+    for (int k = kq; k < nchunk; k += 8) {
+      float2 v = part[((size_t)b * nchunk + k) * G + g];
       a += v.x; q += v.y;
     }
+    pa[kq][g] = a; pq[kq][g] = q;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += pa[k][tid]; q += pq[k][tid]; }
     double n = (double)HW * cpg;
     double mu = a / n, var = q / n - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -180,11 +189,18 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict_
   float* P2c = sm + C;
   const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
   for (int c = tid; c < C; c += 256) {
-    float S1 = 0.f, S2 = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
+    float S1 = 0.f, S2 = 0.f, T1 = 0.f, T2 = 0.f, U1 = 0.f, U2 = 0.f, V1 = 0.f, V2 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nchunk; k += 4) {      // four independent chains keep the partial loads in flight
+      float2 v0 = part[((size_t)b * nchunk + k) * C + c], v1 = part[((size_t)b * nchunk + k + 1) * C + c];
+      float2 v2 = part[((size_t)b * nchunk + k + 2) * C + c], v3 = part[((size_t)b * nchunk + k + 3) * C + c];
+      S1 += v0.x; S2 += v0.y; T1 += v1.x; T2 += v1.y; U1 += v2.x; U2 += v2.y; V1 += v3.x; V2 += v3.y;
+    }
+    for (; k < nchunk; ++k) {
       float2 v = part[((size_t)b * nchunk + k) * C + c];
       S1 += v.x; S2 += v.y;
     }
+    S1 = (S1 + T1) + (U1 + V1); S2 = (S2 + T2) + (U2 + V2);
     int g = c / cpg;
     float mu = mean[b * G + g], r = rstd[b * G + g];
     float D1 = S1, D2 = r * (S2 - mu * S1);

@@ -56,51 +56,66 @@ template <> struct Mma<float> {
 
 constexpr int BK = 32, BT = 64;   // 64 x 64 output tile, 32-deep K step
 
-// Stage a [64 rows][32 k] tile of an operand into LDS (K-contiguous, padded pitch).
-// src layout: trans = 0 -> element (r, k) at src[r*ld + k]; trans = 1 -> src[k*ld + r].
+// A [64 rows][32 k] operand tile is staged into LDS (K-contiguous, padded pitch) in two halves:
+// fetch_tile issues the global loads into registers (next tile, while the MFMAs of the current one
+// run), commit_tile writes them to LDS.  src layout: trans = 0 -> element (r, k) at src[r*ld + k];
+// trans = 1 -> src[k*ld + r] (loaded along its contiguous axis, scattered on commit).
+template <typename T> struct TileRegs { float v[2][Elem<T>::VE]; };
+
 template <typename T, bool VEC>
-__device__ __forceinline__ void stage_tile(T* lds, int pitch, const T* src, int ld, int trans, int r0, int k0,
-                                           int R, int Kend, int tid) {
+__device__ __forceinline__ void fetch_tile(TileRegs<T>& t, const T* src, int ld, int trans, int r0, int k0, int R,
+                                           int Kend, int tid) {
   constexpr int VE = Elem<T>::VE;
-  if (!trans) {
-    constexpr int VPR = BK / VE, RPP = 256 / VPR;
+  constexpr int NP = VE == 8 ? 1 : 2;       // passes: 256 vectors (bf16) / 512 vectors (fp32) per tile
 #pragma unroll
-    for (int i = 0; i < BT / RPP; ++i) {
-      int r = tid / VPR + i * RPP, kk = (tid % VPR) * VE;
-      float v[VE];
+  for (int i = 0; i < NP; ++i) {
+    int r, kk;
+    const T* ptr;
+    bool ok;
+    if (!trans) {
+      constexpr int VPR = BK / VE, RPP = 256 / VPR;
+      r = tid / VPR + i * RPP; kk = (tid % VPR) * VE;
+      ok = r0 + r < R && k0 + kk < Kend;
+      ptr = src + (size_t)(r0 + r) * ld + k0 + kk;
       if (VEC) {
-        if (r0 + r < R && k0 + kk < Kend) Vec16<T>::load(src + (size_t)(r0 + r) * ld + k0 + kk, v);
-        else {
-#pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] = 0.f;
-        }
+        if (ok) Vec16<T>::load(ptr, t.v[i]);
       } else {
 #pragma unroll
-        for (int e = 0; e < VE; ++e)
-          v[e] = (r0 + r < R && k0 + kk + e < Kend) ? Elem<T>::ld(src + (size_t)(r0 + r) * ld + k0 + kk + e) : 0.f;
+        for (int e = 0; e < VE; ++e) t.v[i][e] = (r0 + r < R && k0 + kk + e < Kend) ? Elem<T>::ld(ptr + e) : 0.f;
       }
-      Vec16<T>::store(lds + r * pitch + kk, v);
+    } else {
+      constexpr int VPK = BT / VE, KPP = 256 / VPK;
+      kk = tid / VPK + i * KPP; r = (tid % VPK) * VE;
+      ok = k0 + kk < Kend && r0 + r < R;
+      ptr = src + (size_t)(k0 + kk) * ld + r0 + r;
+      if (VEC) {
+        if (ok) Vec16<T>::load(ptr, t.v[i]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) t.v[i][e] = (k0 + kk < Kend && r0 + r + e < R) ? Elem<T>::ld(ptr + e) : 0.f;
+      }
     }
-  } else {
-    constexpr int VPK = BT / VE;            // vectors per k-row
-    constexpr int KPP = 256 / VPK;          // k rows per pass
+    if (VEC && !ok) {
 #pragma unroll
-    for (int i = 0; i < BK / KPP; ++i) {
+      for (int e = 0; e < VE; ++e) t.v[i][e] = 0.f;
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void commit_tile(const TileRegs<T>& t, T* lds, int pitch, int trans, int tid) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int NP = VE == 8 ? 1 : 2;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (!trans) {
+      constexpr int VPR = BK / VE, RPP = 256 / VPR;
+      Vec16<T>::store(lds + (tid / VPR + i * RPP) * pitch + (tid % VPR) * VE, t.v[i]);
+    } else {
+      constexpr int VPK = BT / VE, KPP = 256 / VPK;
       int k = tid / VPK + i * KPP, rr = (tid % VPK) * VE;
-      float v[VE];
-      if (VEC) {
-        if (k0 + k < Kend && r0 + rr < R) Vec16<T>::load(src + (size_t)(k0 + k) * ld + r0 + rr, v);
-        else {
 #pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] = 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VE; ++e)
-          v[e] = (k0 + k < Kend && r0 + rr + e < R) ? Elem<T>::ld(src + (size_t)(k0 + k) * ld + r0 + rr + e) : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < VE; ++e) Elem<T>::st(lds + (rr + e) * pitch + k, v[e]);
+      for (int e = 0; e < VE; ++e) Elem<T>::st(lds + (rr + e) * pitch + k, t.v[i][e]);
     }
   }
 }
@@ -127,10 +142,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  TileRegs<T> ra, rb;
+  if (kbeg < kend) {
+    fetch_tile<T, VEC>(ra, A, p.lda, p.ta, m0, kbeg, p.M, kend, tid);
+    fetch_tile<T, VEC>(rb, B, p.ldb, p.tb, n0, kbeg, p.N, kend, tid);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    stage_tile<T, VEC>(As, PITCH, A, p.lda, p.ta, m0, k0, p.M, kend, tid);
-    stage_tile<T, VEC>(Bs, PITCH, B, p.ldb, p.tb, n0, k0, p.N, kend, tid);
+    commit_tile<T>(ra, As, PITCH, p.ta, tid);
+    commit_tile<T>(rb, Bs, PITCH, p.tb, tid);
     __syncthreads();
+    if (k0 + BK < kend) {      // next tile's loads fly during this tile's MFMAs
+      fetch_tile<T, VEC>(ra, A, p.lda, p.ta, m0, k0 + BK, p.M, kend, tid);
+      fetch_tile<T, VEC>(rb, B, p.ldb, p.tb, n0, k0 + BK, p.N, kend, tid);
+    }
     typename Mma<T>::Frag nf[2], mf[2];
     const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll

@@ -122,10 +122,11 @@ int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma
 
 /* ---- dense contractions: attention bmm's (modules.py:152-159), linears
  * (modules.py:22-27, 269-276; models.py:244, 470-472, LatentUNet 147-163) and gradients.
- * C[b][m][n] = alpha * sum_k opA[m][k]*opB[n][k] (+bias[n]); ta/tb = 1 when the operand
+ * C[b][m][n] = alpha * sum_k opA[m][k]*opB[n][k] (+bias[n]) (+res[b][m][n]); ta/tb = 1 when the operand
  * is stored K-major ([K][M] / [K][N]).  splitk > 1 accumulates with fp32 atomics into a
  * pre-zeroed fp32 C (out_f32 = 1). */
-int idf_bgemm(const void* A, const void* B, void* C, const float* bias, int batch, long sA, long sB, long sC,
+int idf_bgemm(const void* A, const void* B, void* C, const float* bias, const void* res, int batch, long sA,
+              long sB, long sC,
               int lda, int ldb, int ldc, int M, int N, int K, int ta, int tb, float alpha, int out_f32,
               int splitk, int dtype, void* stream);
 int idf_softmax_fwd(void* s, long R, int N, int dtype, void* stream);            /* modules.py:156 */

@@ -29,7 +29,7 @@ SIGNATURES = {
     'idf_gn_apply': ([_p, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_conv_wgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 10 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_bgemm': ([_p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
+    'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
     'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),
     'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),
     'idf_qsample': ([_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p], C.c_int),

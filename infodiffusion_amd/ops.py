@@ -99,6 +99,11 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
     B, Cin, Hs, Ws = x.shape
     Ho, Wo = out_hw_ if out_hw_ is not None else out_hw(mode, Hs, Ws)
     y = empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+    if taps == 1 and mode == S1 and act == 0 and Cin % 8 == 0 and Cout % 4 == 0:
+        # 1x1 conv = [pixels, Cin] x [Cout, Cin]^T (+bias, +residual): the short-K GEMM
+        M = B * Ho * Wo
+        bgemm_raw(x, 0, w_fwd, 0, y, 0, bias, 1, 0, 0, 0, Cin, Cin, Cout, M, Cout, Cin, 0, 0, res=residual)
+        return y
     if uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
         call('idf_conv3x3_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout,
              {S1: 0, UP2: 2, T2: 3}[mode], _st())
@@ -174,8 +179,8 @@ def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh
 
 
 def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, ldc, M, N, K, ta, tb,
-              alpha=1.0, out_f32=False, splitk=1, dtype=None):
-    call('idf_bgemm', _p(A, offA), _p(B_, offB), _p(Cout, offC), _p(bias), batch, sA, sB, sC, lda, ldb, ldc,
+              alpha=1.0, out_f32=False, splitk=1, dtype=None, res=None):
+    call('idf_bgemm', _p(A, offA), _p(B_, offB), _p(Cout, offC), _p(bias), _p(res), batch, sA, sB, sC, lda, ldb, ldc,
          M, N, K, ta, tb, float(alpha), int(out_f32), splitk, _dt(A) if dtype is None else dtype, _st())
 
 

@@ -73,32 +73,36 @@ def seed_everything(r_seed):
         torch.cuda.manual_seed_all(r_seed)
 
 
-class AverageMeter(object):
+class AverageMeter:
+    """Running value / mean tracker with the reference's printing format (utils.py:93-113)."""
+
     def __init__(self, name, fmt=':f'):
         self.name, self.fmt = name, fmt
-        self.reset()
+        self.val = self.avg = self.sum = self.count = 0
 
     def reset(self):
         self.val = self.avg = self.sum = self.count = 0
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
         self.avg = self.sum / self.count
 
     def __str__(self):
-        return ('{name} {val' + self.fmt + '} ({avg' + self.fmt + '})').format(**self.__dict__)
+        spec = self.fmt
+        return ('%s {v%s} ({a%s})' % (self.name, spec, spec)).format(v=self.val, a=self.avg)
 
 
-class ProgressMeter(object):
+class ProgressMeter:
+    """`Epoch [ 3/50]<tab>Loss 0.1234 (0.1234)` lines, carriage-returned (utils.py:116-130)."""
+
     def __init__(self, num_batches, meters, prefix=""):
-        nd = len(str(num_batches // 1))
-        self.fmt = '[{:' + str(nd) + 'd}/' + ('{:' + str(nd) + 'd}').format(num_batches) + ']'
-        self.meters, self.prefix = meters, prefix
+        width = len(str(int(num_batches)))
+        self.template = '[{:%dd}/%s]' % (width, str(int(num_batches)).rjust(width))
+        self.meters, self.prefix = list(meters), prefix
 
     def display(self, batch):
-        print('\r' + '\t'.join([self.prefix + self.fmt.format(batch)] + [str(m) for m in self.meters]), end='')
+        cells = [self.prefix + self.template.format(batch)] + [str(m) for m in self.meters]
+        print('\r' + '\t'.join(cells), end='')
 
 
 class GradualWarmupScheduler(_LRScheduler):
@@ -133,13 +137,15 @@ class GradualWarmupScheduler(_LRScheduler):
 
 
 class LatentDataset(Dataset):
-    """utils.py:163-172: `all_a` array of a save_latent .npz."""
+    """The `all_a` latents of a `save_latent` archive (.npz wire format between the two phases,
+    utils.py:163-172)."""
 
     def __init__(self, data_path):
-        self.x = torch.from_numpy(np.load(data_path)['all_a']).float()
+        with np.load(data_path) as archive:
+            self.x = torch.as_tensor(archive['all_a'], dtype=torch.float32)
+
+    def __len__(self):
+        return self.x.shape[0]
 
     def __getitem__(self, index):
         return self.x[index]
-
-    def __len__(self):
-        return len(self.x)

@@ -107,9 +107,10 @@ int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, c
                     float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed, uint32_t salt,
                     float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 
-/* One-launch forms for samples that fit one 1024-thread workgroup (HW*C <= 64 Ki bf16 elements: the
- * 16x16 and 8x8 levels): statistics + fold + apply, and the whole backward.  IDF_ERR_UNSUPPORTED
- * otherwise (use the three-launch forms above). */
+/* One-launch forms for small samples (the 16x16 and 8x8 levels): statistics + fold + apply, and the
+ * whole backward, one workgroup per (sample, slice of whole groups).  IDF_ERR_UNSUPPORTED for shapes
+ * idf_gn_fused_ok() reports 0 for (use the three-launch forms above). */
+int idf_gn_fused_ok(int B, int HW, int C, int dtype);
 int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
                      const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc,
                      float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C,

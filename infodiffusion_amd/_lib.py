@@ -23,6 +23,7 @@ SIGNATURES = {
     'idf_pack_conv_weight': ([_p, _l, _l, _l, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_pack_conv_weights_batched': ([_p, _i, _i, _p], C.c_int),
     'idf_gn_workspace_floats': ([_i, _i, _i], C.c_int),
+    'idf_gn_fused_ok': ([_i, _i, _i, _i], C.c_int),
     'idf_gn_coef_fwd': ([_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_fused_fwd': ([_p] * 6 + [_i, _i, _f] + [_p] * 5 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_fused_bwd': ([_p] * 7 + [_i, _i] + [_p] * 8 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),

@@ -15,6 +15,7 @@
 // LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-ed with
 // 2*((row>>2)&1), which makes ds_read_b128 of any 16 consecutive rows conflict-free.
 #include "idf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,16 +29,19 @@ struct C3P {
   int R, tiles_per_img, n_tiles, wshift;
 };
 
-constexpr int HV = 5;     // max halo vectors per thread  ((R+2)*(W+2)*4 <= 1280)
+constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048;   // (R+2)*(W+2)*4 budget per block size
 constexpr int CK = 32;
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
 
-template <int MODE, int TM, int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
-  constexpr int TN = BN / 32;                 // cout 16-tiles per wave (2 x 2 waves)
-  constexpr int WV = (BN * 36 + 255) / 256;   // weight vectors per thread per chunk
-  constexpr int BM = TM * 32;                 // pixels per block
+// NWM = waves along the pixel axis (2 -> 256 threads; 4 -> 512 threads: a 256-pixel tile shares one
+// weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
+template <int MODE, int TM, int BN, int NWM>
+__global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
+  constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
+  constexpr int TN = BN / 32;                 // cout 16-tiles per wave
+  constexpr int WV = (BN * 36 + NT - 1) / NT; // weight vectors per thread per chunk
+  constexpr int BM = NWM * TM * 16;           // pixels per block
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = p.W, R = p.R, WH = W + 2;
   const int npix_h = (R + 2) * WH;
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
   const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
-  const int wm0 = (wave & 1) * (BM / 2), wn0 = (wave >> 1) * (BN / 2);
+  const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
   const int fr = lane & 15, fq = lane >> 4;
 
   // per-lane fragment bases
@@ -67,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
     wbase[a] = n * 64 + swz(n, fq) * 16;
   }
 
+  constexpr int HV = (NWM == 4 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256) / NT;   // halo vectors per thread
   f32x4_t acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
   int hlds[HV], wlds[WV];
 #pragma unroll
   for (int k = 0; k < HV; ++k) {
-    int idx = tid + k * 256;
+    int idx = tid + k * NT;
     hoff[k] = -1; hlds[k] = -1;
     if (idx < npix_h * 4) {
       int pix = idx >> 2, ch = idx & 3;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
   }
 #pragma unroll
   for (int k = 0; k < WV; ++k) {
-    int idx = tid + k * 256;            // over [BN][9][4]
+    int idx = tid + k * NT;             // over [BN][9][4]
     int ch = idx & 3, r = idx >> 2;
     int tap = r % 9, n = r / 9;
     woff[k] = -1; wlds[k] = -1;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
     }
     __syncthreads();
     constexpr int CPR = BN / 8;                      // 16-byte output chunks per pixel row
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
       int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
       if (pl >= KT || cc >= ncols) continue;
       float o[8];
@@ -213,12 +218,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16(const C3P p) {
   }
 }
 
-template <int MODE, int TM, int BN>
+template <int MODE, int TM, int BN, int NWM = 2>
 void launch(const C3P& p, hipStream_t st) {
   size_t lds = ((size_t)(p.R + 2) * (p.W + 2) + 9 * BN) * 64;
-  size_t olds = (size_t)TM * 32 * (BN + 4) * sizeof(float);      // epilogue tile
+  size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
-  hipLaunchKernelGGL((conv3x3_halo_bf16<MODE, TM, BN>), dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(256), lds, st, p);
+  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM>;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
 
 }  // namespace
@@ -241,12 +248,21 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   p.wshift = ws;
   // 128-pixel tiles when the problem is big enough to still fill the chip, else 64
   long M = (long)B * H * W;
+  static const int force_bm = getenv("IDF_CONV_BM") ? atoi(getenv("IDF_CONV_BM")) : 0;
   int BM = ((M / 128) * idf_cdiv(Cout, 64) >= 256 && H * W >= 128) ? 128 : 64;
-  int R = BM / W;
-  if (R < 1) R = 1;
-  if (R > H) R = H;
-  while (H % R) --R;
-  if ((R + 2) * (W + 2) * 4 > HV * 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
+  // 512-thread blocks (256 pixels share one weight slab) once the grid still covers the chip
+  if ((M / 256) * idf_cdiv(Cout, 64) >= 256 && H * W >= 256 && Cout > 32) BM = 256;
+  if (force_bm && H * W >= force_bm && !(force_bm == 256 && Cout <= 32)) BM = force_bm;
+  int R;
+  for (;;) {
+    R = BM / W;
+    if (R < 1) R = 1;
+    if (R > H) R = H;
+    while (H % R) --R;
+    if (BM == 256 && (R + 2) * (W + 2) * 4 > HALO_VEC_MAX_512) { BM = 128; continue; }
+    break;
+  }
+  if ((R + 2) * (W + 2) * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
   p.R = R; p.tiles_per_img = H / R;
   hipStream_t st = (hipStream_t)stream;
   const bool bn32 = Cout <= 32;
@@ -254,7 +270,7 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
 #define IDF_C3_LAUNCH(MODE)                                              \
   do {                                                                   \
     if (bn32) { if (BM == 128) launch<MODE, 4, 32>(p, st); else launch<MODE, 2, 32>(p, st); } \
-    else { if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); }      \
+    else { if (BM == 256) launch<MODE, 4, 64, 4>(p, st); else if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); } \
   } while (0)
   if (mode == 0) IDF_C3_LAUNCH(0);
   else if (mode == 2) IDF_C3_LAUNCH(2);

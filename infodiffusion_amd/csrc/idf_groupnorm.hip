@@ -14,6 +14,7 @@
 //   dx = sc*du + k1[b,g]*x + k0[b,g]      (+ dres)
 // with k1, k0, dgamma, dbeta and the FiLM gradients derived from S1, S2 only.
 #include "idf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -311,10 +312,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ------------------------------------------------- one-launch forms for small samples
-// When a sample's tensor fits one workgroup's registers (HW*C <= 64 Ki elements in bf16: every
-// 16x16 and 8x8 level) the whole GroupNorm-FiLM-SiLU-dropout pass -- statistics, coefficient fold
-// and apply -- is ONE launch with one block of 1024 threads per sample, x read once and held in
+// When a (sample, channel slice) fits one workgroup's registers the whole GroupNorm-FiLM-SiLU-dropout
+// pass -- statistics, coefficient fold and apply -- is ONE launch, x read once and held in
 // registers; likewise its backward (S1/S2 sums, k1/k0, FiLM / gamma / beta gradients, dx).
+// Groups are independent, so a sample is cut along channels into slices of whole groups
+// (grid = B x C/CS): one block per sample would leave 7/8 of the CUs idle at B = 32.
 constexpr int SNV = 8;        // 16-byte vectors per thread
 
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
@@ -327,19 +329,20 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, flo
   for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// per-wave partial sums of the slice's CS channels -> red[wave][CS][2]
 template <int VE>
-__device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], float* red, int vpp, int C, int v) {
-  // lanes of a wave that share the channel slot v sit vpp apart
-  for (int off = 32; off >= vpp; off >>= 1) {
+__device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], float* red, int vs, int CS, int v) {
+  // lanes of a wave that share the channel slot v sit vs apart
+  for (int off = 32; off >= vs; off >>= 1) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) { s[e] += __shfl_xor(s[e], off, 64); q[e] += __shfl_xor(q[e], off, 64); }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < vpp || vpp > 64) {
+  if (lane < vs) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      red[(wave * C + v * VE + e) * 2] = s[e];
-      red[(wave * C + v * VE + e) * 2 + 1] = q[e];
+      red[(wave * CS + v * VE + e) * 2] = s[e];
+      red[(wave * CS + v * VE + e) * 2 + 1] = q[e];
     }
   }
 }
@@ -350,16 +353,17 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, float eps, float* __restrict__ mean,
                                                      float* __restrict__ rstd, float* __restrict__ sc,
-                                                     float* __restrict__ sh, int HW, int C, int act,
+                                                     float* __restrict__ sh, int HW, int C, int CS, int act,
                                                      const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale) {
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* red = sm;                       // [16 waves][C][2]
-  float* chs = red + 16 * C * 2;         // [C][2]
-  float* gst = chs + C * 2;              // [G][2] mean, rstd
-  float* cof = gst + G * 2;              // [C][2] sc, sh
-  const int vpp = C / VE, lanes = 1024 / vpp, tid = threadIdx.x, cpg = C / G;
-  const int b = blockIdx.x, v = tid % vpp, pl = tid / vpp;
+  const int NT = blockDim.x, nw = NT >> 6, cpg = C / G, GS = CS / cpg;
+  float* red = sm;                       // [nw][CS][2]
+  float* chs = red + nw * CS * 2;        // [CS][2]
+  float* gst = chs + CS * 2;             // [GS][2] mean, rstd
+  float* cof = gst + GS * 2;             // [CS][2] sc, sh
+  const int vs = CS / VE, lanes = NT / vs, tid = threadIdx.x;
+  const int b = blockIdx.x, c0 = blockIdx.y * CS, v = tid % vs, pl = tid / vs;
   float xv[SNV][VE], s[VE], q[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
@@ -367,37 +371,38 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
-      Vec16<T>::load(x + ((size_t)b * HW + p) * C + v * VE, xv[k]);
+      Vec16<T>::load(x + ((size_t)b * HW + p) * C + c0 + v * VE, xv[k]);
 #pragma unroll
       for (int e = 0; e < VE; ++e) { s[e] += xv[k][e]; q[e] += xv[k][e] * xv[k][e]; }
     }
   }
-  small_reduce<VE>(s, q, red, vpp, C, v);
+  small_reduce<VE>(s, q, red, vs, CS, v);
   __syncthreads();
-  if (tid < C) {
+  for (int c = tid; c < CS; c += NT) {
     float a = 0.f, d = 0.f;
-    for (int w = 0; w < 16; ++w) { a += red[(w * C + tid) * 2]; d += red[(w * C + tid) * 2 + 1]; }
-    chs[tid * 2] = a; chs[tid * 2 + 1] = d;
+    for (int w = 0; w < nw; ++w) { a += red[(w * CS + c) * 2]; d += red[(w * CS + c) * 2 + 1]; }
+    chs[c * 2] = a; chs[c * 2 + 1] = d;
   }
   __syncthreads();
-  if (tid < G) {
+  for (int gl = tid; gl < GS; gl += NT) {
     double a = 0.0, d = 0.0;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[c * 2]; d += chs[c * 2 + 1]; }
+    for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) { a += chs[c * 2]; d += chs[c * 2 + 1]; }
     double n = (double)HW * cpg, mu = a / n, var = d / n - mu * mu;
     if (var < 0.0) var = 0.0;
     float r = (float)(1.0 / sqrt(var + (double)eps));
-    gst[tid * 2] = (float)mu; gst[tid * 2 + 1] = r;
-    mean[b * G + tid] = (float)mu; rstd[b * G + tid] = r;
+    gst[gl * 2] = (float)mu; gst[gl * 2 + 1] = r;
+    const int g = c0 / cpg + gl;
+    mean[b * G + g] = (float)mu; rstd[b * G + g] = r;
   }
   __syncthreads();
-  if (tid < C) {
-    int g = tid / cpg;
-    float ga = gamma ? gamma[tid] : 1.f, be = beta ? beta[tid] : 0.f;
-    float a = gst[g * 2 + 1] * ga, d = be - gst[g * 2] * a;
-    if (film_t) { float f = 1.f + film_t[(size_t)b * ld_t + tid]; a *= f; d = d * f + film_t[(size_t)b * ld_t + C + tid]; }
-    if (film_a) { float f = 1.f + film_a[(size_t)b * ld_a + tid]; a *= f; d = d * f + film_a[(size_t)b * ld_a + C + tid]; }
-    cof[tid * 2] = a; cof[tid * 2 + 1] = d;
-    sc[(size_t)b * C + tid] = a; sh[(size_t)b * C + tid] = d;
+  for (int cl = tid; cl < CS; cl += NT) {
+    const int gl = cl / cpg, c = c0 + cl;
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float a = gst[gl * 2 + 1] * ga, d = be - gst[gl * 2] * a;
+    if (film_t) { float f = 1.f + film_t[(size_t)b * ld_t + c]; a *= f; d = d * f + film_t[(size_t)b * ld_t + C + c]; }
+    if (film_a) { float f = 1.f + film_a[(size_t)b * ld_a + c]; a *= f; d = d * f + film_a[(size_t)b * ld_a + C + c]; }
+    cof[cl * 2] = a; cof[cl * 2 + 1] = d;
+    sc[(size_t)b * C + c] = a; sh[(size_t)b * C + c] = d;
   }
   __syncthreads();
   float scv[VE], shv[VE];
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
-      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
       const int l0 = (int)(e0 & 7);
 #pragma unroll
@@ -432,19 +437,20 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
                                                      const float* __restrict__ rstd, const float* __restrict__ sc,
                                                      const float* __restrict__ sh, float* __restrict__ dfilm_t,
                                                      float* __restrict__ dfilm_a, float* __restrict__ dgb, int HW, int C,
-                                                     int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
+                                                     int CS, int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
                                                      float dscale) {
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* red = sm;                       // [16][C][2]
-  float* pc = red + 16 * C * 2;          // [C][2]  ga*f*D1, ga*f*D2
-  float* kk = pc + C * 2;                // [G][2]  k1, k0
-  const int vpp = C / VE, lanes = 1024 / vpp, tid = threadIdx.x, cpg = C / G;
-  const int b = blockIdx.x, v = tid % vpp, pl = tid / vpp;
+  const int NT = blockDim.x, nw = NT >> 6, cpg = C / G, GS = CS / cpg;
+  float* red = sm;                       // [nw][CS][2]
+  float* pc = red + nw * CS * 2;         // [CS][2]  ga*f*D1, ga*f*D2
+  float* kk = pc + CS * 2;               // [GS][2]  k1, k0
+  const int vs = CS / VE, lanes = NT / vs, tid = threadIdx.x;
+  const int b = blockIdx.x, c0 = blockIdx.y * CS, v = tid % vs, pl = tid / vs;
   float scv[VE], shv[VE], s1[VE], s2[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    scv[e] = sc[(size_t)b * C + v * VE + e]; shv[e] = sh[(size_t)b * C + v * VE + e];
+    scv[e] = sc[(size_t)b * C + c0 + v * VE + e]; shv[e] = sh[(size_t)b * C + c0 + v * VE + e];
     s1[e] = s2[e] = 0.f;
   }
   uint4 xr[SNV];                // packed x stays in registers; dA is re-read (L2-hot) in the apply pass
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
-      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       xr[k] = *reinterpret_cast<const uint4*>(x + e0);
       float xv[VE], dav[VE], du[VE];
       unpack16<T>(xr[k], xv);
@@ -462,12 +468,12 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       for (int e = 0; e < VE; ++e) { s1[e] += du[e]; s2[e] += du[e] * xv[e]; }
     }
   }
-  small_reduce<VE>(s1, s2, red, vpp, C, v);
+  small_reduce<VE>(s1, s2, red, vs, CS, v);
   __syncthreads();
-  if (tid < C) {
-    const int c = tid, g = c / cpg;
+  for (int cl = tid; cl < CS; cl += NT) {
+    const int c = c0 + cl, g = c / cpg;
     float S1 = 0.f, S2 = 0.f;
-    for (int w = 0; w < 16; ++w) { S1 += red[(w * C + c) * 2]; S2 += red[(w * C + c) * 2 + 1]; }
+    for (int w = 0; w < nw; ++w) { S1 += red[(w * CS + cl) * 2]; S2 += red[(w * CS + cl) * 2 + 1]; }
     float mu = mean[b * G + g], r = rstd[b * G + g];
     float D1 = S1, D2 = r * (S2 - mu * S1);
     float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -480,26 +486,27 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     if (dfilm_a) { dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
     dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
     dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
-    pc[c * 2] = ga * f * D1; pc[c * 2 + 1] = ga * f * D2;
+    pc[cl * 2] = ga * f * D1; pc[cl * 2 + 1] = ga * f * D2;
   }
   __syncthreads();
-  if (tid < G) {
+  for (int gl = tid; gl < GS; gl += NT) {
     float P1 = 0.f, P2 = 0.f;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { P1 += pc[c * 2]; P2 += pc[c * 2 + 1]; }
-    float mu = mean[b * G + tid], r = rstd[b * G + tid];
+    for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) { P1 += pc[c * 2]; P2 += pc[c * 2 + 1]; }
+    const int g = c0 / cpg + gl;
+    float mu = mean[b * G + g], r = rstd[b * G + g];
     float invN = 1.f / ((float)HW * cpg);
-    kk[tid * 2] = -r * r * P2 * invN;
-    kk[tid * 2 + 1] = (-r * P1 + r * r * mu * P2) * invN;
+    kk[gl * 2] = -r * r * P2 * invN;
+    kk[gl * 2 + 1] = (-r * P1 + r * r * mu * P2) * invN;
   }
   __syncthreads();
   float k1v[VE], k0v[VE];
 #pragma unroll
-  for (int e = 0; e < VE; ++e) { int g = (v * VE + e) / cpg; k1v[e] = kk[g * 2]; k0v[e] = kk[g * 2 + 1]; }
+  for (int e = 0; e < VE; ++e) { int gl = (v * VE + e) / cpg; k1v[e] = kk[gl * 2]; k0v[e] = kk[gl * 2 + 1]; }
 #pragma unroll
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
-      size_t e0 = ((size_t)b * HW + p) * C + v * VE;
+      size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       float xv[VE], dav[VE], du[VE], o[VE];
       unpack16<T>(xr[k], xv);
       Vec16<T>::load(dA + e0, dav);
@@ -511,10 +518,30 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   }
 }
 
-bool small_ok(int HW, int C, int VE) {
-  int vpp = C / VE;
-  return C % G == 0 && C % VE == 0 && vpp >= 1 && vpp <= 64 && (vpp & (vpp - 1)) == 0 && C <= 1024 &&
-         (long)HW * vpp <= 1024L * SNV;
+// Slice plan for the one-launch kernels: CS channels per block (whole groups, whole 16-byte vectors,
+// CS/VE a power of two <= 64) and the block size.  Largest slice that still gives >= ~256 blocks.
+struct SmallPlan { int CS, NT; };
+bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan) {
+  static const int max_hw = getenv("IDF_GN_SMALL_MAXHW") ? atoi(getenv("IDF_GN_SMALL_MAXHW")) : 4096;
+  static const int want = getenv("IDF_GN_SMALL_BLOCKS") ? atoi(getenv("IDF_GN_SMALL_BLOCKS")) : 256;
+  if (C % G || C % VE || C > 1024 || HW > max_hw || HW < 1) return false;
+  const int cpg = C / G;
+  int unit = cpg;                       // lcm(cpg, VE)
+  while (unit % VE) unit += cpg;
+  int best = 0;
+  for (int cs = unit; cs <= C; cs *= 2) {
+    const int vs = cs / VE;
+    if (C % cs || (vs & (vs - 1)) || vs > 64) continue;
+    if ((long)HW * vs > 1024L * SNV) break;
+    if (!best || (long)B * (C / cs) >= want) best = cs;
+  }
+  if (!best) return false;
+  const int vectors = HW * (best / VE);
+  int nt = ((vectors + 1) / 2 + 63) / 64 * 64;
+  if (nt < 64) nt = 64;
+  if (nt > 1024) nt = 1024;
+  plan->CS = best; plan->NT = nt;
+  return true;
 }
 
 int pick_chunk(int B, int HW) {
@@ -628,6 +655,12 @@ extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const flo
   return IDF_OK;
 }
 
+// 1 when idf_gn_fused_fwd / idf_gn_fused_bwd cover this shape (the host picks the path with it).
+extern "C" int idf_gn_fused_ok(int B, int HW, int C, int dtype) {
+  SmallPlan sp;
+  return small_plan(B, HW, C, dtype == IDF_F32 ? 4 : 8, &sp) ? 1 : 0;
+}
+
 // One-launch GroupNorm + FiLM fold + apply for small samples (statistics, sc/sh, a = act(x*sc+sh)).
 // IDF_ERR_UNSUPPORTED when a sample does not fit one workgroup: use idf_gn_coef_fwd + idf_gn_apply.
 extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
@@ -635,21 +668,22 @@ extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, co
                                 float* sc, float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act,
                                 int B, int HW, int C, int dtype, void* stream) {
   int VE = dtype == IDF_F32 ? 4 : 8;
-  if (!small_ok(HW, C, VE)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_fwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  SmallPlan sp;
+  if (!small_plan(B, HW, C, VE, &sp)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_fwd: HW=%d C=%d does not fit one workgroup", HW, C);
   if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "gn_fused_fwd: act must be 1 or 2");
   if (B == 0) return IDF_OK;
   uint32_t thr = idf_drop_thresh(p_drop);
   float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
   const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
-  size_t lds = ((size_t)16 * C * 2 + C * 2 + G * 2 + C * 2) * sizeof(float);
+  size_t lds = ((size_t)(sp.NT / 64) * sp.CS * 2 + sp.CS * 2 + G * 2 + sp.CS * 2) * sizeof(float);
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B), dim3(1024), lds, st, (const float*)x, (float*)out, gamma, beta, film_t,
-                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)x, (float*)out, gamma, beta, film_t,
+                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B), dim3(1024), lds, st, (const bf16_t*)x, (bf16_t*)out, gamma, beta,
-                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, act, sd, salt, thr, dscale);
+    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)x, (bf16_t*)out, gamma, beta,
+                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -660,22 +694,23 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const f
                                 float* dgb, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW,
                                 int C, int dtype, void* stream) {
   int VE = dtype == IDF_F32 ? 4 : 8;
-  if (!small_ok(HW, C, VE)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_bwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  SmallPlan sp;
+  if (!small_plan(B, HW, C, VE, &sp)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_bwd: HW=%d C=%d does not fit one workgroup", HW, C);
   if (B == 0) return IDF_OK;
   uint32_t thr = idf_drop_thresh(p_drop);
   float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
   const uint64_t* sd = (act == 2 && p_drop > 0.f) ? seed : nullptr;
-  size_t lds = ((size_t)16 * C * 2 + C * 2 + G * 2) * sizeof(float);
+  size_t lds = ((size_t)(sp.NT / 64) * sp.CS * 2 + sp.CS * 2 + G * 2) * sizeof(float);
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B), dim3(1024), lds, st, (const float*)dA, (const float*)x, (float*)dx,
-                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW, C, act, sd,
+    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)dA, (const float*)x, (float*)dx,
+                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW, C, sp.CS, act, sd,
                        salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B), dim3(1024), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
+    hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
                        (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW,
-                       C, act, sd, salt, thr, dscale);
+                       C, sp.CS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

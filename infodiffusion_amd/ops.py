@@ -5,6 +5,8 @@ Raw launchers (`*_raw`) take/return torch CUDA tensors whose memory is dense NHW
 current stream; `torch.autograd.Function`s on top provide backward through the
 hand-written gradient kernels.  There is no non-HIP fallback.
 """
+import functools
+
 import torch
 
 from . import _lib
@@ -82,10 +84,16 @@ def out_hw(mode, H, W):
 
 def _halo_fits(H, W, B, Cout):
     BM = 128 if (B * H * W // 128 * -(-Cout // 64) >= 256 and H * W >= 128) else 64
-    R = max(1, min(H, BM // W))
-    while H % R:
-        R -= 1
-    return (R + 2) * (W + 2) * 4 <= 1280
+    if B * H * W // 256 * -(-Cout // 64) >= 256 and H * W >= 256 and Cout > 32:
+        BM = 256
+    while True:
+        R = max(1, min(H, BM // W))
+        while H % R:
+            R -= 1
+        if BM == 256 and (R + 2) * (W + 2) * 4 > 2048:
+            BM = 128
+            continue
+        return (R + 2) * (W + 2) * 4 <= (2048 if BM == 256 else 1280)
 
 
 def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
@@ -185,13 +193,15 @@ def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, 
 
 
 # ------------------------------------------------------------- fused conv op
+@functools.lru_cache(maxsize=None)
+def _gn_fused_ok(B, HW, C, dt):
+    return bool(_lib.load().idf_gn_fused_ok(B, HW, C, dt))
+
+
 def gn_small_ok(x):
-    """A sample fits one 1024-thread workgroup: the one-launch GroupNorm kernels apply."""
+    """The one-launch GroupNorm kernels cover this tensor (idf_gn_fused_ok)."""
     B, C, H, W = x.shape
-    VE = 4 if x.dtype == torch.float32 else 8
-    vpp = C // VE
-    return (C % 32 == 0 and C % VE == 0 and 1 <= vpp <= 64 and not (vpp & (vpp - 1)) and C <= 1024
-            and H * W * vpp <= 8192)
+    return _gn_fused_ok(B, H * W, C, _dt(x))
 
 
 def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act):

@@ -21,7 +21,10 @@ class FusedClipAdamW(torch.optim.Optimizer):
 
     def _dense_like(self, p, g):
         """Gradient memory must be element-aligned with the parameter's."""
-        return g.dtype == torch.float32 and g.stride() == p.stride() and g.is_cuda
+        if g.dtype != torch.float32 or not g.is_cuda or g.shape != p.shape:
+            return False
+        # strides of size-1 dims carry no layout (a 1x1 conv weight is dense in either memory format)
+        return all(n == 1 or a == b for n, a, b in zip(p.shape, g.stride(), p.stride()))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,8 +36,7 @@ class FusedClipAdamW(torch.optim.Optimizer):
             if p.grad is None:
                 continue
             if not self._dense_like(p, p.grad):
-                p.grad = p.grad.clone(memory_format=torch.preserve_format) if p.grad.stride() == p.stride() \
-                    else torch.empty_like(p).copy_(p.grad)
+                p.grad = torch.empty_like(p).copy_(p.grad)
             st = self.state[p]
             if not st:
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)

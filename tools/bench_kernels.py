@@ -16,16 +16,24 @@ SHAPES = [(64, 64, 64), (128, 64, 64), (192, 64, 64), (128, 128, 64), (128, 128,
 
 
 def timeit(fn, n=20):
+    """Average GPU time of one call: n calls captured in a hipGraph (no host launch gaps), replayed."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side), torch.cuda.graph(g, stream=side):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3   # us
+    return e0.elapsed_time(e1) / (3 * n) * 1e3   # us
 
 
 def main(which):
@@ -56,6 +64,14 @@ def main(which):
                 return ops.gn_apply_raw(x, sc, sh, None, 0, 0.0, 2)
             t = timeit(gn)
             line += ' gn-fwd %6.1f us %5.0f GB/s' % (t, 3 * x.numel() * 2 / t / 1e3)
+            dA = torch.randn_like(x)
+            if ops.gn_small_ok(x):
+                _, m, r, sc, sh = ops.gn_fused_fwd_raw(x, g, b_, None, None, None, 0, 0.0, 2)
+                t = timeit(lambda: ops.gn_fused_bwd_raw(dA, x, g, b_, None, None, m, r, sc, sh, None, 0, 0.0, 2))
+            else:
+                m, r, sc, sh = ops.gn_coef_fwd_raw(x, g, b_, None, None)
+                t = timeit(lambda: ops.gn_coef_bwd_raw(dA, x, None, g, b_, None, None, m, r, sc, sh, None, 0, 0.0, 2))
+            line += ' gn-bwd %6.1f us %5.0f GB/s' % (t, 3 * x.numel() * 2 / t / 1e3)
         print(line, flush=True)
 
 

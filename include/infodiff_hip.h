@@ -69,9 +69,11 @@ int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, 
 /* bf16 fast path of the weight gradient (taps 9 or 1; mode S1, S2 or UP2; H, W = dy dims) on an
  * already-activated input `a`
  * (halo tile in LDS, transposed LDS reads); also accumulates db[n] = sum dy when db != NULL.
+ * accumulate = 0: dW / db are zeroed inside first; 1: the kernel adds onto what they hold (the
+ * host's gradient arena: every parameter gradient zeroed by ONE memset per step).
  * Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (use idf_conv2d_wgrad then). */
 int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
-                        int Cout, int taps, int mode, void* stream);
+                        int Cout, int taps, int mode, int accumulate, void* stream);
 
 /* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
  * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */
@@ -100,12 +102,14 @@ int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, con
                  float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 /* Backward through act(GN/FiLM(x)) given dA (gradient w.r.t. the activated tensor):
  * dx (+ dres), dfilm_t/dfilm_a [B,2C], dgb [B][2][C] (per-sample dgamma, dbeta;
- * sum over B with idf_colsum), k1/k0 [B,32] scratch. */
+ * sum over B with idf_colsum) when non-NULL, and/or atomic accumulation of the batch sums
+ * straight into dgamma_acc[C] / dbeta_acc[C] (gradient arena) when non-NULL; k1/k0 [B,32] scratch. */
 int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
                     const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
                     const float* mean, const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
-                    float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed, uint32_t salt,
-                    float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
+                    float* dgb, float* dgamma_acc, float* dbeta_acc, float* k1, float* k0, float* workspace,
+                    const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype,
+                    void* stream);
 
 /* One-launch forms for small samples (the 16x16 and 8x8 levels): statistics + fold + apply, and the
  * whole backward, one workgroup per (sample, slice of whole groups).  IDF_ERR_UNSUPPORTED for shapes
@@ -118,8 +122,8 @@ int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* 
 int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma, const float* beta,
                      const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                      const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,
-                     const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype,
-                     void* stream);
+                     float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt, float p_drop, int act,
+                     int B, int HW, int C, int dtype, void* stream);
 
 /* ---- dense contractions: attention bmm's (modules.py:152-159), linears
  * (modules.py:22-27, 269-276; models.py:244, 470-472, LatentUNet 147-163) and gradients.

@@ -26,10 +26,10 @@ SIGNATURES = {
     'idf_gn_fused_ok': ([_i, _i, _i, _i], C.c_int),
     'idf_gn_coef_fwd': ([_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_fused_fwd': ([_p] * 6 + [_i, _i, _f] + [_p] * 5 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_gn_fused_bwd': ([_p] * 7 + [_i, _i] + [_p] * 8 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_gn_fused_bwd': ([_p] * 7 + [_i, _i] + [_p] * 10 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_apply': ([_p, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_conv_wgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 10 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_conv_wgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 12 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
     'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),
     'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict_
                                                        int ld_t, int ld_a, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        float* __restrict__ k1, float* __restrict__ k0,
                                                        float* __restrict__ dfilm_t, float* __restrict__ dfilm_a,
-                                                       float* __restrict__ dgb) {
+                                                       float* __restrict__ dgb, float* __restrict__ dgam_acc,
+                                                       float* __restrict__ dbet_acc) {
   extern __shared__ float sm[];   // P1c[C], P2c[C]
   float* P1c = sm;
   float* P2c = sm + C;
@@ -219,8 +220,12 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize(const float2* __restrict_
       dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt;
       dfilm_a[(size_t)b * 2 * C + C + c] = Ge;
     }
-    dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
-    dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    if (dgb) {
+      dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
+      dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    }
+    if (dgam_acc) atomicAdd(dgam_acc + c, f * D2);     // B adds per address: accumulate straight into the
+    if (dbet_acc) atomicAdd(dbet_acc + c, f * D1);     // (pre-zeroed) parameter gradients, no column-sum pass
     P1c[c] = ga * f * D1;
     P2c[c] = ga * f * D2;
   }
@@ -436,7 +441,8 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
                                                      int ld_t, int ld_a, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ sc,
                                                      const float* __restrict__ sh, float* __restrict__ dfilm_t,
-                                                     float* __restrict__ dfilm_a, float* __restrict__ dgb, int HW, int C,
+                                                     float* __restrict__ dfilm_a, float* __restrict__ dgb,
+                                                     float* __restrict__ dgam_acc, float* __restrict__ dbet_acc, int HW, int C,
                                                      int CS, int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
                                                      float dscale) {
   constexpr int VE = Elem<T>::VE;
@@ -484,8 +490,12 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     float Gf = ga * D2 + be * D1, Ge = D1;
     if (dfilm_t) { dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
     if (dfilm_a) { dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
-    dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
-    dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    if (dgb) {
+      dgb[((size_t)b * 2 + 0) * C + c] = f * D2;
+      dgb[((size_t)b * 2 + 1) * C + c] = f * D1;
+    }
+    if (dgam_acc) atomicAdd(dgam_acc + c, f * D2);
+    if (dbet_acc) atomicAdd(dbet_acc + c, f * D1);
     pc[cl * 2] = ga * f * D1; pc[cl * 2 + 1] = ga * f * D2;
   }
   __syncthreads();
@@ -595,8 +605,9 @@ extern "C" int idf_gn_coef_fwd(const void* x, const float* gamma, const float* b
 extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma,
                                const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
                                const float* mean, const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
-                               float* dgb, float* k1, float* k0, float* workspace, const uint64_t* seed,
-                               uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
+                               float* dgb, float* dgamma_acc, float* dbeta_acc, float* k1, float* k0, float* workspace,
+                               const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C,
+                               int dtype, void* stream) {
   if (B == 0) return IDF_OK;
   int VE = dtype == IDF_F32 ? 4 : 8;
   if (C % G || C % VE || C / VE > 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "groupnorm bwd: C=%d unsupported", C);
@@ -617,7 +628,7 @@ extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, 
   IDF_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_finalize, dim3(B), dim3(256), 2 * C * sizeof(float), st, (const float2*)workspace, nchunk,
                      HW, C, gamma, beta, film_t, film_a, ld_t ? ld_t : 2 * C, ld_a ? ld_a : 2 * C, mean, rstd, k1, k0,
-                     dfilm_t, dfilm_a, dgb);
+                     dfilm_t, dfilm_a, dgb, dgamma_acc, dbeta_acc);
   IDF_CHECK_LAUNCH();
   int achunk = pick_chunk_ew(B, HW);
   dim3 ga(idf_cdiv(HW, achunk), B);
@@ -691,7 +702,8 @@ extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, co
 extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma, const float* beta,
                                 const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                                 const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
-                                float* dgb, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW,
+                                float* dgb, float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt,
+                                float p_drop, int act, int B, int HW,
                                 int C, int dtype, void* stream) {
   int VE = dtype == IDF_F32 ? 4 : 8;
   SmallPlan sp;
@@ -705,12 +717,12 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const f
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
     hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)dA, (const float*)x, (float*)dx,
-                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW, C, sp.CS, act, sd,
+                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd,
                        salt, thr, dscale);
   else
     hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
-                       (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, HW,
-                       C, sp.CS, act, sd, salt, thr, dscale);
+                       (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb,
+                       dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

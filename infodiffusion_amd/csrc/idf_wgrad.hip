@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
 // outputs) for shapes this kernel does not cover; the caller then uses idf_conv2d_wgrad.
 // dW / db are zeroed inside.
 extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
-                                   int Cin, int Cout, int taps, int mode, void* stream) {
+                                   int Cin, int Cout, int taps, int mode, int accumulate, void* stream) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -228,8 +228,9 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
   hipStream_t st = (hipStream_t)stream;
   const size_t nW = (size_t)Cout * taps * Cin;
-  hipError_t e;
-  if (db == dW + nW) e = hipMemsetAsync(dW, 0, (nW + Cout) * sizeof(float), st);   // caller packed dW | db
+  hipError_t e = hipSuccess;
+  if (accumulate) {}                     // dW / db already hold zeros or a running sum (gradient arena)
+  else if (db == dW + nW) e = hipMemsetAsync(dW, 0, (nW + Cout) * sizeof(float), st);   // caller packed dW | db
   else {
     e = hipMemsetAsync(dW, 0, nW * sizeof(float), st);
     if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);

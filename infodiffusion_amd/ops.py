@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import call, F32, BF16
+from .grad_arena import slot_of
 
 GN_EPS = 1e-5
 S1, S2, UP2, T2 = 0, 1, 2, 3
@@ -169,19 +170,30 @@ def gn_coef_fwd_raw(x, gamma, beta, film_t, film_a):
     return mean, rstd, sc, sh
 
 
-def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act):
+def _gn_acc(acc):
+    """acc = (gamma slot, beta slot) of the gradient arena -> their views when both are free."""
+    if acc is None or acc[0] is None or acc[1] is None or not (acc[0].available() and acc[1].available()):
+        return None
+    return acc[0].take(), acc[1].take()
+
+
+def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None):
     B, C, H, W = x.shape
     dev = x.device
     dx = torch.empty_like(x, memory_format=CL)
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+    acc = _gn_acc(acc)
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
     k1 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     k0 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
     call('idf_gn_coef_bwd', _p(dA), _p(x), _p(dres), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a),
-         _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(k1), _p(k0), _p(ws), _p(seed),
+         _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
+         _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(k1), _p(k0), _p(ws), _p(seed),
          salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
+    if acc:
+        return dx, acc[0], acc[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -218,16 +230,20 @@ def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act):
     return a, mean, rstd, sc, sh
 
 
-def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act):
+def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None):
     B, C, H, W = x.shape
     dev = x.device
     dx = torch.empty_like(x, memory_format=CL)
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+    acc = _gn_acc(acc)
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
     call('idf_gn_fused_bwd', _p(dA), _p(x), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
-         _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb), _p(seed), salt, float(p_drop),
+         _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
+         _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop),
          act, B, H * W, C, _dt(x), _st())
+    if acc:
+        return dx, acc[0], acc[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -261,10 +277,22 @@ def _pad_channels(t, mult=8):
     return out
 
 
-def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias):
+def _slot_views(w_slot, b_slot, want_bias, shape):
+    """(dW view, db view) from the gradient arena when both are free this step, else None."""
+    if w_slot is None or not w_slot.available() or tuple(w_slot.view.shape) != tuple(shape):
+        return None
+    if not w_slot.view.permute(0, 2, 3, 1).is_contiguous():      # kernel layout [O][kh][kw][I]
+        return None
+    if want_bias and (b_slot is None or not b_slot.available()):
+        return None
+    return w_slot.take(), (b_slot.take() if want_bias else None)
+
+
+def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None):
     """dW (fp32, logical [O,I,kh,kw], memory [O][taps][I]) and db for a conv whose
     (already activated) input is `a`.  Channel counts that are not multiples of 8
-    (image input, epsilon output) are zero-padded so the MFMA kernel covers them."""
+    (image input, epsilon output) are zero-padded so the MFMA kernel covers them.
+    With gradient-arena slots the kernel accumulates straight into them (no memset)."""
     B, Cin, Hs, Ws = a.shape
     _, Cout, Ho, Wo = dy.shape
     k = 3 if taps == 9 else 1
@@ -272,11 +300,16 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias):
         ap, dyp = _pad_channels(a), _pad_channels(dy)
         Cip, Cop = ap.shape[1], dyp.shape[1]
         if _fast_wgrad_ok(Cip, Cop, Ho, Wo, a.dtype, mode, taps):
+            views = _slot_views(w_slot, b_slot, want_bias, (Cout, Cin, k, k)) if (Cip == Cin and Cop == Cout) else None
+            if views is not None:
+                dW, db = views
+                call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 1, _st())
+                return dW, db
             nW = Cop * k * k * Cip
             buf = torch.empty((nW + Cop,), dtype=torch.float32, device=a.device)   # dW | db: one memset
             dW = buf[:nW].view(Cop, k, k, Cip)
             db = buf[nW:] if want_bias else None
-            call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, _st())
+            call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 0, _st())
             dW = dW.permute(0, 3, 1, 2)
             if Cip != Cin or Cop != Cout:
                 dW = dW[:Cout, :Cin]
@@ -298,7 +331,7 @@ class _FusedConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False):
+    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None):
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
@@ -312,7 +345,7 @@ class _FusedConv(torch.autograd.Function):
             a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
         w_fwd = cfg['shadows'](x.dtype, train)[0]
         y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, weight.shape[0])
-        ctx.cfg, ctx.p_drop = cfg, p_drop
+        ctx.cfg, ctx.p_drop, ctx.slots = cfg, p_drop, slots or (None, None, None, None)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                               seed)
@@ -330,29 +363,33 @@ class _FusedConv(torch.autograd.Function):
         dW = db = dx = dgw = dgb = dft = dfa = dres = None
         want_b = bias is not None and need[2]
         if need[1]:
-            dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b)
+            dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b, ctx.slots[0], ctx.slots[1])
         elif want_b:
             B, Co, Ho, Wo = dy.shape
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
         if need[0] or (act and (need[3] or need[5] or need[6])):
             w_dgrad = cfg['shadows'](x.dtype, True)[1]
             dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
+            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
             if act and gn_small_ok(x):
                 dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                          seed, salt, p_drop, act)
+                                                          seed, salt, p_drop, act, gacc)
             elif act:
                 dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, None, gn_w, gn_b, film_t, film_a, mean, rstd,
-                                                         sc, sh, seed, salt, p_drop, act)
+                                                         sc, sh, seed, salt, p_drop, act, gacc)
             else:
                 dx = dA
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None
 
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None):
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
-    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train)
+    slots = None
+    if torch.is_grad_enabled():
+        slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
+    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots)
 
 
 # ------------------------------------------------------------------ attention

@@ -5,19 +5,29 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from .grad_arena import GradArena
 from ._lib import call
 
 _CHUNK = 65536
 
 
 class FusedClipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=1.0):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=1.0,
+                 grad_arena=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_norm))
+        # fixed gradient slots the backward kernels accumulate into; cleared by zero_grad() in one memset
+        self.arena = GradArena([p for g in self.param_groups for p in g['params']]) if grad_arena else None
         self._key = None
         self._table = self._partial = None
         self._state = None
         self._lr = None
         self._pinned = None
+
+    def zero_grad(self, set_to_none=True):
+        """Always drops the `.grad` tensors (they may alias arena slots) and clears the arena."""
+        if self.arena is not None:
+            self.arena.zero()
+        super().zero_grad(set_to_none=True)
 
     def _dense_like(self, p, g):
         """Gradient memory must be element-aligned with the parameter's."""

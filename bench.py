@@ -214,7 +214,8 @@ def main():
         opt = FusedClipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, max_norm=1.0)
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, capturable=bool(a.graph))
-    sync = GradSync(model, world, force=force_sync) if (world > 1 or force_sync) else None
+    sync = GradSync(model, world, force=force_sync, arena=getattr(opt, 'arena', None)) if (world > 1 or force_sync) \
+        else None
     if sync is not None:
         sync.broadcast_parameters()
 

@@ -10,7 +10,9 @@ order backward produces them.  Packing / unpacking a bucket is ONE multi-tensor
 copy each (bucket views carry the gradients' own strides, so channels-last conv
 gradients move as dense memory), and each bucket's all-reduce is issued on a side
 stream as soon as it is packed, so packing bucket k+1 overlaps the wire time of
-bucket k.  Parameters that never receive a gradient (the dead `crossattn.*`
+bucket k.  Gradients that already live in the optimizer's gradient arena (grad_arena.py: every
+conv / GroupNorm gradient the kernels accumulated in place) need no packing at all: the arena's flat
+buffer is all-reduced in place, in bucket-sized pieces.  Parameters that never receive a gradient (the dead `crossattn.*`
 weights, `encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are
 skipped.
 """
@@ -29,7 +31,8 @@ def _dense(t):
 
 
 class GradSync:
-    def __init__(self, model, world_size=None, bucket_bytes=32 << 20, force=False):
+    def __init__(self, model, world_size=None, bucket_bytes=32 << 20, force=False, arena=None):
+        self.arena = arena      # optimizer's GradArena: its resident gradients are reduced in place
         self.force = force      # run the exchange even at world size 1 (single-GPU validation of the DP path)
         self.world = world_size if world_size is not None else dist.get_world_size()
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -81,17 +84,38 @@ class GradSync:
         self._plan_key, self._plan = key, plan
         return plan
 
+    def _reduce_mean(self, flat):
+        if flat.is_cuda:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL averages in the collective: no divide pass
+        else:
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+
     @torch.no_grad()
     def all_reduce_grads(self):
         """Average the gradients over all ranks (in place)."""
         grads = [p.grad for p in reversed(self.params) if p.grad is not None]
         if not grads or (self.world == 1 and not self.force):
             return
-        plan = self._make_plan(grads)
         use_side = grads[0].is_cuda
         cur = torch.cuda.current_stream() if use_side else None
         if use_side and self._side is None:
             self._side = torch.cuda.Stream()
+        if self.arena is not None and any(self.arena.holds(g) for g in grads):
+            # zero-copy part: the arena itself, piecewise (slots nobody wrote this step hold zeros)
+            grads = [g for g in grads if not self.arena.holds(g)]
+            flat = self.arena.flat
+            step = max(1, self.bucket_bytes // 4)
+            if use_side:
+                self._side.wait_stream(cur)
+            for off in range(0, flat.numel(), step):
+                piece = flat[off:off + step]
+                if use_side:
+                    with torch.cuda.stream(self._side):
+                        self._reduce_mean(piece)
+                else:
+                    self._reduce_mean(piece)
+        plan = self._make_plan(grads) if grads else []
         i = 0
         for flat, views, n in plan:
             group = grads[i:i + n]
@@ -100,11 +124,9 @@ class GradSync:
             if use_side:
                 self._side.wait_stream(cur)
                 with torch.cuda.stream(self._side):
-                    dist.all_reduce(flat)
-                    flat.div_(self.world)
+                    self._reduce_mean(flat)
             else:
-                dist.all_reduce(flat)
-                flat.div_(self.world)
+                self._reduce_mean(flat)
         if use_side:
             cur.wait_stream(self._side)
         i = 0

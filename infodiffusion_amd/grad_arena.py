@@ -50,7 +50,7 @@ def _dense(p):
 
 class GradArena:
     def __init__(self, params):
-        params = [p for p in params if p.requires_grad and p.is_cuda and p.dtype == torch.float32 and _dense(p)]
+        params = [p for p in params if p.requires_grad and p.dtype == torch.float32 and _dense(p)]
         self.epoch = 0
         self.flat = None
         if not params:
@@ -68,6 +68,13 @@ class GradArena:
         if self.flat is not None:
             self.flat.zero_()
         self.epoch += 1
+
+    def holds(self, t):
+        """`t`'s memory lies inside the arena (a gradient the kernels accumulated in place)."""
+        if self.flat is None or t.device != self.flat.device:
+            return False
+        lo = self.flat.data_ptr()
+        return lo <= t.data_ptr() < lo + 4 * self.flat.numel()
 
     def covers(self, p):
         s = _SLOTS.get(id(p))

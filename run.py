@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 from infodiffusion_amd.data import get_dataset, get_dataset_config
 from infodiffusion_amd.dist import GradSync, shard_range
+from infodiffusion_amd.optim import FusedClipAdamW
 from infodiffusion_amd.models import Diff, InfoDiff
 from infodiffusion_amd.sampling import DiffusionProcess, LatentDiffusionProcess, TwoPhaseDiffusionProcess
 from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter,
@@ -99,10 +100,12 @@ def save_model(args, epoch, model, latent=False):
 
 
 def _fit(args, model, batches, world, rank, latent=False):
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, weight_decay=1e-5)
+    # reference run.py:177,199-200: AdamW(lr, weight_decay=1e-5) after clip_grad_norm_(1.0) -- here one fused
+    # clip+AdamW kernel sequence over a device chunk table, gradients accumulated in the optimizer's arena
+    opt = FusedClipAdamW(model.parameters(), lr=args.learning_rate, weight_decay=1e-5, max_norm=1.0)
     cosine = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=args.epochs, eta_min=0, last_epoch=-1)
     warm = GradualWarmupScheduler(optimizer=opt, multiplier=2., warm_epoch=1, after_scheduler=cosine)
-    sync = GradSync(model, world) if world > 1 else None
+    sync = GradSync(model, world, arena=opt.arena) if world > 1 else None
     if sync is not None:
         sync.broadcast_parameters()
     losses = AverageMeter('Loss', ':.4f')
@@ -117,8 +120,7 @@ def _fit(args, model, batches, world, rank, latent=False):
             loss.backward()
             if sync is not None:
                 sync.all_reduce_grads()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
-            opt.step()
+            opt.step()                                  # global-norm clip at 1.0 + AdamW
             total += loss.detach()
             n += 1
         losses.update(float(total) / max(n - 1, 1))   # reference divides by the last index (run.py:205)

@@ -35,8 +35,24 @@ def _worker(rank, world, port, q):
     local = [p.grad.clone() for p in net.parameters()]
     sync.all_reduce_grads()
     # plain lists: tensors in an mp.Queue travel by fd and die with the worker
+    avg1 = [p.grad.tolist() for p in net.parameters()]
+    # second exchange: some gradients live in a gradient arena (reduced in place, no packing), one does not
+    from infodiffusion_amd.grad_arena import GradArena, slot_of
+    arena = GradArena(list(net.parameters()))
+    sync2 = GradSync(model, world, bucket_bytes=256, arena=arena)
+    plist = list(net.parameters())
+    for p, g in zip(plist, local):
+        if p is plist[1]:
+            p.grad = g.clone()                   # stand-alone gradient
+        else:
+            v = slot_of(p).take()
+            v.copy_(g)
+            p.grad = v
+    sync2.all_reduce_grads()
     res = {'params': [p.detach().tolist() for p in net.parameters()],
-           'local': [t.tolist() for t in local], 'avg': [p.grad.tolist() for p in net.parameters()],
+           'local': [t.tolist() for t in local], 'avg': avg1,
+           'avg_arena': [p.grad.tolist() for p in plist],
+           'in_arena': [arena.holds(p.grad) for p in plist],
            'dead_none': all(p.grad is None for p in dead.parameters()),
            'shard': shard_range(10, rank, world)}
     q.put((rank, res))
@@ -63,5 +79,9 @@ def test_grad_allreduce_world2():
         la, lb, ga, gb = T(la), T(lb), T(ga), T(gb)
         want = (la + lb) / 2
         assert torch.allclose(ga, want, atol=1e-7) and torch.equal(ga, gb)
+    for la, lb, ga, gb in zip(a['local'], b['local'], a['avg_arena'], b['avg_arena']):
+        la, lb, ga, gb = T(la), T(lb), T(ga), T(gb)
+        assert torch.allclose(ga, (la + lb) / 2, atol=1e-7) and torch.equal(ga, gb)
+    assert a['in_arena'] == [True, False, True, True]
     assert a['dead_none'] and b['dead_none']
     assert a['shard'] == (0, 5) and b['shard'] == (5, 10)

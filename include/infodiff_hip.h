@@ -75,6 +75,20 @@ int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, 
 int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
                         int Cout, int taps, int mode, int accumulate, void* stream);
 
+/* Batched form of the same kernel: ALL weight gradients of a backward pass in one launch per
+ * (taps, mode) class (the reference computes them one aten::convolution_backward at a time; they are
+ * only read by the optimizer, so the host defers them to the end of backward).  The host fills one
+ * table entry per convolution (idf_wgrad_desc_bytes() bytes each; arguments as idf_conv_wgrad_bf16,
+ * always accumulating: dW / db pre-zeroed), chaining blk0 = sum of the previous blocks_out, copies
+ * the table to device memory and launches it.  target_blocks = grid budget per problem (<= 0:
+ * default 128); lds_bytes = max of the entries' lds_out. */
+int idf_wgrad_desc_bytes(void);
+int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* dy, float* dW, float* db, int B,
+                        int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks, int blk0,
+                        int* blocks_out, int* lds_out);
+int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
+                                void* stream);
+
 /* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
  * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */
 int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fwd, void* w_dgrad, int O, int I,

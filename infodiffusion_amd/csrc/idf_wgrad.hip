@@ -55,7 +55,7 @@ __device__ __forceinline__ bf16x8_t mkfrag(s16x4_t lo, s16x4_t hi) {
 // MODE 0: stride 1; 1: stride 2 (DownSample); 2: nearest-x2-upsampled input (UpSample):
 // only the staging differs -- the LDS tile always holds the pixels the taps address.
 template <int KW, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
+__device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALO = KW / 2;
   constexpr int SX = (MODE == 1) ? 2 : 1;
@@ -66,13 +66,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
   bf16_t* Ds = Xs + (size_t)npix_h * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx = blockIdx.x;
   const int ky = (KW == 3) ? bx % 3 : 0;
   if (KW == 3) bx /= 3;
   const int c0 = (bx % p.c_tiles) * 64, n0 = (bx / p.c_tiles) * 64;
   const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
   const int tiles_per_img = p.H / R;
-  const int t_beg = blockIdx.y * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
+  const int t_beg = by * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
   const int ntaps = KW * KW;
 
   f32x4_t acc[KW][2][2];
@@ -210,14 +209,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
   }
 }
 
-}  // namespace
+template <int KW, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
+  wgrad_block<KW, MODE>(p, blockIdx.x, blockIdx.y);
+}
 
-// taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
-// (3x3 only).  H, W are the OUTPUT (dy) dims.  Returns IDF_ERR_UNSUPPORTED (without touching
-// outputs) for shapes this kernel does not cover; the caller then uses idf_conv2d_wgrad.
-// dW / db are zeroed inside.
-extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
-                                   int Cin, int Cout, int taps, int mode, int accumulate, void* stream) {
+// One launch for many convolutions (all weight gradients of a backward pass, deferred to its end):
+// blocks [blk0, blk0 + gx*gy) of the 1-D grid belong to table entry i.  Small problems no longer pay
+// a launch each nor leave CUs idle, one problem's atomic tail overlaps its neighbours' loads, and each
+// problem can use fewer pixel splits (= fewer atomic bytes) because the others fill the chip.
+struct WgDesc {
+  WgP p;
+  int blk0, gx, gy, pad;
+};
+
+template <int KW, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDesc* __restrict__ tab, int n) {
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (tab[mid].blk0 <= bid) lo = mid; else hi = mid;
+  }
+  const WgDesc* d = tab + lo;
+  const WgP p = d->p;
+  const int local = bid - d->blk0, gx = d->gx;
+  wgrad_block<KW, MODE>(p, local % gx, local / gx);
+}
+
+// Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
+int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
+            int W, int Cin, int Cout, int taps, int mode, int target_blocks) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -226,6 +248,50 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
   if (R > H) R = H;
   if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
+  p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
+  p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
+  p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
+  p.tiles = B * (H / R);
+  p.c_tiles = idf_cdiv(Cin, 64);
+  p.n_tiles = idf_cdiv(Cout, 64);
+  const int kh = taps == 9 ? 3 : 1;
+  gx = p.c_tiles * p.n_tiles * kh;
+  if (target_blocks <= 0) {
+    // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
+    // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
+    // per atomic byte (profiles/r01_wgrad_grid_sweep.txt)
+    static const int forced = getenv("IDF_WGRAD_BLOCKS") ? atoi(getenv("IDF_WGRAD_BLOCKS")) : 0;
+    const long M = (long)B * H * W, cc = (long)Cin * Cout;
+    target_blocks = 512;
+    if (cc <= 64 * 64 || (M <= 32768 && cc <= 128 * 128)) target_blocks = 256;
+    else if (M >= 131072 && cc >= 128 * 128) target_blocks = 768;
+    if (forced > 0) target_blocks = forced;
+  }
+  int split = idf_cdiv(target_blocks, gx);
+  if (split > p.tiles) split = p.tiles;
+  if (split < 1) split = 1;
+  p.tiles_per_blk = idf_cdiv(p.tiles > 0 ? p.tiles : 1, split);
+  gy = idf_cdiv(p.tiles, p.tiles_per_blk);
+  const int sx = mode == 1 ? 2 : 1;
+  lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
+  if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
+  return IDF_OK;
+}
+
+}  // namespace
+
+// taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
+// (3x3 only).  H, W are the OUTPUT (dy) dims.  Returns IDF_ERR_UNSUPPORTED (without touching
+// outputs) for shapes this kernel does not cover; the caller then uses idf_conv2d_wgrad.
+// dW / db are zeroed inside.
+extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
+                                   int Cin, int Cout, int taps, int mode, int accumulate, void* stream) {
+  WgP p;
+  int gx, gy;
+  size_t lds;
+  int rc = wg_plan(p, gx, gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, 0);
+  if (rc != IDF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t nW = (size_t)Cout * taps * Cin;
   hipError_t e = hipSuccess;
@@ -237,37 +303,50 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
   }
   if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: memset failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
-  WgP p;
-  p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
-  p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
-  p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
-  p.tiles = B * (H / R);
-  p.c_tiles = idf_cdiv(Cin, 64);
-  p.n_tiles = idf_cdiv(Cout, 64);
-  const int kh = taps == 9 ? 3 : 1;
-  int gx = p.c_tiles * p.n_tiles * kh;
-  // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
-  // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
-  // per atomic byte (profiles/r01_wgrad_grid_sweep.txt)
-  static const int forced = getenv("IDF_WGRAD_BLOCKS") ? atoi(getenv("IDF_WGRAD_BLOCKS")) : 0;
-  const long M = (long)B * H * W, cc = (long)Cin * Cout;
-  int target_blocks = 512;
-  if (cc <= 64 * 64 || (M <= 32768 && cc <= 128 * 128)) target_blocks = 256;
-  else if (M >= 131072 && cc >= 128 * 128) target_blocks = 768;
-  if (forced > 0) target_blocks = forced;
-  int split = idf_cdiv(target_blocks, gx);
-  if (split > p.tiles) split = p.tiles;
-  p.tiles_per_blk = idf_cdiv(p.tiles, split);
-  split = idf_cdiv(p.tiles, p.tiles_per_blk);
-  const int sx = mode == 1 ? 2 : 1;
-  size_t lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
-  if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
-  dim3 g(gx, split);
-  if (kh == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<1, 0>), g, dim3(256), lds, st, p);
+  dim3 g(gx, gy);
+  if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<1, 0>), g, dim3(256), lds, st, p);
   else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 0>), g, dim3(256), lds, st, p);
   else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 1>), g, dim3(256), lds, st, p);
   else hipLaunchKernelGGL((conv_wgrad_tr_bf16<3, 2>), g, dim3(256), lds, st, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// ---- batched form: host fills a table entry per problem, uploads the table, one launch per
+// (taps, mode) class.  Accumulating only (dW / db pre-zeroed: the gradient arena).
+extern "C" int idf_wgrad_desc_bytes(void) { return (int)sizeof(WgDesc); }
+
+extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* dy, float* dW, float* db,
+                                   int B, int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks,
+                                   int blk0, int* blocks_out, int* lds_out) {
+  if (!host_table || index < 0 || !blocks_out || !lds_out) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: null argument");
+  if (B <= 0) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: empty batch");
+  WgDesc d;
+  memset(&d, 0, sizeof(d));
+  size_t lds;
+  static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
+  if (forced > 0) target_blocks = forced;
+  int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128);
+  if (rc != IDF_OK) return rc;
+  d.blk0 = blk0;
+  memcpy((char*)host_table + (size_t)index * sizeof(WgDesc), &d, sizeof(d));
+  *blocks_out = d.gx * d.gy;
+  *lds_out = (int)lds;
+  return IDF_OK;
+}
+
+extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
+                                           int mode, void* stream) {
+  if (n <= 0 || total_blocks <= 0) return IDF_OK;
+  if (!dev_table || (taps != 9 && taps != 1) || mode < 0 || mode > 2 || (mode && taps != 9))
+    IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16_batched: bad arguments (taps %d mode %d)", taps, mode);
+  hipStream_t st = (hipStream_t)stream;
+  const WgDesc* tab = (const WgDesc*)dev_table;
+  dim3 g(total_blocks);
+  if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n);
+  else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n);
+  else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 1>), g, dim3(256), lds_bytes, st, tab, n);
+  else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -5,7 +5,9 @@ Raw launchers (`*_raw`) take/return torch CUDA tensors whose memory is dense NHW
 current stream; `torch.autograd.Function`s on top provide backward through the
 hand-written gradient kernels.  There is no non-HIP fallback.
 """
+import ctypes
 import functools
+import os
 
 import torch
 
@@ -288,7 +290,63 @@ def _slot_views(w_slot, b_slot, want_bias, shape):
     return w_slot.take(), (b_slot.take() if want_bias else None)
 
 
-def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None):
+class WgradBatch:
+    """Deferred weight gradients.  Only the optimizer reads them, so backward just queues each
+    convolution's (a, dy, arena slots) and ONE launch per (taps, mode) class at the end of the
+    backward pass computes them all (`idf_conv_wgrad_bf16_batched`): no per-conv launch, small
+    problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
+    enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
+    pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode)
+    _bufs = {}         # (taps, mode) -> [pinned host table, device table, key]   (eager: reused)
+    _graph_bufs = []   # tables referenced by captured graphs: never touched again
+
+    @classmethod
+    def add(cls, item):
+        cls.pending.append(item)
+        if len(cls.pending) == 1:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+            except RuntimeError:          # not inside a backward pass: nothing to defer to
+                cls.flush()
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, []
+        groups = {}
+        for it in items:
+            groups.setdefault((it[9], it[10]), []).append(it)
+        lib = _lib.load()
+        nb = lib.idf_wgrad_desc_bytes()
+        capturing = torch.cuda.is_current_stream_capturing()
+        for (taps, mode), grp in groups.items():
+            n = len(grp)
+            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] for it in grp)
+            buf = cls._bufs.get((taps, mode))
+            if buf is None or buf[0].numel() < n * nb:
+                dev = grp[0][0].device
+                buf = [torch.empty((max(n, 16) * nb,), dtype=torch.uint8).pin_memory(),
+                       torch.empty((max(n, 16) * nb,), dtype=torch.uint8, device=dev), None, 0, 0]
+                cls._bufs[(taps, mode)] = buf
+            if capturing:
+                # the captured copy node reads this pinned table at every replay: retire the pair from
+                # eager use (the warm-up step allocated it; later eager steps get a fresh one)
+                cls._graph_bufs.append(cls._bufs.pop((taps, mode)))
+                buf[2] = None
+            if buf[2] != key:
+                host = buf[0].data_ptr()
+                blk, lds = 0, 0
+                nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
+                for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _) in enumerate(grp):
+                    _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(dy), dW, db, B, H, W, Cin, Cout, taps,
+                                                       mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)), 'idf_wgrad_desc_fill')
+                    blk += nblk.value
+                    lds = max(lds, nlds.value)
+                buf[1][:n * nb].copy_(buf[0][:n * nb], non_blocking=True)
+                buf[2], buf[3], buf[4] = key, blk, lds
+            call('idf_conv_wgrad_bf16_batched', _p(buf[1]), n, buf[3], buf[4], taps, mode, _st())
+
+
+def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, defer=False):
     """dW (fp32, logical [O,I,kh,kw], memory [O][taps][I]) and db for a conv whose
     (already activated) input is `a`.  Channel counts that are not multiples of 8
     (image input, epsilon output) are zero-padded so the MFMA kernel covers them.
@@ -303,7 +361,12 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None):
             views = _slot_views(w_slot, b_slot, want_bias, (Cout, Cin, k, k)) if (Cip == Cin and Cop == Cout) else None
             if views is not None:
                 dW, db = views
-                call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 1, _st())
+                if defer and WgradBatch.enabled:
+                    # slot ADDRESSES, not the tensors: AccumulateGrad adopts a gradient only if nobody else holds it
+                    WgradBatch.add((ap, dyp, _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode))
+                else:
+                    call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 1,
+                         _st())
                 return dW, db
             nW = Cop * k * k * Cip
             buf = torch.empty((nW + Cop,), dtype=torch.float32, device=a.device)   # dW | db: one memset
@@ -363,7 +426,10 @@ class _FusedConv(torch.autograd.Function):
         dW = db = dx = dgw = dgb = dft = dfa = dres = None
         want_b = bias is not None and need[2]
         if need[1]:
-            dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b, ctx.slots[0], ctx.slots[1])
+            # deferring is safe only when AccumulateGrad merely adopts the slot views (no kernel reads them
+            # before the end-of-backward launch)
+            defer = weight.is_leaf and weight.grad is None and (bias is None or (bias.is_leaf and bias.grad is None))
+            dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b, ctx.slots[0], ctx.slots[1], defer)
         elif want_b:
             B, Co, Ho, Wo = dy.shape
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))

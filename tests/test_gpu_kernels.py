@@ -283,3 +283,36 @@ def test_gn_one_launch_small(C, H, dtype):
     btol = 3e-4 if dtype == torch.float32 else 4e-2
     for got, want in ((dx, xr.grad), (dgam, gr.grad), (dbet, br.grad), (dft, ftr.grad), (dfa, far.grad)):
         assert rel(got, want) < btol
+
+
+def test_wgrad_bf16_batched_matches_single_launches():
+    """All weight gradients of a backward pass from ONE table-driven launch per (taps, mode) class
+    (idf_conv_wgrad_bf16_batched, accumulating into gradient-arena slots) == the per-conv launches."""
+    from infodiffusion_amd.grad_arena import GradArena, slot_of
+    cases = [(4, 32, 32, 32, 32, 9, ops.S1), (4, 64, 16, 16, 128, 9, ops.S1), (2, 128, 8, 8, 128, 1, ops.S1),
+             (4, 32, 32, 32, 64, 9, ops.S1), (4, 128, 8, 8, 128, 9, ops.S1), (2, 64, 16, 16, 64, 9, ops.S2),
+             (2, 64, 16, 16, 64, 9, ops.UP2), (2, 64, 64, 64, 64, 9, ops.S1)]
+    ws, bs, data, refs = [], [], [], []
+    for i, (B, Cin, H, W, Cout, taps, mode) in enumerate(cases):
+        k = 3 if taps == 9 else 1
+        ws.append(torch.nn.Parameter(torch.zeros(Cout, Cin, k, k, device=DEV).contiguous(memory_format=CL)))
+        bs.append(torch.nn.Parameter(torch.zeros(Cout, device=DEV)))
+        Hs, Ws = (2 * H, 2 * W) if mode == ops.S2 else ((H // 2, W // 2) if mode == ops.UP2 else (H, W))
+        a = rnd(10 + i, B, Cin, Hs, Ws).to(DEV).bfloat16().contiguous(memory_format=CL)
+        dy = rnd(40 + i, B, Cout, H, W).to(DEV).bfloat16().contiguous(memory_format=CL)
+        data.append((a, dy))
+        refs.append(ops.conv_wgrad_bias_raw(a, dy, mode, taps, True))
+    arena = GradArena(ws + bs)
+    assert ops.WgradBatch.enabled and not ops.WgradBatch.pending
+    ops.WgradBatch.pending.append(None)              # hold the queue open as a running backward pass would
+    outs = []
+    for (a, dy), w, b, c in zip(data, ws, bs, cases):
+        outs.append(ops.conv_wgrad_bias_raw(a, dy, c[6], c[5], True, slot_of(w), slot_of(b), True))
+    ops.WgradBatch.pending.pop(0)
+    assert len(ops.WgradBatch.pending) == len(cases)
+    assert all(float(o[0].abs().max()) == 0.0 for o in outs)      # nothing launched yet
+    ops.WgradBatch.flush()
+    assert not ops.WgradBatch.pending
+    for (rW, rb), (oW, ob) in zip(refs, outs):
+        assert arena.holds(oW) and arena.holds(ob)
+        assert rel(oW.cpu(), rW.cpu()) < 1e-5 and rel(ob.cpu(), rb.cpu()) < 1e-5

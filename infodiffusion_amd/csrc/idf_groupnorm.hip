@@ -435,7 +435,8 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x, T* __restrict__ dx,
+__global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x,
+                                                     const T* __restrict__ dres, T* __restrict__ dx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, const float* __restrict__ mean,
@@ -523,6 +524,12 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
+      if (dres) {                 // gradient arriving over the block's residual / shortcut branch
+        float rv[VE];
+        Vec16<T>::load(dres + e0, rv);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] += rv[e];
+      }
       Vec16<T>::store(dx + e0, o);
     }
   }
@@ -699,7 +706,7 @@ extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, co
   return IDF_OK;
 }
 
-extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const float* gamma, const float* beta,
+extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma, const float* beta,
                                 const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                                 const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
                                 float* dgb, float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt,
@@ -716,12 +723,13 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, void* dx, const f
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)dA, (const float*)x, (float*)dx,
+    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)dA, (const float*)x,
+                       (const float*)dres, (float*)dx,
                        gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd,
                        salt, thr, dscale);
   else
     hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
-                       (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb,
+                       (const bf16_t*)dres, (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb,
                        dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;

@@ -308,12 +308,13 @@ class _ResBase(nn.Module):
         if isinstance(self.shortcut, nn.Conv2d):
             self._cfg_sc = _cfg(_Shadows(self.shortcut), ops.S1, 1, _ACT_NONE)
 
-    def _gn_conv(self, name, x, film_t=None, film_a=None, drop_site=None, residual=None):
+    def _gn_conv(self, name, x, film_t=None, film_a=None, drop_site=None, residual=None, passthrough=False):
         blk = getattr(self, name)
         gn, conv = blk[0], blk[-1]
         seed = self.ctx.seed if (drop_site is not None and self.training) else None
         cfg = _cfg(getattr(self, '_sh_' + name), ops.S1, 9, _ACT_SILU, self.p_drop, self.salt + (drop_site or 0))
-        return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed)
+        return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
+                              passthrough)
 
     def _shortcut(self, x):
         if isinstance(self.shortcut, nn.Conv2d):
@@ -335,7 +336,7 @@ class ResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb):
-        h = self._gn_conv('block1', x)
+        h, x = self._gn_conv('block1', x, passthrough=True)    # x: the residual branch's gradient joins in block1
         ft = self._film.pop('t', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
@@ -361,7 +362,7 @@ class AuxResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb, aemb=None):
-        h = self._gn_conv('block1', x)
+        h, x = self._gn_conv('block1', x, passthrough=True)    # x: the residual branch's gradient joins in block1
         ft = self._film.pop('t', None) if self._film else None
         fa = self._film.pop('a', None) if self._film else None
         if ft is None:
@@ -388,7 +389,7 @@ class ResBlock_encoder(_ResBase):
         self._setup(dropout)
 
     def forward(self, x):
-        h = self._gn_conv('block1', x)
+        h, x = self._gn_conv('block1', x, passthrough=True)
         h = self._gn_conv('block2', h, drop_site=1, residual=self._shortcut(x))
         return self.attn(h)
 

@@ -232,7 +232,8 @@ def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act):
     return a, mean, rstd, sc, sh
 
 
-def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None):
+def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None,
+                     dres=None):
     B, C, H, W = x.shape
     dev = x.device
     dx = torch.empty_like(x, memory_format=CL)
@@ -240,7 +241,7 @@ def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, see
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
     acc = _gn_acc(acc)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
-    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
+    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(dres), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
          _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop),
          act, B, H * W, C, _dt(x), _st())
@@ -394,7 +395,8 @@ class _FusedConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None):
+    def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None,
+                passthrough=False):
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
@@ -412,10 +414,14 @@ class _FusedConv(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                               seed)
+        if passthrough:
+            # second output = x itself: whatever gradient the block's residual / shortcut branch sends
+            # back arrives HERE and is added inside the GroupNorm backward kernel (no autograd add pass)
+            return y, x.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxp=None):
         x, a, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
         cfg, p_drop = ctx.cfg, ctx.p_drop
         act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
@@ -437,25 +443,33 @@ class _FusedConv(torch.autograd.Function):
             w_dgrad = cfg['shadows'](x.dtype, True)[1]
             dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
             gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
+            dres_in = _nhwc(dxp.to(x.dtype)) if dxp is not None else None
             if act and gn_small_ok(x):
                 dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                          seed, salt, p_drop, act, gacc)
+                                                          seed, salt, p_drop, act, gacc, dres_in)
             elif act:
-                dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, None, gn_w, gn_b, film_t, film_a, mean, rstd,
+                dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, dres_in, gn_w, gn_b, film_t, film_a, mean, rstd,
                                                          sc, sh, seed, salt, p_drop, act, gacc)
             else:
-                dx = dA
+                dx = dA if dres_in is None else dA + dres_in
+        elif dxp is not None and need[0]:
+            dx = dxp
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None
 
 
-def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None):
+def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None,
+               passthrough=False):
+    """passthrough=True returns (y, x'): x' aliases x, and gradients sent to x' (the residual / shortcut
+    branch of a ResBlock) are added to dx inside this op's GroupNorm backward kernel."""
+    if passthrough and os.environ.get('IDF_PASSTHROUGH', '1') == '0':
+        return fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed), x
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
     slots = None
     if torch.is_grad_enabled():
         slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
-    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots)
+    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, passthrough)
 
 
 # ------------------------------------------------------------------ attention
@@ -517,8 +531,20 @@ class _Linear(torch.autograd.Function):
             call('idf_silu_fwd', _p(x), _p(xs), x.numel(), _st())
         Bn, K = x.shape
         N = w.shape[0]
-        y = torch.empty((Bn, N), dtype=torch.float32, device=x.device)
-        bgemm_raw(xs, 0, w, 0, y, 0, _f32c(bias), 1, 0, 0, 0, K, K, N, Bn, N, K, 0, 0, dtype=F32)
+        # a handful of output tiles over a long contraction (encoder fc_a: 32 x 32 over K = 4096): the K range
+        # is cut into `sk` batch entries whose partial products are summed in a fixed order -- no atomics,
+        # the forward pass stays bit-reproducible
+        tiles = -(-Bn // 64) * -(-N // 64)
+        sk = 32 if (tiles < 8 and K >= 2048 and K % (32 * 64) == 0) else 1
+        if sk > 1:
+            part = torch.empty((sk, Bn * N), dtype=torch.float32, device=x.device)
+            bgemm_raw(xs, 0, w, 0, part, 0, None, sk, K // sk, K // sk, Bn * N, K, K, N, Bn, N, K // sk, 0, 0, dtype=F32)
+            y = colsum_raw(part).view(Bn, N)
+            if bias is not None:
+                y += _f32c(bias)
+        else:
+            y = torch.empty((Bn, N), dtype=torch.float32, device=x.device)
+            bgemm_raw(xs, 0, w, 0, y, 0, _f32c(bias), 1, 0, 0, 0, K, K, N, Bn, N, K, 0, 0, dtype=F32)
         ctx.silu_in = silu_in
         ctx.save_for_backward(x, xs, w)
         return y
@@ -532,12 +558,20 @@ class _Linear(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = dW = db = None
         if need[0]:
-            # few output tiles but a long contraction (batched FiLM: N ~ 5k): split K over blocks
+            # few output tiles but a long contraction (batched FiLM: N ~ 5k): the contraction is cut into `sk`
+            # batch entries and the partial products summed in a fixed order (bit-reproducible, no atomics)
             tiles = -(-Bn // 64) * -(-K // 64)
             sk = max(1, min(32, N // 256)) if tiles < 64 else 1
-            dxs = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
-            bgemm_raw(dy, 0, w, 0, dxs, 0, None, 1, 0, 0, 0, N, K, K, Bn, K, N, 0, 1, out_f32=True, splitk=sk,
-                      dtype=F32)
+            while sk > 1 and N % sk:
+                sk -= 1
+            if sk > 1:
+                part = torch.empty((sk, Bn * K), dtype=torch.float32, device=x.device)
+                bgemm_raw(dy, 0, w, 0, part, 0, None, sk, N // sk, (N // sk) * K, Bn * K, N, K, K, Bn, K, N // sk, 0, 1,
+                          out_f32=True, dtype=F32)
+                dxs = colsum_raw(part).view(Bn, K)
+            else:
+                dxs = torch.empty_like(x)
+                bgemm_raw(dy, 0, w, 0, dxs, 0, None, 1, 0, 0, 0, N, K, K, Bn, K, N, 0, 1, out_f32=True, dtype=F32)
             if ctx.silu_in:
                 dx = torch.empty_like(x)
                 call('idf_silu_bwd', _p(x), _p(dxs), _p(dx), x.numel(), _st())

@@ -283,6 +283,11 @@ def test_gn_one_launch_small(C, H, dtype):
     btol = 3e-4 if dtype == torch.float32 else 4e-2
     for got, want in ((dx, xr.grad), (dgam, gr.grad), (dbet, br.grad), (dft, ftr.grad), (dfa, far.grad)):
         assert rel(got, want) < btol
+    # the residual-branch gradient joins inside the kernel (dx + dres in one pass)
+    dres = rnd(9, *x.shape).to(dtype)
+    dx2 = ops.gn_fused_bwd_raw(dA, xd, g(gam), g(bet), g(ft), g(fa), mean, rstd, sc, sh, None, 0, 0.0, 2,
+                               dres=dres.to(DEV).contiguous(memory_format=CL))[0]
+    assert rel(dx2, xr.grad + dres.float()) < btol
 
 
 def test_wgrad_bf16_batched_matches_single_launches():

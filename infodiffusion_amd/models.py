@@ -11,7 +11,8 @@ from torch.nn import init
 
 from . import ops
 from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
-                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, timestep_embedding)
+                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, film_groups,
+                      timestep_embedding)
 from .utils import compute_mmd, gaussian_mixture, swiss_roll
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
@@ -70,6 +71,10 @@ class _UNetSkeleton(nn.Module):
         self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)
         self._cfg_tail = _cfg(_Shadows(self.tail[-1]), ops.S1, 9, _ACT_SILU)
         self._shadow_set = ShadowSet(self)
+        blocks = self._res_blocks()
+        for which in ('t', 'a'):
+            if blocks and hasattr(blocks[0], 'temb_proj' if which == 't' else 'aemb_proj'):
+                film_groups(blocks, which)      # parameter groups must exist before an optimizer lays out its arena
 
     def _res_blocks(self):
         return [m for m in list(self.downblocks) + list(self.middleblocks) + list(self.upblocks)

@@ -42,16 +42,20 @@ class _Shadows:
         self.convs = convs
         self.key = None
         self.val = [None, None]
+        # several convs applied as one (q, k, v): their weights / biases live adjacently so the
+        # concatenation is a view and its gradient is written once (grad_arena.ParamGroup)
+        self.wgroup = ops.ParamGroup([c.weight for c in convs]) if len(convs) > 1 else None
+        self.bgroup = ops.ParamGroup([c.bias for c in convs]) if len(convs) > 1 else None
 
     def weight(self):
         if len(self.convs) == 1:
             return self.convs[0].weight
-        return torch.cat([c.weight for c in self.convs], dim=0)
+        return ops.cat_params(self.wgroup)
 
     def bias(self):
         if len(self.convs) == 1:
             return self.convs[0].bias
-        return torch.cat([c.bias for c in self.convs], dim=0)
+        return ops.cat_params(self.bgroup)
 
     def current_key(self, dtype):
         return tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
@@ -402,14 +406,25 @@ def bind_context(net, ctx):
             m.salt = 4 * i
 
 
+def film_groups(blocks, which):
+    """(weight group, bias group) of every block's FiLM projection: adjacent storage, so the batched
+    GEMM reads the concatenated weights as a view.  Built once (the network's _post), kept on block 0."""
+    name = 'temb_proj' if which == 't' else 'aemb_proj'
+    groups = getattr(blocks[0], '_film_groups_' + which, None)
+    if groups is None:
+        lins = [getattr(b, name)[1] for b in blocks]
+        groups = (ops.ParamGroup([l.weight for l in lins]), ops.ParamGroup([l.bias for l in lins]))
+        setattr(blocks[0], '_film_groups_' + which, groups)
+    return groups
+
+
 def batched_film(blocks, emb, which):
     """All blocks' FiLM projections Linear(SiLU(emb)) (modules.py:269-276, 312, 316) as ONE
     GEMM over the concatenated weights; each block then reads its [B, 2C] column slice in
     place (row stride = total width).  `which`: 't' (temb_proj) or 'a' (aemb_proj)."""
     name = 'temb_proj' if which == 't' else 'aemb_proj'
     lins = [getattr(b, name)[1] for b in blocks]
-    W = torch.cat([l.weight for l in lins], dim=0)
-    bias = torch.cat([l.bias for l in lins], dim=0)
-    out = ops.linear(emb, W, bias, silu_in=True)
+    groups = film_groups(blocks, which)
+    out = ops.linear(emb, ops.cat_params(groups[0]), ops.cat_params(groups[1]), silu_in=True)
     for blk, chunk in zip(blocks, out.split([l.weight.shape[0] for l in lins], dim=1)):
         blk._film[which] = chunk

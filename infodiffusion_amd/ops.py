@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import call, F32, BF16
-from .grad_arena import slot_of
+from .grad_arena import slot_of, ParamGroup
 
 GN_EPS = 1e-5
 S1, S2, UP2, T2 = 0, 1, 2, 3
@@ -148,12 +148,13 @@ def conv_wgrad_raw(x, dy, sc, sh, seed, salt, p_drop, mode, taps, act):
     return dW.permute(0, 3, 1, 2)
 
 
-def colsum_raw(t2d):
-    """fp32 column sums of a [R, N] view (fp32 or bf16, dense)."""
+def colsum_raw(t2d, out=None):
+    """fp32 column sums of a [R, N] view (fp32 or bf16, dense); `out`: a dense fp32 [N] destination."""
     R, N = t2d.shape
     nb = _lib.load().idf_colsum_blocks(R)
     ws = torch.empty((nb * N,), dtype=torch.float32, device=t2d.device)
-    out = torch.empty((N,), dtype=torch.float32, device=t2d.device)
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=t2d.device)
     call('idf_colsum', _p(t2d), _p(out), _p(ws), R, N, _dt(t2d), _st())
     return out
 
@@ -384,6 +385,18 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, 
     return dW, db
 
 
+def _grad_free(slot):
+    """No gradient accumulated yet on the slot's parameter (on every member of a parameter group)."""
+    if slot is None:
+        return False
+    members = getattr(slot, 'slots', None) or [slot]
+    for m in members:
+        p = m.ref()
+        if p is None or p.grad is not None:
+            return False
+    return True
+
+
 class _FusedConv(torch.autograd.Function):
     """y = conv(act(GN/FiLM(x))) + bias (+ residual);  act per `cfg`.
 
@@ -434,7 +447,7 @@ class _FusedConv(torch.autograd.Function):
         if need[1]:
             # deferring is safe only when AccumulateGrad merely adopts the slot views (no kernel reads them
             # before the end-of-backward launch)
-            defer = weight.is_leaf and weight.grad is None and (bias is None or (bias.is_leaf and bias.grad is None))
+            defer = _grad_free(ctx.slots[0]) and (bias is None or _grad_free(ctx.slots[1]))
             dW, db = conv_wgrad_bias_raw(a, dy, mode, taps, want_b, ctx.slots[0], ctx.slots[1], defer)
         elif want_b:
             B, Co, Ho, Wo = dy.shape
@@ -515,12 +528,45 @@ def attention(qkv):
     return _Attention.apply(qkv)
 
 
+# ------------------------------------------------- concatenated parameter views
+class _CatParams(torch.autograd.Function):
+    """cat(params, dim 0) for a ParamGroup whose storage is adjacent: the forward is a view, the
+    backward hands each parameter its arena slot when the consumer wrote the gradient of the
+    concatenation straight into the group's arena region (else plain row slices)."""
+
+    @staticmethod
+    def forward(ctx, group, *params):
+        ctx.group = group
+        return group.cat()
+
+    @staticmethod
+    def backward(ctx, dcat):
+        grp = ctx.group
+        slots = [slot_of(q) for q in grp.params]
+        if all(s is not None for s in slots):
+            from .grad_arena import _GroupSlot
+            parts = _GroupSlot(grp, slots).split(dcat)
+            if parts is not None:
+                return (None,) + tuple(parts)
+        return (None,) + tuple(dcat.split(grp.rows, dim=0))
+
+
+def cat_params(group):
+    """The concatenation of a ParamGroup's parameters as an autograd-tracked view."""
+    group.ensure()
+    if not (torch.is_grad_enabled() and any(p.requires_grad for p in group.params)):
+        return group.cat()
+    out = _CatParams.apply(group, *group.params)
+    out._idf_cat_group = group
+    return out
+
+
 # --------------------------------------------------------------------- linear
 class _Linear(torch.autograd.Function):
     """y = silu?(x) @ W^T + b, fp32 [B, K] -> [B, N]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, silu_in):
+    def forward(ctx, x, weight, bias, silu_in, slots=None):
         x = _f32c(x)
         if not x.is_cuda:
             raise RuntimeError('infodiffusion_amd kernels run on the GPU only')
@@ -545,7 +591,7 @@ class _Linear(torch.autograd.Function):
         else:
             y = torch.empty((Bn, N), dtype=torch.float32, device=x.device)
             bgemm_raw(xs, 0, w, 0, y, 0, _f32c(bias), 1, 0, 0, 0, K, K, N, Bn, N, K, 0, 0, dtype=F32)
-        ctx.silu_in = silu_in
+        ctx.silu_in, ctx.slots = silu_in, slots or (None, None)
         ctx.save_for_backward(x, xs, w)
         return y
 
@@ -577,16 +623,23 @@ class _Linear(torch.autograd.Function):
                 call('idf_silu_bwd', _p(x), _p(dxs), _p(dx), x.numel(), _st())
             else:
                 dx = dxs
+        ws, bs = ctx.slots
         if need[1]:
-            dW = torch.empty_like(w)
+            # straight into the parameter's (or the parameter group's) gradient-arena slot when it is free
+            if ws is not None and ws.available() and tuple(ws.view.shape) == tuple(w.shape) and ws.view.is_contiguous():
+                dW = ws.take()
+            else:
+                dW = torch.empty_like(w)
             bgemm_raw(dy, 0, xs, 0, dW, 0, None, 1, 0, 0, 0, N, K, K, N, K, Bn, 1, 1, dtype=F32)
         if need[2]:
-            db = colsum_raw(dy)
-        return dx, dW, db, None
+            dbv = bs.take() if (bs is not None and bs.available() and tuple(bs.view.shape) == (N,)) else None
+            db = colsum_raw(dy, out=dbv)
+        return dx, dW, db, None, None
 
 
 def linear(x, weight, bias=None, silu_in=False):
-    return _Linear.apply(x, weight, bias, silu_in)
+    slots = (slot_of(weight), slot_of(bias)) if torch.is_grad_enabled() else None
+    return _Linear.apply(x, weight, bias, silu_in, slots)
 
 
 # --------------------------------------------------------- gather / q_sample

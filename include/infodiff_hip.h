@@ -151,6 +151,16 @@ int idf_bgemm(const void* A, const void* B, void* C, const float* bias, const vo
 int idf_softmax_fwd(void* s, long R, int N, int dtype, void* stream);            /* modules.py:156 */
 int idf_softmax_bwd(const void* P, void* dP, long R, int N, int dtype, void* stream);
 
+/* Fused single-head attention of the AttnBlock (modules.py:129-164: bmm, softmax, bmm and their
+ * backward) for the shapes idf_attn_fused_ok() accepts (N = 256 tokens, D = C in {64, 128}, bf16):
+ * qkv [B, N, 3D] (q | k | v along channels), o [B, N, D], lse [B, N] row logsumexp kept for the
+ * backward, dsum [B, N] scratch (row sums of P dP), dqkv [B, N, 3D].  scale = C^-1/2.
+ * Scores / probabilities stay in registers; other shapes use idf_bgemm + idf_softmax_*. */
+int idf_attn_fused_ok(int N, int D, int dtype);
+int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int D, float scale, int dtype, void* stream);
+int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int N, int D,
+                 float scale, int dtype, void* stream);
+
 /* ---- elementwise / reductions */
 /* q_sample, models.py:702-704: xt = sqrt_ab[idx[b]]*x + sqrt_1mab[idx[b]]*eps; the two [T] tables
  * hold sqrt(alpha_bar), sqrt(1-alpha_bar) (host torch CPU ops => bit-exact gathers and fp32 result) */

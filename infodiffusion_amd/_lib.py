@@ -36,6 +36,9 @@ SIGNATURES = {
     'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
     'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),
     'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),
+    'idf_attn_fused_ok': ([_i, _i, _i], C.c_int),
+    'idf_attn_fwd': ([_p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
+    'idf_attn_bwd': ([_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
     'idf_qsample': ([_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p], C.c_int),
     'idf_gather_rows': ([_p, _p, _p, _i, _i, _p], C.c_int),
     'idf_silu_fwd': ([_p, _p, _l, _p], C.c_int),

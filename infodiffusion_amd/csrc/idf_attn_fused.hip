@@ -1,0 +1,320 @@
+// Fused single-head spatial self-attention (modules.py:129-164 of the reference AttnBlock) for the
+// N = 256-token level (16x16), head dim D = C in {64, 128}, bf16 activations:
+//   forward   O = softmax(Q K^T * scale) V            one launch  (was bmm, softmax, bmm)
+//   backward  dQ, dK, dV                              two launches (was 4 bmm + softmax backward)
+// qkv is the [B, N, 3D] output of the fused q/k/v 1x1 conv (token-major, q | k | v along channels).
+//
+// One block = 64 "row" tokens (16 per wave) against ALL 256 "column" tokens, whose two [256][D]
+// operands sit in LDS for the whole kernel.  The score products take the LDS operand K-contiguous
+// (ds_read_b128) and the row operand from registers; the MFMA result leaves each lane holding, for
+// ONE row token (lane & 15), 64 of its 256 scores -- the other 192 are in the three lanes 16 / 32 /
+// 48 apart, so a row softmax is a register reduction plus two shuffles, and the probabilities are
+// ALREADY laid out as the B operand of the second product (k slot (g, j) = column 32s + 4g + j /
+// 32s + 16 + 4g + j - 4), whose A operand comes from the same LDS tile through the gfx950
+// transposed read ds_read_b64_tr_b16.  Scores, probabilities and dS never touch memory.
+//
+//   fwd   : LDS = K, V       rows = queries   P = softmax(S)            O  = P V      (+ row logsumexp)
+//   bwd-A : LDS = K, V       rows = queries   dS = P o (dP - sum P dP)  dQ = dS K     (+ row sum P dP)
+//   bwd-B : LDS = Q, dO      rows = keys      P^T, dS^T from the saved row statistics
+//                                             dV = P^T dO, dK = dS^T Q
+#include "idf_common.h"
+
+namespace {
+
+constexpr int AN = 256;      // tokens
+constexpr int ANT = 256;     // threads: 4 waves x 16 rows
+
+template <int D> struct ACfg {
+  static constexpr int PITCH = D + 16;          // elements; (2D + 32) bytes: tr reads conflict-free
+  static constexpr int KS = D / 32;             // k-steps of a score product
+  static constexpr int CT = D / 16;             // channel tiles of an output product
+  static constexpr size_t LDS = (size_t)2 * AN * PITCH * sizeof(bf16_t) + 2 * AN * sizeof(float);
+};
+
+__device__ __forceinline__ s16x4_t atr_read(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+__device__ __forceinline__ bf16x8_t amk(s16x4_t lo, s16x4_t hi) {
+  union { struct { s16x4_t a, b; } s; bf16x8_t v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// [256][D] rows of `src` (row pitch ld elements) -> LDS, pitch ACfg<D>::PITCH
+template <int D>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int ld, bf16_t* lds, int tid) {
+  constexpr int VPR = D / 8, NV = AN * VPR / ANT;
+  uint4 r[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int idx = tid + k * ANT, row = idx / VPR, v = idx - row * VPR;
+    r[k] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + v * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    int idx = tid + k * ANT, row = idx / VPR, v = idx - row * VPR;
+    *reinterpret_cast<uint4*>(lds + row * ACfg<D>::PITCH + v * 8) = r[k];
+  }
+}
+
+// this lane's row operand: row (lane & 15) of `rows`, 8 channels (lane >> 4) * 8 of every k-step
+template <int D>
+__device__ __forceinline__ void load_rowfrag(const bf16_t* __restrict__ rows, int ld, int lane, bf16x8_t (&f)[ACfg<D>::KS]) {
+  const bf16_t* p = rows + (size_t)(lane & 15) * ld + (lane >> 4) * 8;
+#pragma unroll
+  for (int s = 0; s < ACfg<D>::KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + s * 32);
+}
+
+// acc[t][r] = <X[16 t + 4 (lane >> 4) + r], row (lane & 15)>
+template <int D>
+__device__ __forceinline__ void scores(f32x4_t (&acc)[16], const bf16_t* X, const bf16x8_t (&f)[ACfg<D>::KS], int lane) {
+  const bf16_t* xb = X + (lane & 15) * ACfg<D>::PITCH + (lane >> 4) * 8;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < ACfg<D>::KS; ++s) {
+      bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xb + t * 16 * ACfg<D>::PITCH + s * 32);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, f[s], acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// 64 fp32 weights per lane (as `scores` lays them out) -> the 8 B-operand fragments of `outprod`
+__device__ __forceinline__ void pack_w(const f32x4_t (&w)[16], bf16x8_t (&pk)[8]) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bf16x8_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = (__bf16)w[2 * s][r]; v[4 + r] = (__bf16)w[2 * s + 1][r]; }
+    pk[s] = v;
+  }
+}
+
+// out[c][r] = sum over the 256 LDS rows j of w[j] * X[j][16 c + 4 (lane >> 4) + r]   (for row lane & 15)
+template <int D>
+__device__ __forceinline__ void outprod(f32x4_t (&out)[ACfg<D>::CT], const bf16_t* X, const bf16x8_t (&pk)[8], int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int c = 0; c < ACfg<D>::CT; ++c) out[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const bf16_t* x0 = X + (32 * s + 4 * g + q) * ACfg<D>::PITCH + 4 * pp;
+    const bf16_t* x1 = x0 + 16 * ACfg<D>::PITCH;
+#pragma unroll
+    for (int c = 0; c < ACfg<D>::CT; ++c) {
+      bf16x8_t a = amk(atr_read(x0 + c * 16), atr_read(x1 + c * 16));
+      out[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pk[s], out[c], 0, 0, 0);
+    }
+  }
+}
+
+// row (lane & 15) of dst gets channels 16 c + 4 (lane >> 4) + r
+template <int D>
+__device__ __forceinline__ void store_out(bf16_t* __restrict__ dst, int ld, const f32x4_t (&out)[ACfg<D>::CT], int lane,
+                                          float alpha) {
+  bf16_t* p = dst + (size_t)(lane & 15) * ld + (lane >> 4) * 4;
+#pragma unroll
+  for (int c = 0; c < ACfg<D>::CT; ++c) {
+    uint32_t lo = (uint32_t)f32_to_bf16(out[c][0] * alpha) | ((uint32_t)f32_to_bf16(out[c][1] * alpha) << 16);
+    uint32_t hi = (uint32_t)f32_to_bf16(out[c][2] * alpha) | ((uint32_t)f32_to_bf16(out[c][3] * alpha) << 16);
+    *reinterpret_cast<uint2*>(p + c * 16) = make_uint2(lo, hi);
+  }
+}
+
+__device__ __forceinline__ float quad_max(float v) {   // over the 4 lanes that share lane & 15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                       float* __restrict__ lse, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vs = Ks + AN * ACfg<D>::PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
+  const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
+  stage_rows<D>(base + D, 3 * D, Ks, tid);
+  stage_rows<D>(base + 2 * D, 3 * D, Vs, tid);
+  bf16x8_t qf[ACfg<D>::KS];
+  load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
+  __syncthreads();
+  f32x4_t s[16];
+  scores<D>(s, Ks, qf, lane);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[t][r] *= scale; mx = fmaxf(mx, s[t][r]); }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); sum += s[t][r]; }
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[t][r] *= inv;
+  bf16x8_t pk[8];
+  pack_w(s, pk);
+  f32x4_t out[ACfg<D>::CT];
+  outprod<D>(out, Vs, pk, lane);
+  store_out<D>(o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
+  if (lse && lane < 16) lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
+}
+
+// ------------------------------------------------- backward A: dQ and the row sums  sum_j P dP
+template <int D>
+__global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dsum, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vs = Ks + AN * ACfg<D>::PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
+  const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
+  stage_rows<D>(base + D, 3 * D, Ks, tid);
+  stage_rows<D>(base + 2 * D, 3 * D, Vs, tid);
+  bf16x8_t qf[ACfg<D>::KS], gf[ACfg<D>::KS];
+  load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
+  load_rowfrag<D>(dO + ((size_t)b * AN + r0) * D, D, lane, gf);
+  __syncthreads();
+  f32x4_t p[16], dp[16];
+  scores<D>(p, Ks, qf, lane);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[t][r] *= scale; mx = fmaxf(mx, p[t][r]); }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[t][r] = __expf(p[t][r] - mx); sum += p[t][r]; }
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+  scores<D>(dp, Vs, gf, lane);
+  float dot = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[t][r] *= inv; dot += p[t][r] * dp[t][r]; }
+  dot = quad_sum(dot);
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[t][r] = p[t][r] * (dp[t][r] - dot);
+  bf16x8_t pk[8];
+  pack_w(p, pk);
+  f32x4_t out[ACfg<D>::CT];
+  outprod<D>(out, Ks, pk, lane);
+  store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D, 3 * D, out, lane, scale);
+  if (lane < 16) dsum[(size_t)b * AN + r0 + lane] = dot;
+}
+
+// ------------------------------------------------- backward B: dK and dV (rows = keys)
+template <int D>
+__global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                          bf16_t* __restrict__ dqkv, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Gs = Qs + AN * ACfg<D>::PITCH;
+  float* Ls = reinterpret_cast<float*>(Gs + AN * ACfg<D>::PITCH);   // [256] row logsumexp
+  float* Ds = Ls + AN;                                               // [256] row sum P dP
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
+  const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
+  stage_rows<D>(base, 3 * D, Qs, tid);
+  stage_rows<D>(dO + (size_t)b * AN * D, D, Gs, tid);
+  Ls[tid] = lse[(size_t)b * AN + tid];
+  Ds[tid] = dsum[(size_t)b * AN + tid];
+  bf16x8_t kf[ACfg<D>::KS], vf[ACfg<D>::KS];
+  load_rowfrag<D>(base + (size_t)r0 * 3 * D + D, 3 * D, lane, kf);
+  load_rowfrag<D>(base + (size_t)r0 * 3 * D + 2 * D, 3 * D, lane, vf);
+  __syncthreads();
+  const int g4 = (lane >> 4) * 4;
+  f32x4_t p[16], dp[16];
+  scores<D>(p, Qs, kf, lane);            // p[t][r]: query 16 t + g4 + r  x  key (lane & 15)
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[t][r] = __expf(p[t][r] * scale - Ls[16 * t + g4 + r]);
+  bf16x8_t pk[8];
+  f32x4_t out[ACfg<D>::CT];
+  pack_w(p, pk);
+  outprod<D>(out, Gs, pk, lane);         // dV = P^T dO
+  store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + 2 * D, 3 * D, out, lane, 1.0f);
+  scores<D>(dp, Gs, vf, lane);           // dP^T
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[t][r] = p[t][r] * (dp[t][r] - Ds[16 * t + g4 + r]);
+  pack_w(p, pk);
+  outprod<D>(out, Qs, pk, lane);         // dK = dS^T Q
+  store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + D, 3 * D, out, lane, scale);
+}
+
+template <int D>
+int set_lds(const void* k) {
+  return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACfg<D>::LDS);
+}
+
+}  // namespace
+
+extern "C" int idf_attn_fused_ok(int N, int D, int dtype) { return (N == AN && (D == 64 || D == 128) && dtype == IDF_BF16) ? 1 : 0; }
+
+extern "C" int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int D, float scale, int dtype,
+                            void* stream) {
+  if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
+  if (B == 0) return IDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(AN / 64, B);
+  if (D == 128) {
+    set_lds<128>((const void*)attn_fwd_kernel<128>);
+    hipLaunchKernelGGL(attn_fwd_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (bf16_t*)o, lse, scale);
+  } else {
+    set_lds<64>((const void*)attn_fwd_kernel<64>);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (bf16_t*)o, lse, scale);
+  }
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+extern "C" int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int N,
+                            int D, float scale, int dtype, void* stream) {
+  if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_bwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
+  if (B == 0) return IDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(AN / 64, B);
+  if (D == 128) {
+    set_lds<128>((const void*)attn_bwd_q_kernel<128>);
+    set_lds<128>((const void*)attn_bwd_kv_kernel<128>);
+    hipLaunchKernelGGL(attn_bwd_q_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       (bf16_t*)dqkv, dsum, scale);
+    IDF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       lse, dsum, (bf16_t*)dqkv, scale);
+  } else {
+    set_lds<64>((const void*)attn_bwd_q_kernel<64>);
+    set_lds<64>((const void*)attn_bwd_kv_kernel<64>);
+    hipLaunchKernelGGL(attn_bwd_q_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       (bf16_t*)dqkv, dsum, scale);
+    IDF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       lse, dsum, (bf16_t*)dqkv, scale);
+  }
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

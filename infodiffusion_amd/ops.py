@@ -495,6 +495,13 @@ class _Attention(torch.autograd.Function):
         B, C3, H, W = qkv.shape
         C, N = C3 // 3, H * W
         dev, dt = qkv.device, qkv.dtype
+        ctx.fused = bool(_lib.load().idf_attn_fused_ok(N, C, _dt(qkv)))
+        if ctx.fused:       # one launch, scores and probabilities never leave the registers
+            o = empty_nhwc(B, C, H, W, dt, dev)
+            lse = torch.empty((B, N), dtype=torch.float32, device=dev)
+            call('idf_attn_fwd', _p(qkv), _p(o), _p(lse), B, N, C, float(int(C) ** (-0.5)), _dt(qkv), _st())
+            ctx.save_for_backward(qkv, lse)
+            return o
         S = torch.empty((B, N, N), dtype=dt, device=dev)
         bgemm_raw(qkv, 0, qkv, C, S, 0, None, B, N * C3, N * C3, N * N, C3, C3, N, N, N, C, 0, 0,
                   alpha=float(int(C) ** (-0.5)))
@@ -512,6 +519,10 @@ class _Attention(torch.autograd.Function):
         do = _nhwc(do.to(qkv.dtype))
         scale = float(int(C) ** (-0.5))
         dqkv = torch.empty_like(qkv, memory_format=CL)
+        if ctx.fused:
+            dsum = torch.empty_like(P)       # P is the saved row logsumexp here
+            call('idf_attn_bwd', _p(qkv), _p(do), _p(P), _p(dsum), _p(dqkv), B, N, C, scale, _dt(qkv), _st())
+            return dqkv
         # dV = P^T dO
         bgemm_raw(P, 0, do, 0, dqkv, 2 * C, None, B, N * N, N * C, N * C3, N, C, C3, N, C, N, 1, 1)
         # dP = dO V^T

@@ -59,6 +59,12 @@ int idf_conv2d_fwd(const void* x, const void* w, const float* bias, const void* 
  * not cover (Cin % 32, W not a power of two in 4..128): use idf_conv2d_fwd then. */
 int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B, int H,
                      int W, int Cin, int Cout, int mode, void* stream);
+/* 1x1 stride-1 convolution (AttnBlock q/k/v and proj, modules.py:136-139; ResBlock shortcuts, modules.py:228,
+ * and their data gradients) through the same pipeline without the halo: w [Cout][Cin] bf16, optional
+ * fp32 bias and bf16 residual.  IDF_ERR_UNSUPPORTED outside Cin % 32 == 0, Cout % 8 == 0, W a power
+ * of two in 4..128 (use idf_bgemm then). */
+int idf_conv1x1_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B, int H, int W,
+                     int Cin, int Cout, void* stream);
 
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */

@@ -36,18 +36,21 @@ __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1
 
 // NWM = waves along the pixel axis (2 -> 256 threads; 4 -> 512 threads: a 256-pixel tile shares one
 // weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
-template <int MODE, int TM, int BN, int NWM>
+// KS = 3 (3x3, pad 1) or 1 (1x1: the same pipeline without the halo -- the AttnBlock q/k/v and proj
+// convs, ResBlock shortcuts and their data gradients; MODE 0 only).
+template <int MODE, int TM, int BN, int NWM, int KS = 3>
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
-  constexpr int WV = (BN * 36 + NT - 1) / NT; // weight vectors per thread per chunk
+  constexpr int TAPS = KS * KS, HALO = KS / 2;
+  constexpr int WV = (BN * TAPS * 4 + NT - 1) / NT; // weight vectors per thread per chunk
   constexpr int BM = NWM * TM * 16;           // pixels per block
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int W = p.W, R = p.R, WH = W + 2;
-  const int npix_h = (R + 2) * WH;
+  const int W = p.W, R = p.R, WH = W + 2 * HALO;
+  const int npix_h = (R + 2 * HALO) * WH;
   const int KT = R * W;                       // valid pixels of the tile (<= BM)
   unsigned char* Xs = smem;                   // [npix_h][64 B]
-  unsigned char* Ws = smem + (size_t)npix_h * 64;   // [9][BN][64 B]
+  unsigned char* Ws = smem + (size_t)npix_h * 64;   // [TAPS][BN][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     if (idx < npix_h * 4) {
       int pix = idx >> 2, ch = idx & 3;
       int hy = pix / WH, hx = pix - hy * WH;
-      int iy = oy0 + hy - 1, ix = hx - 1;
+      int iy = oy0 + hy - HALO, ix = hx - HALO;
       bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
       if (MODE != 0) { iy >>= 1; ix >>= 1; }
@@ -102,12 +105,12 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   }
 #pragma unroll
   for (int k = 0; k < WV; ++k) {
-    int idx = tid + k * NT;             // over [BN][9][4]
+    int idx = tid + k * NT;             // over [BN][TAPS][4]
     int ch = idx & 3, r = idx >> 2;
-    int tap = r % 9, n = r / 9;
+    int tap = r % TAPS, n = r / TAPS;
     woff[k] = -1; wlds[k] = -1;
-    if (idx < BN * 36) {
-      if (n0 + n < p.Cout) woff[k] = ((long)(n0 + n) * 9 + tap) * p.Cin + ch * 8;
+    if (idx < BN * TAPS * 4) {
+      if (n0 + n < p.Cout) woff[k] = ((long)(n0 + n) * TAPS + tap) * p.Cin + ch * 8;
       wlds[k] = (tap * BN + n) * 64 + swz(n, ch) * 16;
     }
   }
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     __syncthreads();
     if (ck + 1 < nchunks) load_chunk(ck + 1);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = (tap / 3) * WH + (tap % 3);
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int toff = (tap / KS) * WH + (tap % KS);
       bf16x8_t wf[TN], xf[TM];
 #pragma unroll
       for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Ws + tap * BN * 64 + wbase[a]);
@@ -218,12 +221,12 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   }
 }
 
-template <int MODE, int TM, int BN, int NWM = 2>
+template <int MODE, int TM, int BN, int NWM = 2, int KS = 3>
 void launch(const C3P& p, hipStream_t st) {
-  size_t lds = ((size_t)(p.R + 2) * (p.W + 2) + 9 * BN) * 64;
+  size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
   size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
-  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM>;
+  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS>;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
@@ -276,6 +279,39 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   else if (mode == 2) IDF_C3_LAUNCH(2);
   else IDF_C3_LAUNCH(3);
 #undef IDF_C3_LAUNCH
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// 1x1 convolution (stride 1) forward / data gradient through the same pipeline (KS = 1): w [Cout][Cin].
+// IDF_ERR_UNSUPPORTED for shapes it does not cover (the caller then uses idf_bgemm).
+extern "C" int idf_conv1x1_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
+                                int H, int W, int Cin, int Cout, void* stream) {
+  if ((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (B == 0) return IDF_OK;
+  C3P p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Hs = H; p.Ws = W;
+  int ws = 0;
+  while ((1 << ws) < W) ++ws;
+  p.wshift = ws;
+  const long M = (long)B * H * W;
+  const int nt = idf_cdiv(Cout, 64);
+  int BM = 64;
+  if ((M / 128) * nt >= 256 && H * W >= 128) BM = 128;
+  if ((M / 256) * nt >= 256 && H * W >= 256) BM = 256;
+  int R = BM / W;
+  if (R < 1) R = 1;
+  if (R > H) R = H;
+  while (H % R) --R;
+  if (R * W * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tile too large (R%d W%d)", R, W);
+  p.R = R; p.tiles_per_img = H / R; p.n_tiles = nt;
+  hipStream_t st = (hipStream_t)stream;
+  if (BM == 256) launch<0, 4, 64, 4, 1>(p, st);
+  else if (BM == 128) launch<0, 4, 64, 2, 1>(p, st);
+  else launch<0, 2, 64, 2, 1>(p, st);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
 // problem can use fewer pixel splits (= fewer atomic bytes) because the others fill the chip.
 struct WgDesc {
   WgP p;
-  int blk0, gx, gy, pad;
+  int blk0, gx, gy, xcd;   // xcd = 1: blocks [blk0, blk0 + gx * roundup8(gy)) in XCD-major order
 };
 
 template <int KW, int MODE>
@@ -234,7 +234,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
   const WgDesc* d = tab + lo;
   const WgP p = d->p;
   const int local = bid - d->blk0, gx = d->gx;
-  wgrad_block<KW, MODE>(p, local % gx, local / gx);
+  if (d->xcd) {
+    // workgroups go round-robin over the 8 XCDs: give XCD x the pixel splits x, x + 8, ... and ALL the
+    // (kernel row, cout tile, cin tile) blocks of each, so the gx blocks that read the same a / dy tiles
+    // share one L2 instead of fetching them over the fabric gx times
+    const int x = local & 7, j = local >> 3;
+    const int by = x + 8 * (j / gx);
+    if (by >= d->gy) return;
+    wgrad_block<KW, MODE>(p, j % gx, by);
+  } else {
+    if (local >= gx * d->gy) return;      // alignment padding
+    wgrad_block<KW, MODE>(p, local % gx, local / gx);
+  }
 }
 
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
@@ -329,8 +340,11 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
+  static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;
+  d.xcd = (xcd && (blk0 % 8) == 0 && d.gy >= 8) ? 1 : 0;
   memcpy((char*)host_table + (size_t)index * sizeof(WgDesc), &d, sizeof(d));
-  *blocks_out = d.gx * d.gy;
+  *blocks_out = d.xcd ? d.gx * ((d.gy + 7) / 8 * 8) : d.gx * d.gy;
+  if (!d.xcd && (*blocks_out % 8)) *blocks_out += 8 - *blocks_out % 8;     // keep later entries 8-aligned
   *lds_out = (int)lds;
   return IDF_OK;
 }

@@ -105,11 +105,19 @@ def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
             and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _halo_fits(Ho, Wo, B, Cout))
 
 
+_CONV1X1 = os.environ.get('IDF_CONV1X1', '1') != '0'
+
+
 def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
     """x logical [B,Cin,Hs,Ws] NHWC-dense; w_fwd [Cout][taps][Cin] in x.dtype."""
     B, Cin, Hs, Ws = x.shape
     Ho, Wo = out_hw_ if out_hw_ is not None else out_hw(mode, Hs, Ws)
     y = empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+    if (taps == 1 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin % 32 == 0 and Cout % 8 == 0
+            and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _CONV1X1):
+        # 1x1 conv through the halo-conv pipeline without the halo (LDS-swizzled tiles, full-line epilogue)
+        call('idf_conv1x1_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout, _st())
+        return y
     if taps == 1 and mode == S1 and act == 0 and Cin % 8 == 0 and Cout % 4 == 0:
         # 1x1 conv = [pixels, Cin] x [Cout, Cin]^T (+bias, +residual): the short-K GEMM
         M = B * Ho * Wo

@@ -33,6 +33,9 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
     (2, 64, 16, 16, 64, 9, ops.S2), (2, 64, 8, 8, 64, 9, ops.UP2), (2, 128, 8, 8, 384, 1, ops.S1),
     (2, 3, 16, 16, 64, 9, ops.S1), (2, 64, 16, 16, 3, 9, ops.S1), (2, 1, 32, 32, 32, 9, ops.S1),
     (2, 32, 8, 8, 1, 9, ops.S1), (5, 96, 4, 4, 32, 9, ops.S1), (2, 256, 32, 32, 128, 9, ops.S1),
+    # 1x1 through the halo pipeline (bf16): 64 / 128 / 256-pixel tiles, ragged cout tile, tiny images
+    (3, 128, 16, 16, 128, 1, ops.S1), (33, 64, 64, 64, 128, 1, ops.S1), (5, 192, 32, 32, 64, 1, ops.S1),
+    (2, 64, 4, 4, 72, 1, ops.S1), (40, 128, 16, 16, 384, 1, ops.S1),
 ])
 def test_conv_fwd_dgrad_wgrad(case, dtype):
     B, Cin, H, W, Cout, taps, mode = case

@@ -434,7 +434,10 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
   }
 }
 
-template <typename T>
+// KEEP > 0: at most KEEP vectors per thread and du = dA * act'(...) stays in registers between the two
+// phases (no second read of dA, no second sigmoid / dropout-hash evaluation); KEEP = 0: up to SNV
+// vectors per thread, du recomputed in the apply phase (register budget of a 1024-thread block).
+template <typename T, int KEEP>
 __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -460,9 +463,11 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     scv[e] = sc[(size_t)b * C + c0 + v * VE + e]; shv[e] = sh[(size_t)b * C + c0 + v * VE + e];
     s1[e] = s2[e] = 0.f;
   }
-  uint4 xr[SNV];                // packed x stays in registers; dA is re-read (L2-hot) in the apply pass
+  constexpr int NV = KEEP > 0 ? KEEP : SNV;
+  uint4 xr[NV];                 // packed x stays in registers
+  float duk[KEEP > 0 ? KEEP : 1][VE];
 #pragma unroll
-  for (int k = 0; k < SNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
@@ -472,7 +477,10 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       Vec16<T>::load(dA + e0, dav);
       du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) { s1[e] += du[e]; s2[e] += du[e] * xv[e]; }
+      for (int e = 0; e < VE; ++e) {
+        s1[e] += du[e]; s2[e] += du[e] * xv[e];
+        if (KEEP > 0) duk[k][e] = du[e];
+      }
     }
   }
   small_reduce<VE>(s1, s2, red, vs, CS, v);
@@ -514,14 +522,20 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
 #pragma unroll
   for (int e = 0; e < VE; ++e) { int gl = (v * VE + e) / cpg; k1v[e] = kk[gl * 2]; k0v[e] = kk[gl * 2 + 1]; }
 #pragma unroll
-  for (int k = 0; k < SNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
-      float xv[VE], dav[VE], du[VE], o[VE];
+      float xv[VE], du[VE], o[VE];
       unpack16<T>(xr[k], xv);
-      Vec16<T>::load(dA + e0, dav);
-      du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+      if (KEEP > 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) du[e] = duk[k][e];
+      } else {
+        float dav[VE];
+        Vec16<T>::load(dA + e0, dav);        // L2-hot second read
+        du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
+      }
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
       if (dres) {                 // gradient arriving over the block's residual / shortcut branch
@@ -722,15 +736,16 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres,
   size_t lds = ((size_t)(sp.NT / 64) * sp.CS * 2 + sp.CS * 2 + G * 2) * sizeof(float);
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_bwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)dA, (const float*)x,
-                       (const float*)dres, (float*)dx,
-                       gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd,
-                       salt, thr, dscale);
-  else
-    hipLaunchKernelGGL(gn_small_bwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)dA, (const bf16_t*)x,
-                       (const bf16_t*)dres, (bf16_t*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, dfilm_a, dgb,
-                       dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale);
+  static const int keep_env = getenv("IDF_GN_KEEP") ? atoi(getenv("IDF_GN_KEEP")) : 1;
+  const int nvt = idf_cdiv((long)HW * (sp.CS / VE), sp.NT);      // vectors per thread
+  const bool keep = keep_env && nvt <= 4;
+#define IDF_GN_BWD(T, K)                                                                                          \
+  hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
+                     (const T*)dres, (T*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
+                     dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale)
+  if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else IDF_GN_BWD(float, 0); }
+  else { if (keep) IDF_GN_BWD(bf16_t, 4); else IDF_GN_BWD(bf16_t, 0); }
+#undef IDF_GN_BWD
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

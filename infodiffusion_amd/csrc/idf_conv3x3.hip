@@ -27,6 +27,7 @@ struct C3P {
   bf16_t* y;            // [B, H, W, Cout]
   int B, H, W, Hs, Ws, Cin, Cout;
   int R, tiles_per_img, n_tiles, wshift;
+  unsigned wh_magic;    // (pix * wh_magic) >> 16 == pix / (W + 2*halo) for every halo pixel index (checked on the host)
 };
 
 constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048;   // (R+2)*(W+2)*4 budget per block size
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 
   // chunk-invariant staging plan: global element offsets (-1 = zero fill) and LDS byte offsets
   // (-1 = no slot), computed once so the chunk loop is loads + stores only
-  long hoff[HV], woff[WV];
+  int hoff[HV], woff[WV];      // element offsets (tensors < 2^31 elements: checked on the host)
   int hlds[HV], wlds[WV];
 #pragma unroll
   for (int k = 0; k < HV; ++k) {
@@ -94,12 +95,12 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     hoff[k] = -1; hlds[k] = -1;
     if (idx < npix_h * 4) {
       int pix = idx >> 2, ch = idx & 3;
-      int hy = pix / WH, hx = pix - hy * WH;
+      int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
       int iy = oy0 + hy - HALO, ix = hx - HALO;
       bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
       if (MODE != 0) { iy >>= 1; ix >>= 1; }
-      if (ok) hoff[k] = ((long)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
+      if (ok) hoff[k] = ((b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
       hlds[k] = pix * 64 + swz(pix, ch) * 16;
     }
   }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     int tap = r % TAPS, n = r / TAPS;
     woff[k] = -1; wlds[k] = -1;
     if (idx < BN * TAPS * 4) {
-      if (n0 + n < p.Cout) woff[k] = ((long)(n0 + n) * TAPS + tap) * p.Cin + ch * 8;
+      if (n0 + n < p.Cout) woff[k] = ((n0 + n) * TAPS + tap) * p.Cin + ch * 8;
       wlds[k] = (tap * BN + n) * 64 + swz(n, ch) * 16;
     }
   }
@@ -221,6 +222,14 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   }
 }
 
+// magic multiplier for the division by the halo-row width; 0 when not exact over [0, npix)
+inline unsigned wh_magic(int WH, int npix) {
+  unsigned m = 65536u / (unsigned)WH + 1u;
+  for (int i = 0; i < npix; ++i)
+    if ((((unsigned)i * m) >> 16) != (unsigned)(i / WH)) return 0;
+  return m;
+}
+
 template <int MODE, int TM, int BN, int NWM = 2, int KS = 3>
 void launch(const C3P& p, hipStream_t st) {
   size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
@@ -267,6 +276,9 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   }
   if ((R + 2) * (W + 2) * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
   p.R = R; p.tiles_per_img = H / R;
+  p.wh_magic = wh_magic(W + 2, (R + 2) * (W + 2));
+  if (!p.wh_magic || (long)B * p.Hs * p.Ws * Cin >= (1L << 31) || (long)Cout * 9 * Cin >= (1L << 31))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
   const bool bn32 = Cout <= 32;
   p.n_tiles = idf_cdiv(Cout, bn32 ? 32 : 64);
@@ -308,6 +320,9 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* w, const float* bias,
   if (R * W * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tile too large (R%d W%d)", R, W);
   p.R = R; p.tiles_per_img = H / R; p.n_tiles = nt;
+  p.wh_magic = wh_magic(W, R * W);
+  if (!p.wh_magic || (long)B * H * W * Cin >= (1L << 31))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
   if (BM == 256) launch<0, 4, 64, 4, 1>(p, st);
   else if (BM == 128) launch<0, 4, 64, 2, 1>(p, st);

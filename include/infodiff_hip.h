@@ -62,9 +62,11 @@ int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void
 /* 1x1 stride-1 convolution (AttnBlock q/k/v and proj, modules.py:136-139; ResBlock shortcuts, modules.py:228,
  * and their data gradients) through the same pipeline without the halo: w [Cout][Cin] bf16, optional
  * fp32 bias and bf16 residual.  IDF_ERR_UNSUPPORTED outside Cin % 32 == 0, Cout % 8 == 0, W a power
- * of two in 4..128 (use idf_bgemm then). */
-int idf_conv1x1_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B, int H, int W,
-                     int Cin, int Cout, void* stream);
+ * of two in 4..128 (use idf_bgemm then).  x2 != NULL: the input is the never-materialised channel
+ * concatenation x [.., C1] | x2 [.., Cin - C1] of a skip connection (models.py:321 torch.cat), C1 % 32 == 0;
+ * the GroupNorm one-launch kernels and the weight-gradient table take the same (x2, C1) pair. */
+int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* res, void* y,
+                     int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */
@@ -89,9 +91,9 @@ int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int
  * the table to device memory and launches it.  target_blocks = grid budget per problem (<= 0:
  * default 128); lds_bytes = max of the entries' lds_out. */
 int idf_wgrad_desc_bytes(void);
-int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* dy, float* dW, float* db, int B,
-                        int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks, int blk0,
-                        int* blocks_out, int* lds_out);
+int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy, float* dW,
+                        float* db, int B, int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks,
+                        int blk0, int* blocks_out, int* lds_out);
 int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
                                 void* stream);
 
@@ -134,12 +136,13 @@ int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, void* dx, c
 /* One-launch forms for small samples (the 16x16 and 8x8 levels): statistics + fold + apply, and the
  * whole backward, one workgroup per (sample, slice of whole groups).  IDF_ERR_UNSUPPORTED for shapes
  * idf_gn_fused_ok() reports 0 for (use the three-launch forms above). */
-int idf_gn_fused_ok(int B, int HW, int C, int dtype);
-int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
+int idf_gn_fused_ok(int B, int HW, int C, int C1, int dtype);   /* C1 > 0: two-source input x [..,C1] | x2 [..,C-C1] */
+int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out, const float* gamma, const float* beta, const float* film_t,
                      const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc,
                      float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C,
                      int dtype, void* stream);
-int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma, const float* beta,
+int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, void* dx, void* dx2,
+                     const float* gamma, const float* beta,
                      const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                      const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,
                      float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt, float p_drop, int act,

@@ -21,6 +21,8 @@ namespace {
 
 struct C3P {
   const bf16_t* x;      // source activations [B, Hs, Ws, Cin]
+  const bf16_t* x2;     // DUAL: channels C1.. of the input live here ([B, Hs, Ws, Cin - C1]); x holds [.., C1]
+  int C1;
   const bf16_t* w;      // [Cout][9][Cin]
   const float* bias;    // [Cout] or null
   const bf16_t* res;    // [B, H, W, Cout] or null
@@ -39,7 +41,9 @@ __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1
 // weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
 // KS = 3 (3x3, pad 1) or 1 (1x1: the same pipeline without the halo -- the AttnBlock q/k/v and proj
 // convs, ResBlock shortcuts and their data gradients; MODE 0 only).
-template <int MODE, int TM, int BN, int NWM, int KS = 3>
+// DUAL: the input is the never-materialised channel concatenation x | x2 (skip connection): a 32-channel
+// chunk is fetched from the tensor it lies in (C1 % 32 == 0).
+template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false>
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
       bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
       if (MODE != 0) { iy >>= 1; ix >>= 1; }
-      if (ok) hoff[k] = ((b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
+      if (ok) hoff[k] = DUAL ? (((b * p.Hs + iy) * p.Ws + ix) * 4 + ch)           // pixel index, vector slot
+                             : ((b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
       hlds[k] = pix * 64 + swz(pix, ch) * 16;
     }
   }
@@ -118,6 +123,15 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 
   auto load_chunk = [&](int ck) {
     const int c0 = ck * CK;
+    if (DUAL) {
+      const bool first = c0 < p.C1;
+      const bf16_t* src = first ? p.x + c0 : p.x2 + (c0 - p.C1);
+      const int pitch = first ? p.C1 : p.Cin - p.C1;
+#pragma unroll
+      for (int k = 0; k < HV; ++k)
+        hreg[k] = hoff[k] >= 0 ? *reinterpret_cast<const uint4*>(src + (size_t)(hoff[k] >> 2) * pitch + (hoff[k] & 3) * 8)
+                               : make_uint4(0, 0, 0, 0);
+    } else
 #pragma unroll
     for (int k = 0; k < HV; ++k)
       hreg[k] = hoff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.x + hoff[k] + c0) : make_uint4(0, 0, 0, 0);
@@ -230,12 +244,12 @@ inline unsigned wh_magic(int WH, int npix) {
   return m;
 }
 
-template <int MODE, int TM, int BN, int NWM = 2, int KS = 3>
+template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false>
 void launch(const C3P& p, hipStream_t st) {
   size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
   size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
-  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS>;
+  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL>;
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
@@ -253,6 +267,7 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   if (B == 0) return IDF_OK;
   C3P p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.x2 = nullptr; p.C1 = Cin;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.Hs = mode ? H / 2 : H; p.Ws = mode ? W / 2 : W;
   int ws = 0;
@@ -297,13 +312,15 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
 
 // 1x1 convolution (stride 1) forward / data gradient through the same pipeline (KS = 1): w [Cout][Cin].
 // IDF_ERR_UNSUPPORTED for shapes it does not cover (the caller then uses idf_bgemm).
-extern "C" int idf_conv1x1_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
-                                int H, int W, int Cin, int Cout, void* stream) {
-  if ((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias,
+                                const void* res, void* y, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x2) C1 = Cin;
+  if ((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: B%d H%d W%d Cin%d (C1 %d) Cout%d not covered", B, H, W, Cin, C1, Cout);
   if (B == 0) return IDF_OK;
   C3P p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.x2 = (const bf16_t*)x2; p.C1 = C1;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Hs = H; p.Ws = W;
   int ws = 0;
   while ((1 << ws) < W) ++ws;
@@ -324,7 +341,11 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* w, const float* bias,
   if (!p.wh_magic || (long)B * H * W * Cin >= (1L << 31))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
-  if (BM == 256) launch<0, 4, 64, 4, 1>(p, st);
+  if (x2) {
+    if (BM == 256) launch<0, 4, 64, 4, 1, true>(p, st);
+    else if (BM == 128) launch<0, 4, 64, 2, 1, true>(p, st);
+    else launch<0, 2, 64, 2, 1, true>(p, st);
+  } else if (BM == 256) launch<0, 4, 64, 4, 1>(p, st);
   else if (BM == 128) launch<0, 4, 64, 2, 1>(p, st);
   else launch<0, 2, 64, 2, 1>(p, st);
   IDF_CHECK_LAUNCH();

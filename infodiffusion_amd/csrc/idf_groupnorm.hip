@@ -353,7 +353,8 @@ __device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], flo
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T* __restrict__ out,
+__global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, const T* __restrict__ x2, int C1,
+                                                     T* __restrict__ out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, float eps, float* __restrict__ mean,
@@ -369,6 +370,14 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
   float* cof = gst + GS * 2;             // [CS][2] sc, sh
   const int vs = CS / VE, lanes = NT / vs, tid = threadIdx.x;
   const int b = blockIdx.x, c0 = blockIdx.y * CS, v = tid % vs, pl = tid / vs;
+  // the input may be the channel concatenation of two tensors (skip connection): x [.., C1] | x2 [.., C - C1],
+  // never materialised -- a slice reads from the one it lies in
+  const T* src = x;
+  int spitch = C, sc0 = c0;
+  if (x2) {
+    if (c0 < C1) spitch = C1;
+    else { src = x2; spitch = C - C1; sc0 = c0 - C1; }
+  }
   float xv[SNV][VE], s[VE], q[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
     if (p < HW) {
-      Vec16<T>::load(x + ((size_t)b * HW + p) * C + c0 + v * VE, xv[k]);
+      Vec16<T>::load(src + ((size_t)b * HW + p) * spitch + sc0 + v * VE, xv[k]);
 #pragma unroll
       for (int e = 0; e < VE; ++e) { s[e] += xv[k][e]; q[e] += xv[k][e] * xv[k][e]; }
     }
@@ -439,7 +448,8 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, T*
 // vectors per thread, du recomputed in the apply phase (register budget of a 1024-thread block).
 template <typename T, int KEEP>
 __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x,
-                                                     const T* __restrict__ dres, T* __restrict__ dx,
+                                                     const T* __restrict__ x2, int C1,
+                                                     const T* __restrict__ dres, T* __restrict__ dx, T* __restrict__ dx2,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, const float* __restrict__ mean,
@@ -463,6 +473,13 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     scv[e] = sc[(size_t)b * C + c0 + v * VE + e]; shv[e] = sh[(size_t)b * C + c0 + v * VE + e];
     s1[e] = s2[e] = 0.f;
   }
+  const T* src = x;             // two-source input (see gn_small_fwd); dx goes back to the matching tensor
+  T* dst = dx;
+  int spitch = C, sc0 = c0;
+  if (x2) {
+    if (c0 < C1) spitch = C1;
+    else { src = x2; dst = dx2; spitch = C - C1; sc0 = c0 - C1; }
+  }
   constexpr int NV = KEEP > 0 ? KEEP : SNV;
   uint4 xr[NV];                 // packed x stays in registers
   float duk[KEEP > 0 ? KEEP : 1][VE];
@@ -471,7 +488,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     int p = pl + k * lanes;
     if (p < HW) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
-      xr[k] = *reinterpret_cast<const uint4*>(x + e0);
+      xr[k] = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0 + v * VE);
       float xv[VE], dav[VE], du[VE];
       unpack16<T>(xr[k], xv);
       Vec16<T>::load(dA + e0, dav);
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] += rv[e];
       }
-      Vec16<T>::store(dx + e0, o);
+      Vec16<T>::store(dst + ((size_t)b * HW + p) * spitch + sc0 + v * VE, o);
     }
   }
 }
@@ -552,7 +569,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
 // Slice plan for the one-launch kernels: CS channels per block (whole groups, whole 16-byte vectors,
 // CS/VE a power of two <= 64) and the block size.  Largest slice that still gives >= ~256 blocks.
 struct SmallPlan { int CS, NT; };
-bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan) {
+bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
   static const int max_hw = getenv("IDF_GN_SMALL_MAXHW") ? atoi(getenv("IDF_GN_SMALL_MAXHW")) : 4096;
   static const int want = getenv("IDF_GN_SMALL_BLOCKS") ? atoi(getenv("IDF_GN_SMALL_BLOCKS")) : 256;
   if (C % G || C % VE || C > 1024 || HW > max_hw || HW < 1) return false;
@@ -563,6 +580,7 @@ bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan) {
   for (int cs = unit; cs <= C; cs *= 2) {
     const int vs = cs / VE;
     if (C % cs || (vs & (vs - 1)) || vs > 64) continue;
+    if (C1 > 0 && (C1 % cs)) continue;           // a slice must lie inside one of the two sources
     if ((long)HW * vs > 1024L * SNV) break;
     if (!best || (long)B * (C / cs) >= want) best = cs;
   }
@@ -688,20 +706,23 @@ extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const flo
 }
 
 // 1 when idf_gn_fused_fwd / idf_gn_fused_bwd cover this shape (the host picks the path with it).
-extern "C" int idf_gn_fused_ok(int B, int HW, int C, int dtype) {
+extern "C" int idf_gn_fused_ok(int B, int HW, int C, int C1, int dtype) {
   SmallPlan sp;
-  return small_plan(B, HW, C, dtype == IDF_F32 ? 4 : 8, &sp) ? 1 : 0;
+  if (C1 < 0 || C1 >= C) return 0;
+  return small_plan(B, HW, C, dtype == IDF_F32 ? 4 : 8, &sp, C1) ? 1 : 0;
 }
 
 // One-launch GroupNorm + FiLM fold + apply for small samples (statistics, sc/sh, a = act(x*sc+sh)).
 // IDF_ERR_UNSUPPORTED when a sample does not fit one workgroup: use idf_gn_coef_fwd + idf_gn_apply.
-extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, const float* beta, const float* film_t,
+extern "C" int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out, const float* gamma, const float* beta, const float* film_t,
                                 const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd,
                                 float* sc, float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act,
                                 int B, int HW, int C, int dtype, void* stream) {
   int VE = dtype == IDF_F32 ? 4 : 8;
   SmallPlan sp;
-  if (!small_plan(B, HW, C, VE, &sp)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_fwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  if (!x2) C1 = 0;
+  if (C1 < 0 || C1 >= C || !small_plan(B, HW, C, VE, &sp, C1))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_fwd: HW=%d C=%d C1=%d does not fit one workgroup", HW, C, C1);
   if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "gn_fused_fwd: act must be 1 or 2");
   if (B == 0) return IDF_OK;
   uint32_t thr = idf_drop_thresh(p_drop);
@@ -711,16 +732,17 @@ extern "C" int idf_gn_fused_fwd(const void* x, void* out, const float* gamma, co
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)x, (float*)out, gamma, beta, film_t,
+    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)x, (const float*)x2, C1, (float*)out, gamma, beta, film_t,
                        film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)x, (bf16_t*)out, gamma, beta,
+    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)out, gamma, beta,
                        film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
 
-extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres, void* dx, const float* gamma, const float* beta,
+extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, void* dx, void* dx2,
+                                const float* gamma, const float* beta,
                                 const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                                 const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
                                 float* dgb, float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt,
@@ -728,7 +750,9 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres,
                                 int C, int dtype, void* stream) {
   int VE = dtype == IDF_F32 ? 4 : 8;
   SmallPlan sp;
-  if (!small_plan(B, HW, C, VE, &sp)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_bwd: HW=%d C=%d does not fit one workgroup", HW, C);
+  if (!x2) C1 = 0;
+  if (C1 < 0 || C1 >= C || (x2 && !dx2) || !small_plan(B, HW, C, VE, &sp, C1))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_fused_bwd: HW=%d C=%d C1=%d does not fit one workgroup", HW, C, C1);
   if (B == 0) return IDF_OK;
   uint32_t thr = idf_drop_thresh(p_drop);
   float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
@@ -741,7 +765,7 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* dres,
   const bool keep = keep_env && nvt <= 4;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
-                     (const T*)dres, (T*)dx, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
+                     (const T*)x2, C1, (const T*)dres, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
                      dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale)
   if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else IDF_GN_BWD(float, 0); }
   else { if (keep) IDF_GN_BWD(bf16_t, 4); else IDF_GN_BWD(bf16_t, 0); }

@@ -22,7 +22,9 @@
 namespace {
 
 struct WgP {
-  const bf16_t* a;    // [B,H,W,Cin]
+  const bf16_t* a;    // [B,H,W,Cin]  (or [.., C1] when a2 is set)
+  const bf16_t* a2;   // channels C1.. of a never-materialised concatenation ([B,H,W,Cin-C1]) or null; C1 % 64 == 0
+  int C1;
   const bf16_t* dy;   // [B,H,W,Cout]
   float* dW;          // [Cout][taps][Cin]
   float* db;          // [Cout] or null
@@ -95,6 +97,13 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   // register double-buffering: tile t+1 is fetched while tile t is in the MFMAs
   constexpr int XV = 5, DV = 4;           // 16-byte vectors per thread (input rows / dy)
   uint4 xreg[XV], dreg[DV];
+  // input tile source: a cin tile lies entirely in `a` or in `a2`
+  const bf16_t* asrc = p.a + c0;
+  int apitch = p.Cin;
+  if (p.a2) {
+    if (c0 < p.C1) apitch = p.C1;
+    else { asrc = p.a2 + (c0 - p.C1); apitch = p.Cin - p.C1; }
+  }
   auto load_tile = [&](int t) {
     const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
 #pragma unroll
@@ -107,7 +116,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
         int iy = SX * (oy0 + hy) + ky - HALO, ix = hx - HALO;
         if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
           if (MODE == 2) { iy >>= 1; ix >>= 1; }
-          val = *reinterpret_cast<const uint4*>(p.a + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c0 + v8 * 8);
+          val = *reinterpret_cast<const uint4*>(asrc + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * apitch + v8 * 8);
         }
       }
       xreg[k] = val;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
 
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
-            int W, int Cin, int Cout, int taps, int mode, int target_blocks) {
+            int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -259,7 +268,10 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   if (R > H) R = H;
   if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
+  if (a2 && (C1 <= 0 || C1 >= Cin || (C1 % 64) || mode != 0))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: two-source input needs C1 %% 64 == 0 (C1 %d) and stride 1", C1);
   p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
+  p.a2 = (const bf16_t*)a2; p.C1 = a2 ? C1 : Cin;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
   p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
   p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
@@ -327,9 +339,9 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
 // (taps, mode) class.  Accumulating only (dW / db pre-zeroed: the gradient arena).
 extern "C" int idf_wgrad_desc_bytes(void) { return (int)sizeof(WgDesc); }
 
-extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* dy, float* dW, float* db,
-                                   int B, int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks,
-                                   int blk0, int* blocks_out, int* lds_out) {
+extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy,
+                                   float* dW, float* db, int B, int H, int W, int Cin, int Cout, int taps, int mode,
+                                   int target_blocks, int blk0, int* blocks_out, int* lds_out) {
   if (!host_table || index < 0 || !blocks_out || !lds_out) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: null argument");
   if (B <= 0) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: empty batch");
   WgDesc d;
@@ -337,7 +349,8 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   size_t lds;
   static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
   if (forced > 0) target_blocks = forced;
-  int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128);
+  int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128,
+                   a2, C1);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;

@@ -320,6 +320,19 @@ class _ResBase(nn.Module):
         return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
                               passthrough)
 
+    def _block1(self, x):
+        """(h, residual) of the block's first stage.  x may be the pair (h_prev, skip) of an up-path block:
+        the concatenation is then read in place by the two-source kernels instead of being materialised."""
+        if isinstance(x, tuple):
+            blk = self.block1
+            if isinstance(self.shortcut, nn.Conv2d) and ops.block_entry_cat_ok(x[0], x[1], blk[-1].weight,
+                                                                               self.shortcut.weight):
+                cfg = _cfg(self._sh_block1, ops.S1, 9, _ACT_SILU, self.p_drop, self.salt)
+                return ops.block_entry_cat(x[0], x[1], blk[-1], blk[0], self.shortcut, cfg, self._cfg_sc)
+            x = torch.cat(x, dim=1)
+        h, x = self._gn_conv('block1', x, passthrough=True)     # x: the residual branch's gradient joins in block1
+        return h, self._shortcut(x)
+
     def _shortcut(self, x):
         if isinstance(self.shortcut, nn.Conv2d):
             return ops.fused_conv(x, self.shortcut.weight, self.shortcut.bias, self._cfg_sc)
@@ -340,12 +353,12 @@ class ResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb):
-        h, x = self._gn_conv('block1', x, passthrough=True)    # x: the residual branch's gradient joins in block1
+        h, res = self._block1(x)
         ft = self._film.pop('t', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
         h = self._gn_conv('block2', h, film_t=ft, drop_site=1)
-        h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
+        h = self._gn_conv('block3', h, drop_site=2, residual=res)
         return self.attn(h)
 
 
@@ -366,7 +379,7 @@ class AuxResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb, aemb=None):
-        h, x = self._gn_conv('block1', x, passthrough=True)    # x: the residual branch's gradient joins in block1
+        h, res = self._block1(x)
         ft = self._film.pop('t', None) if self._film else None
         fa = self._film.pop('a', None) if self._film else None
         if ft is None:
@@ -374,7 +387,7 @@ class AuxResBlock(_ResBase):
         if fa is None:
             fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
         h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1)
-        h = self._gn_conv('block3', h, drop_site=2, residual=self._shortcut(x))
+        h = self._gn_conv('block3', h, drop_site=2, residual=res)
         h = self.attn(h)
         if self.use_crossattn:
             h = self.crossattn(h, aemb)
@@ -393,8 +406,8 @@ class ResBlock_encoder(_ResBase):
         self._setup(dropout)
 
     def forward(self, x):
-        h, x = self._gn_conv('block1', x, passthrough=True)
-        h = self._gn_conv('block2', h, drop_site=1, residual=self._shortcut(x))
+        h, res = self._block1(x)
+        h = self._gn_conv('block2', h, drop_site=1, residual=res)
         return self.attn(h)
 
 

@@ -116,7 +116,7 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
     if (taps == 1 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin % 32 == 0 and Cout % 8 == 0
             and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _CONV1X1):
         # 1x1 conv through the halo-conv pipeline without the halo (LDS-swizzled tiles, full-line epilogue)
-        call('idf_conv1x1_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout, _st())
+        call('idf_conv1x1_bf16', _p(x), None, 0, _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout, _st())
         return y
     if taps == 1 and mode == S1 and act == 0 and Cin % 8 == 0 and Cout % 4 == 0:
         # 1x1 conv = [pixels, Cin] x [Cout, Cin]^T (+bias, +residual): the short-K GEMM
@@ -217,43 +217,53 @@ def bgemm_raw(A, offA, B_, offB, Cout, offC, bias, batch, sA, sB, sC, lda, ldb, 
 
 # ------------------------------------------------------------- fused conv op
 @functools.lru_cache(maxsize=None)
-def _gn_fused_ok(B, HW, C, dt):
-    return bool(_lib.load().idf_gn_fused_ok(B, HW, C, dt))
+def _gn_fused_ok(B, HW, C, dt, C1=0):
+    return bool(_lib.load().idf_gn_fused_ok(B, HW, C, C1, dt))
 
 
-def gn_small_ok(x):
-    """The one-launch GroupNorm kernels cover this tensor (idf_gn_fused_ok)."""
+def gn_small_ok(x, x2=None):
+    """The one-launch GroupNorm kernels cover this tensor (idf_gn_fused_ok); x2: second source of a
+    never-materialised channel concatenation x | x2."""
     B, C, H, W = x.shape
+    if x2 is not None:
+        return _gn_fused_ok(B, H * W, C + x2.shape[1], _dt(x), C)
     return _gn_fused_ok(B, H * W, C, _dt(x))
 
 
-def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act):
-    """statistics + FiLM fold + apply in one launch -> (a, mean, rstd, sc, sh)."""
-    B, C, H, W = x.shape
+def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act, x2=None):
+    """statistics + FiLM fold + apply in one launch -> (a, mean, rstd, sc, sh).  x2: the input is the
+    channel concatenation x | x2 (read in place, never materialised); `a` is dense over all channels."""
+    B, C1, H, W = x.shape
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
     dev = x.device
     mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
     sc = torch.empty((B, C), dtype=torch.float32, device=dev)
     sh = torch.empty((B, C), dtype=torch.float32, device=dev)
-    a = torch.empty_like(x, memory_format=CL)
-    call('idf_gn_fused_fwd', _p(x), _p(a), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
+    a = empty_nhwc(B, C, H, W, x.dtype, dev)
+    call('idf_gn_fused_fwd', _p(x), _p(x2), C1, _p(a), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
          GN_EPS, _p(mean), _p(rstd), _p(sc), _p(sh), _p(seed), salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
     return a, mean, rstd, sc, sh
 
 
 def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None,
-                     dres=None):
-    B, C, H, W = x.shape
+                     dres=None, x2=None):
+    """x2: two-source input (see gn_fused_fwd_raw); then the first result is the pair (dx, dx2)."""
+    B, C1, H, W = x.shape
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
     dev = x.device
     dx = torch.empty_like(x, memory_format=CL)
+    dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
     acc = _gn_acc(acc)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
-    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(dres), _p(dx), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
+    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(x2), C1, _p(dres), _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
          _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop),
          act, B, H * W, C, _dt(x), _st())
+    if x2 is not None:
+        dx = (dx, dx2)
     if acc:
         return dx, acc[0], acc[1], dft, dfa
     dgam = colsum_raw(dgb)
@@ -306,7 +316,7 @@ class WgradBatch:
     backward pass computes them all (`idf_conv_wgrad_bf16_batched`): no per-conv launch, small
     problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
     enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
-    pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode)
+    pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1)
     _bufs = {}         # (taps, mode) -> [pinned host table, device table, key]   (eager: reused)
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
@@ -330,7 +340,7 @@ class WgradBatch:
         capturing = torch.cuda.is_current_stream_capturing()
         for (taps, mode), grp in groups.items():
             n = len(grp)
-            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] for it in grp)
+            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] + (_p(it[11]), it[12]) for it in grp)
             buf = cls._bufs.get((taps, mode))
             if buf is None or buf[0].numel() < n * nb:
                 dev = grp[0][0].device
@@ -346,8 +356,8 @@ class WgradBatch:
                 host = buf[0].data_ptr()
                 blk, lds = 0, 0
                 nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
-                for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _) in enumerate(grp):
-                    _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(dy), dW, db, B, H, W, Cin, Cout, taps,
+                for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1) in enumerate(grp):
+                    _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout, taps,
                                                        mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)), 'idf_wgrad_desc_fill')
                     blk += nblk.value
                     lds = max(lds, nlds.value)
@@ -373,7 +383,7 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, 
                 dW, db = views
                 if defer and WgradBatch.enabled:
                     # slot ADDRESSES, not the tensors: AccumulateGrad adopts a gradient only if nobody else holds it
-                    WgradBatch.add((ap, dyp, _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode))
+                    WgradBatch.add((ap, dyp, _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, None, 0))
                 else:
                     call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 1,
                          _st())
@@ -491,6 +501,90 @@ def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=N
     if torch.is_grad_enabled():
         slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
     return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, passthrough)
+
+
+# ------------------------------------------- ResBlock entry on a skip concatenation
+def _defer_or_launch_wgrad(a, dy, w_slot, b_slot, taps, a2=None):
+    """Arena-accumulating weight (+bias) gradient of a stride-1 conv, deferred to the end of backward when
+    nothing but AccumulateGrad will touch the slots; returns (dW, db) slot views or None (no free slots)."""
+    B, Cin1, H, W = a.shape
+    Cin = Cin1 + (a2.shape[1] if a2 is not None else 0)
+    Cout = dy.shape[1]
+    k = 3 if taps == 9 else 1
+    if not (_grad_free(w_slot) and _grad_free(b_slot) and WgradBatch.enabled
+            and _fast_wgrad_ok(Cin, Cout, H, W, a.dtype, S1, taps)):
+        return None
+    views = _slot_views(w_slot, b_slot, True, (Cout, Cin, k, k))
+    if views is None:
+        return None
+    WgradBatch.add((a, dy, _p(views[0]), _p(views[1]), B, H, W, Cin, Cout, taps, S1, a2, Cin1))
+    return views
+
+
+class _BlockEntryCat(torch.autograd.Function):
+    """First stage of an up-path ResBlock whose input is the skip concatenation x = cat(x1, x2)
+    (models.py:321) WITHOUT materialising it:   h = conv3x3(SiLU(GN(x))) + b,   s = shortcut1x1(x) + bs.
+    GroupNorm, the 1x1 shortcut and the shortcut's weight gradient read the two tensors in place; the
+    backward returns dx1 and dx2 as separate dense tensors straight from the GroupNorm backward kernel
+    (which also adds the shortcut's data gradient), so neither the concat nor its split copies exist."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b, gn_w, gn_b, sw, sb, cfg, cfg_sc, train, slots):
+        x1, x2 = _nhwc(x1), _nhwc(x2)
+        B, C1, H, W = x1.shape
+        C = C1 + x2.shape[1]
+        a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
+        h = conv_raw(a, cfg['shadows'](x1.dtype, train)[0], b, None, None, None, None, 0, 0.0, S1, 9, 0, w.shape[0])
+        s = empty_nhwc(B, sw.shape[0], H, W, x1.dtype, x1.device)
+        call('idf_conv1x1_bf16', _p(x1), _p(x2), C1, _p(cfg_sc['shadows'](x1.dtype, train)[0]), _p(sb), None, _p(s),
+             B, H, W, C, sw.shape[0], _st())
+        ctx.cfg, ctx.cfg_sc, ctx.slots = cfg, cfg_sc, slots or (None,) * 6
+        ctx.save_for_backward(x1, x2, a, w, b, gn_w, gn_b, sw, sb, mean, rstd, sc, sh)
+        return h, s
+
+    @staticmethod
+    def backward(ctx, dh, ds):
+        x1, x2, a, w, b, gn_w, gn_b, sw, sb, mean, rstd, sc, sh = ctx.saved_tensors
+        cfg, cfg_sc = ctx.cfg, ctx.cfg_sc
+        ws, bs, gws, gbs, sws, sbs = ctx.slots
+        B, C1, H, W = x1.shape
+        C = C1 + x2.shape[1]
+        dh, ds = _nhwc(dh.to(x1.dtype)), _nhwc(ds.to(x1.dtype))
+        # shortcut: weight gradient over the two-source input, data gradient dense (joins in the GN backward)
+        got = _defer_or_launch_wgrad(x1, ds, sws, sbs, 1, a2=x2)
+        if got is None:
+            xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL)
+            got = conv_wgrad_bias_raw(xc, ds, S1, 1, True)
+        dsW, dsb = got
+        dxs = conv_dgrad_raw(ds, cfg_sc['shadows'](x1.dtype, True)[1], S1, 1, (B, C, H, W))
+        got = _defer_or_launch_wgrad(a, dh, ws, bs, 9)
+        if got is None:
+            got = conv_wgrad_bias_raw(a, dh, S1, 9, True)
+        dW, db = got
+        dA = conv_dgrad_raw(dh, cfg['shadows'](x1.dtype, True)[1], S1, 9, a.shape)
+        (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None,
+                                                       cfg['salt'], 0.0, cfg['act'], (gws, gbs), dres=dxs, x2=x2)
+        return dx1, dx2, dW, db, dgw, dgb, dsW, dsb, None, None, None, None
+
+
+def block_entry_cat_ok(x1, x2, conv_w, sc_w):
+    """Shapes the two-source kernels cover (else the caller concatenates)."""
+    if not (x1.is_cuda and x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and x1.shape[2:] == x2.shape[2:]):
+        return False
+    B, C1, H, W = x1.shape
+    C = C1 + x2.shape[1]
+    return (C1 % 64 == 0 and x2.shape[1] % 32 == 0 and 4 <= W <= 128 and not (W & (W - 1)) and sc_w.shape[0] % 8 == 0
+            and conv_w.shape[1] == C and gn_small_ok(x1, x2) and _CONV1X1
+            and uses_halo_kernel(x1.dtype, 9, 0, S1, B, C, conv_w.shape[0], H, W))
+
+
+def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
+    train = torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad)
+    slots = None
+    if torch.is_grad_enabled():
+        slots = tuple(slot_of(p) for p in (conv.weight, conv.bias, gn.weight, gn.bias, shortcut.weight, shortcut.bias))
+    return _BlockEntryCat.apply(x1, x2, conv.weight, conv.bias, gn.weight, gn.bias, shortcut.weight, shortcut.bias,
+                                cfg, cfg_sc, train, slots)
 
 
 # ------------------------------------------------------------------ attention

@@ -528,3 +528,36 @@ def test_gradient_arena_matches_standalone_gradients_and_survives_accumulation()
     close(twice, 2, 'accumulated')
     opt.zero_grad()
     close(grads(), 1, 'after zero_grad')
+
+
+def test_up_block_reads_skip_pair_in_place():
+    """An up-path AuxResBlock given the pair (h, skip) (two-source GroupNorm / 1x1 shortcut / weight
+    gradient, no torch.cat) == the same block on the materialised concatenation: output, both input
+    gradients and every parameter gradient."""
+    from infodiffusion_amd import ops
+    from infodiffusion_amd.modules import AuxResBlock
+    torch.manual_seed(5)
+    blk = AuxResBlock(in_ch=256, out_ch=128, tdim=256, dropout=0.0).to(DEV).train()
+    blk.ctx.act_dtype = torch.bfloat16
+    h0 = torch.randn(4, 128, 16, 16, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    s0 = torch.randn(4, 128, 16, 16, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    temb, aemb = torch.randn(4, 256, device=DEV), torch.randn(4, 256, device=DEV)
+    go = torch.randn(4, 128, 16, 16, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run(pair):
+        for p in blk.parameters():
+            p.grad = None
+        h, s = h0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = blk((h, s) if pair else torch.cat([h, s], dim=1), temb, aemb)
+        y.backward(go)
+        return y.detach().float(), h.grad.float(), s.grad.float(), {n: p.grad.clone() for n, p in blk.named_parameters()
+                                                                     if p.grad is not None}
+    assert ops.block_entry_cat_ok(h0, s0, blk.block1[-1].weight, blk.shortcut.weight)
+    ya, dha, dsa, ga = run(True)
+    yb, dhb, dsb, gb = run(False)
+    rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-9)).item()
+    assert rel(ya, yb) < 1e-2 and rel(dha, dhb) < 2e-2 and rel(dsa, dsb) < 2e-2
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        if gb[n].abs().max() > 1e-3:
+            assert rel(ga[n], gb[n]) < 2e-2, n

@@ -343,7 +343,7 @@ __device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], flo
     for (int e = 0; e < VE; ++e) { s[e] += __shfl_xor(s[e], off, 64); q[e] += __shfl_xor(q[e], off, 64); }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < vs) {
+  if (lane < vs && v * VE < CS) {          // vs may exceed CS / VE (padding lanes of a non-power-of-two slice)
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       red[(wave * CS + v * VE + e) * 2] = s[e];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, float eps, float* __restrict__ mean,
                                                      float* __restrict__ rstd, float* __restrict__ sc,
-                                                     float* __restrict__ sh, int HW, int C, int CS, int act,
+                                                     float* __restrict__ sh, int HW, int C, int CS, int vs, int act,
                                                      const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale) {
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -368,15 +368,18 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
   float* chs = red + nw * CS * 2;        // [CS][2]
   float* gst = chs + CS * 2;             // [GS][2] mean, rstd
   float* cof = gst + GS * 2;             // [CS][2] sc, sh
-  const int vs = CS / VE, lanes = NT / vs, tid = threadIdx.x;
+  // vs lanes per pixel (a power of two >= CS / VE; the lanes beyond CS / VE idle: 192-channel tensors have
+  // 24-channel slices = 3 vectors on 4 lanes)
+  const int lanes = NT / vs, tid = threadIdx.x;
   const int b = blockIdx.x, c0 = blockIdx.y * CS, v = tid % vs, pl = tid / vs;
+  const bool live = v * VE < CS;
   // the input may be the channel concatenation of two tensors (skip connection): x [.., C1] | x2 [.., C - C1],
-  // never materialised -- a slice reads from the one it lies in
+  // never materialised -- each 16-byte vector is read from the tensor it lies in (C1 % VE == 0)
   const T* src = x;
-  int spitch = C, sc0 = c0;
+  int spitch = C, sc0 = c0 + v * VE;
   if (x2) {
-    if (c0 < C1) spitch = C1;
-    else { src = x2; spitch = C - C1; sc0 = c0 - C1; }
+    if (sc0 < C1) spitch = C1;
+    else { src = x2; spitch = C - C1; sc0 -= C1; }
   }
   float xv[SNV][VE], s[VE], q[VE];
 #pragma unroll
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
 #pragma unroll
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
-    if (p < HW) {
-      Vec16<T>::load(src + ((size_t)b * HW + p) * spitch + sc0 + v * VE, xv[k]);
+    if (p < HW && live) {
+      Vec16<T>::load(src + ((size_t)b * HW + p) * spitch + sc0, xv[k]);
 #pragma unroll
       for (int e = 0; e < VE; ++e) { s[e] += xv[k][e]; q[e] += xv[k][e] * xv[k][e]; }
     }
@@ -421,11 +424,14 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
   __syncthreads();
   float scv[VE], shv[VE];
 #pragma unroll
-  for (int e = 0; e < VE; ++e) { scv[e] = cof[(v * VE + e) * 2]; shv[e] = cof[(v * VE + e) * 2 + 1]; }
+  for (int e = 0; e < VE; ++e) {
+    scv[e] = live ? cof[(v * VE + e) * 2] : 0.f;
+    shv[e] = live ? cof[(v * VE + e) * 2 + 1] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < SNV; ++k) {
     int p = pl + k * lanes;
-    if (p < HW) {
+    if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
       const int l0 = (int)(e0 & 7);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
                                                      const float* __restrict__ sh, float* __restrict__ dfilm_t,
                                                      float* __restrict__ dfilm_a, float* __restrict__ dgb,
                                                      float* __restrict__ dgam_acc, float* __restrict__ dbet_acc, int HW, int C,
-                                                     int CS, int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
+                                                     int CS, int vs, int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
                                                      float dscale) {
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -465,20 +471,22 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   float* red = sm;                       // [nw][CS][2]
   float* pc = red + nw * CS * 2;         // [CS][2]  ga*f*D1, ga*f*D2
   float* kk = pc + CS * 2;               // [GS][2]  k1, k0
-  const int vs = CS / VE, lanes = NT / vs, tid = threadIdx.x;
+  const int lanes = NT / vs, tid = threadIdx.x;          // vs lanes per pixel, see gn_small_fwd
   const int b = blockIdx.x, c0 = blockIdx.y * CS, v = tid % vs, pl = tid / vs;
+  const bool live = v * VE < CS;
   float scv[VE], shv[VE], s1[VE], s2[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    scv[e] = sc[(size_t)b * C + c0 + v * VE + e]; shv[e] = sh[(size_t)b * C + c0 + v * VE + e];
+    scv[e] = live ? sc[(size_t)b * C + c0 + v * VE + e] : 0.f;
+    shv[e] = live ? sh[(size_t)b * C + c0 + v * VE + e] : 0.f;
     s1[e] = s2[e] = 0.f;
   }
   const T* src = x;             // two-source input (see gn_small_fwd); dx goes back to the matching tensor
   T* dst = dx;
-  int spitch = C, sc0 = c0;
+  int spitch = C, sc0 = c0 + v * VE;
   if (x2) {
-    if (c0 < C1) spitch = C1;
-    else { src = x2; dst = dx2; spitch = C - C1; sc0 = c0 - C1; }
+    if (sc0 < C1) spitch = C1;
+    else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
   }
   constexpr int NV = KEEP > 0 ? KEEP : SNV;
   uint4 xr[NV];                 // packed x stays in registers
@@ -486,9 +494,9 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
-    if (p < HW) {
+    if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
-      xr[k] = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0 + v * VE);
+      xr[k] = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
       float xv[VE], dav[VE], du[VE];
       unpack16<T>(xr[k], xv);
       Vec16<T>::load(dA + e0, dav);
@@ -537,11 +545,15 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   __syncthreads();
   float k1v[VE], k0v[VE];
 #pragma unroll
-  for (int e = 0; e < VE; ++e) { int gl = (v * VE + e) / cpg; k1v[e] = kk[gl * 2]; k0v[e] = kk[gl * 2 + 1]; }
+  for (int e = 0; e < VE; ++e) {
+    int gl = (v * VE + e) / cpg;
+    k1v[e] = live ? kk[gl * 2] : 0.f;
+    k0v[e] = live ? kk[gl * 2 + 1] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
-    if (p < HW) {
+    if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       float xv[VE], du[VE], o[VE];
       unpack16<T>(xr[k], xv);
@@ -561,14 +573,14 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] += rv[e];
       }
-      Vec16<T>::store(dst + ((size_t)b * HW + p) * spitch + sc0 + v * VE, o);
+      Vec16<T>::store(dst + ((size_t)b * HW + p) * spitch + sc0, o);
     }
   }
 }
 
 // Slice plan for the one-launch kernels: CS channels per block (whole groups, whole 16-byte vectors,
 // CS/VE a power of two <= 64) and the block size.  Largest slice that still gives >= ~256 blocks.
-struct SmallPlan { int CS, NT; };
+struct SmallPlan { int CS, NT, VS; };   // VS = lanes per pixel (power of two >= CS / VE)
 bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
   static const int max_hw = getenv("IDF_GN_SMALL_MAXHW") ? atoi(getenv("IDF_GN_SMALL_MAXHW")) : 4096;
   static const int want = getenv("IDF_GN_SMALL_BLOCKS") ? atoi(getenv("IDF_GN_SMALL_BLOCKS")) : 256;
@@ -577,15 +589,17 @@ bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
   int unit = cpg;                       // lcm(cpg, VE)
   while (unit % VE) unit += cpg;
   int best = 0;
+  if (C1 > 0 && (C1 % VE)) return false;         // a 16-byte vector must lie inside one of the two sources
+  auto lanes_for = [&](int cs) { int v = 1; while (v < cs / VE) v *= 2; return v; };
   for (int cs = unit; cs <= C; cs *= 2) {
-    const int vs = cs / VE;
-    if (C % cs || (vs & (vs - 1)) || vs > 64) continue;
-    if (C1 > 0 && (C1 % cs)) continue;           // a slice must lie inside one of the two sources
+    const int vs = lanes_for(cs);
+    if (C % cs || vs > 64) continue;
     if ((long)HW * vs > 1024L * SNV) break;
     if (!best || (long)B * (C / cs) >= want) best = cs;
   }
   if (!best) return false;
-  const int vectors = HW * (best / VE);
+  plan->VS = lanes_for(best);
+  const int vectors = HW * plan->VS;
   int nt = ((vectors + 1) / 2 + 63) / 64 * 64;
   if (nt < 64) nt = 64;
   if (nt > 1024) nt = 1024;
@@ -733,10 +747,10 @@ extern "C" int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IDF_F32)
     hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)x, (const float*)x2, C1, (float*)out, gamma, beta, film_t,
-                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
+                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale);
   else
     hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)out, gamma, beta,
-                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, act, sd, salt, thr, dscale);
+                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -761,12 +775,12 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
   static const int keep_env = getenv("IDF_GN_KEEP") ? atoi(getenv("IDF_GN_KEEP")) : 1;
-  const int nvt = idf_cdiv((long)HW * (sp.CS / VE), sp.NT);      // vectors per thread
+  const int nvt = idf_cdiv((long)HW * sp.VS, sp.NT);             // vectors per thread
   const bool keep = keep_env && nvt <= 4;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
                      (const T*)x2, C1, (const T*)dres, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
-                     dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, act, sd, salt, thr, dscale)
+                     dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale)
   if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else IDF_GN_BWD(float, 0); }
   else { if (keep) IDF_GN_BWD(bf16_t, 4); else IDF_GN_BWD(bf16_t, 0); }
 #undef IDF_GN_BWD

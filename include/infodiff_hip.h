@@ -141,7 +141,8 @@ int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out, const flo
                      const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc,
                      float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C,
                      int dtype, void* stream);
-int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, void* dx, void* dx2,
+int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, const void* dres2,
+                     void* dx, void* dx2,
                      const float* gamma, const float* beta,
                      const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                      const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,

@@ -455,7 +455,8 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
 template <typename T, int KEEP>
 __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, const T* __restrict__ x,
                                                      const T* __restrict__ x2, int C1,
-                                                     const T* __restrict__ dres, T* __restrict__ dx, T* __restrict__ dx2,
+                                                     const T* __restrict__ dres, const T* __restrict__ dres2,
+                                                     T* __restrict__ dx, T* __restrict__ dx2,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ film_t, const float* __restrict__ film_a,
                                                      int ld_t, int ld_a, const float* __restrict__ mean,
@@ -570,6 +571,12 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       if (dres) {                 // gradient arriving over the block's residual / shortcut branch
         float rv[VE];
         Vec16<T>::load(dres + e0, rv);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] += rv[e];
+      }
+      if (dres2) {                // ... and over a skip connection that branched off the same input
+        float rv[VE];
+        Vec16<T>::load(dres2 + e0, rv);
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] += rv[e];
       }
@@ -755,7 +762,8 @@ extern "C" int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out
   return IDF_OK;
 }
 
-extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, void* dx, void* dx2,
+extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, int C1, const void* dres, const void* dres2,
+                                void* dx, void* dx2,
                                 const float* gamma, const float* beta,
                                 const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                                 const float* rstd, const float* sc, const float* sh, float* dfilm_t, float* dfilm_a,
@@ -779,7 +787,7 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   const bool keep = keep_env && nvt <= 4;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
-                     (const T*)x2, C1, (const T*)dres, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
+                     (const T*)x2, C1, (const T*)dres, (const T*)dres2, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
                      dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale)
   if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else IDF_GN_BWD(float, 0); }
   else { if (keep) IDF_GN_BWD(bf16_t, 4); else IDF_GN_BWD(bf16_t, 0); }

@@ -90,13 +90,30 @@ class _UNetSkeleton(nn.Module):
         return x.to(self.ctx.act_dtype).contiguous(memory_format=torch.channels_last)
 
     def _run(self, x, block_call):
+        """block_call(layer, h, **kw).  While gradients are recorded the skip list holds ALIASES of each
+        tensor handed out by its down-path consumer (`want_alias`): the skip connection's gradient then
+        arrives at that consumer's first op and is added in-kernel instead of by an autograd add pass."""
         h = ops.fused_conv(x, self.head.weight, self.head.bias, self._cfg_head)
-        skips = [h]
+        alias_mode = torch.is_grad_enabled() and h.requires_grad
+        skips = []
         for layer in self.downblocks:
-            h = layer(h) if isinstance(layer, DownSample) else block_call(layer, h)
-            skips.append(h)
+            if alias_mode:
+                h, a = (layer(h, want_alias=True) if isinstance(layer, DownSample)
+                        else block_call(layer, h, want_alias=True))
+                skips.append(a)
+            else:
+                skips.append(h)
+                h = layer(h) if isinstance(layer, DownSample) else block_call(layer, h)
+        first = True
         for layer in self.middleblocks:
-            h = block_call(layer, h)
+            if first and alias_mode:
+                h, a = block_call(layer, h, want_alias=True)
+                skips.append(a)
+            else:
+                if first:
+                    skips.append(h)
+                h = block_call(layer, h)
+            first = False
         for layer in self.upblocks:
             if isinstance(layer, UpSample):
                 h = layer(h)
@@ -127,7 +144,7 @@ class UNet(_UNetSkeleton):
         x = self._prep(x)
         temb = self.time_embedding(t)
         batched_film(self._res_blocks(), temb, 't')
-        return self._run(x, lambda blk, h: blk(h, temb))
+        return self._run(x, lambda blk, h, **kw: blk(h, temb, **kw))
 
 
 class AuxiliaryUNet(_UNetSkeleton):
@@ -158,7 +175,7 @@ class AuxiliaryUNet(_UNetSkeleton):
         blocks = self._res_blocks()
         batched_film(blocks, temb, 't')
         batched_film(blocks, aemb, 'a')
-        return self._run(x, lambda blk, h: blk(h, temb, aemb))
+        return self._run(x, lambda blk, h, **kw: blk(h, temb, aemb, **kw))
 
 
 class Encoder(_UNetSkeleton):
@@ -186,7 +203,7 @@ class Encoder(_UNetSkeleton):
 
     def forward(self, x):
         x = self._prep(x)
-        h = self._run(x, lambda blk, hh: blk(hh))
+        h = self._run(x, lambda blk, hh, **kw: blk(hh, **kw))
         h = torch.flatten(h, start_dim=1).float()
         a = ops.linear(h, self.fc_a.weight, self.fc_a.bias)
         mu = ops.linear(a, self.fc_mu.weight, self.fc_mu.bias)

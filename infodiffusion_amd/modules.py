@@ -220,7 +220,11 @@ class DownSample(nn.Module):
         _xavier_all(self)
         self._cfg = _cfg(_Shadows(self.main), ops.S2, 9, _ACT_NONE)
 
-    def forward(self, x, temb=None, aemb=None):
+    def forward(self, x, temb=None, aemb=None, want_alias=False):
+        """want_alias: also return an alias of x for the skip connection (its gradient joins this conv's
+        data-gradient epilogue instead of an autograd add)."""
+        if want_alias:
+            return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, passthrough=1)
         return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg)
 
 
@@ -262,7 +266,8 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         gn = self.group_norm
-        qkv = ops.fused_conv(x, self._qkv.weight(), self._qkv.bias(), self._cfg_qkv, gn.weight, gn.bias)
+        qkv, x = ops.fused_conv(x, self._qkv.weight(), self._qkv.bias(), self._cfg_qkv, gn.weight, gn.bias,
+                                passthrough=1)      # the residual branch's gradient joins the GN backward
         o = ops.attention(qkv)
         return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x)
 
@@ -320,9 +325,10 @@ class _ResBase(nn.Module):
         return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
                               passthrough)
 
-    def _block1(self, x):
-        """(h, residual) of the block's first stage.  x may be the pair (h_prev, skip) of an up-path block:
-        the concatenation is then read in place by the two-source kernels instead of being materialised."""
+    def _block1(self, x, want_alias=False):
+        """(h, residual[, alias of x]) of the block's first stage.  x may be the pair (h_prev, skip) of an
+        up-path block: the concatenation is then read in place by the two-source kernels instead of being
+        materialised.  want_alias: a second alias of x for the skip connection that branches off here."""
         if isinstance(x, tuple):
             blk = self.block1
             if isinstance(self.shortcut, nn.Conv2d) and ops.block_entry_cat_ok(x[0], x[1], blk[-1].weight,
@@ -330,7 +336,10 @@ class _ResBase(nn.Module):
                 cfg = _cfg(self._sh_block1, ops.S1, 9, _ACT_SILU, self.p_drop, self.salt)
                 return ops.block_entry_cat(x[0], x[1], blk[-1], blk[0], self.shortcut, cfg, self._cfg_sc)
             x = torch.cat(x, dim=1)
-        h, x = self._gn_conv('block1', x, passthrough=True)     # x: the residual branch's gradient joins in block1
+        if want_alias:
+            h, x, alias = self._gn_conv('block1', x, passthrough=2)
+            return h, self._shortcut(x), alias
+        h, x = self._gn_conv('block1', x, passthrough=1)     # x: the residual branch's gradient joins in block1
         return h, self._shortcut(x)
 
     def _shortcut(self, x):
@@ -352,14 +361,15 @@ class ResBlock(_ResBase):
         _xavier_all(self)
         self._setup(dropout)
 
-    def forward(self, x, temb):
-        h, res = self._block1(x)
+    def forward(self, x, temb, want_alias=False):
+        h, res, *alias = self._block1(x, want_alias)
         ft = self._film.pop('t', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
         h = self._gn_conv('block2', h, film_t=ft, drop_site=1)
         h = self._gn_conv('block3', h, drop_site=2, residual=res)
-        return self.attn(h)
+        h = self.attn(h)
+        return (h, alias[0]) if want_alias else h
 
 
 class AuxResBlock(_ResBase):
@@ -378,8 +388,8 @@ class AuxResBlock(_ResBase):
         _xavier_all(self)   # also resets attn.proj to gain 1 (reference quirk 9)
         self._setup(dropout)
 
-    def forward(self, x, temb, aemb=None):
-        h, res = self._block1(x)
+    def forward(self, x, temb, aemb=None, want_alias=False):
+        h, res, *alias = self._block1(x, want_alias)
         ft = self._film.pop('t', None) if self._film else None
         fa = self._film.pop('a', None) if self._film else None
         if ft is None:
@@ -391,7 +401,7 @@ class AuxResBlock(_ResBase):
         h = self.attn(h)
         if self.use_crossattn:
             h = self.crossattn(h, aemb)
-        return h
+        return (h, alias[0]) if want_alias else h
 
 
 class ResBlock_encoder(_ResBase):
@@ -405,10 +415,11 @@ class ResBlock_encoder(_ResBase):
         _xavier_all(self)
         self._setup(dropout)
 
-    def forward(self, x):
-        h, res = self._block1(x)
+    def forward(self, x, want_alias=False):
+        h, res, *alias = self._block1(x, want_alias)
         h = self._gn_conv('block2', h, drop_site=1, residual=res)
-        return self.attn(h)
+        h = self.attn(h)
+        return (h, alias[0]) if want_alias else h
 
 
 def bind_context(net, ctx):

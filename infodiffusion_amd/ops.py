@@ -132,17 +132,18 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
     return y
 
 
-def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape):
-    """Data gradient w.r.t. the (activated) conv input of logical shape x_shape."""
+def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape, residual=None):
+    """Data gradient w.r.t. the (activated) conv input of logical shape x_shape (+ residual: a gradient
+    arriving over another branch of the same input, added in the epilogue)."""
     B, Cin, Hs, Ws = x_shape
     if mode_fwd == S2:
-        return conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, T2, taps, 0, Cin, (Hs, Ws))
+        return conv_raw(dy, w_dgrad, None, residual, None, None, None, 0, 0.0, T2, taps, 0, Cin, (Hs, Ws))
     if mode_fwd == UP2:
         up = conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, S1, taps, 0, Cin)
         out = empty_nhwc(B, Cin, Hs, Ws, dy.dtype, dy.device)
         call('idf_pool2_sum', _p(up), _p(out), B, Hs, Ws, Cin, _dt(dy), _st())
-        return out
-    return conv_raw(dy, w_dgrad, None, None, None, None, None, 0, 0.0, S1, taps, 0, Cin)
+        return out if residual is None else out + residual
+    return conv_raw(dy, w_dgrad, None, residual, None, None, None, 0, 0.0, S1, taps, 0, Cin)
 
 
 def conv_wgrad_raw(x, dy, sc, sh, seed, salt, p_drop, mode, taps, act):
@@ -247,7 +248,7 @@ def gn_fused_fwd_raw(x, gamma, beta, film_t, film_a, seed, salt, p_drop, act, x2
 
 
 def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None,
-                     dres=None, x2=None):
+                     dres=None, x2=None, dres2=None):
     """x2: two-source input (see gn_fused_fwd_raw); then the first result is the pair (dx, dx2)."""
     B, C1, H, W = x.shape
     C = C1 + (x2.shape[1] if x2 is not None else 0)
@@ -258,7 +259,7 @@ def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, see
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
     acc = _gn_acc(acc)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
-    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(x2), C1, _p(dres), _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
+    call('idf_gn_fused_bwd', _p(dA), _p(x), _p(x2), C1, _p(dres), _p(dres2), _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
          _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop),
          act, B, H * W, C, _dt(x), _st())
@@ -446,13 +447,14 @@ class _FusedConv(torch.autograd.Function):
         ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                               seed)
         if passthrough:
-            # second output = x itself: whatever gradient the block's residual / shortcut branch sends
-            # back arrives HERE and is added inside the GroupNorm backward kernel (no autograd add pass)
-            return y, x.detach()
+            # extra outputs = x itself (1 or 2 aliases): whatever gradient the block's residual / shortcut
+            # branch, or a skip connection branching off x, sends back arrives HERE and is added inside the
+            # GroupNorm backward kernel / the data-gradient epilogue (no autograd add pass)
+            return (y,) + tuple(x.detach() for _ in range(int(passthrough)))
         return y
 
     @staticmethod
-    def backward(ctx, dy, dxp=None):
+    def backward(ctx, dy, dxp=None, dxp2=None):
         x, a, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
         cfg, p_drop = ctx.cfg, ctx.p_drop
         act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
@@ -472,19 +474,31 @@ class _FusedConv(torch.autograd.Function):
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
         if need[0] or (act and (need[3] or need[5] or need[6])):
             w_dgrad = cfg['shadows'](x.dtype, True)[1]
-            dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
-            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
             dres_in = _nhwc(dxp.to(x.dtype)) if dxp is not None else None
+            dres2_in = _nhwc(dxp2.to(x.dtype)) if dxp2 is not None else None
+            if dres_in is None:
+                dres_in, dres2_in = dres2_in, None
+            if not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
+                dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
+                dres_in = None
+            else:
+                dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
+            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
             if act and gn_small_ok(x):
                 dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                          seed, salt, p_drop, act, gacc, dres_in)
+                                                          seed, salt, p_drop, act, gacc, dres_in, dres2=dres2_in)
             elif act:
+                if dres2_in is not None:
+                    dres_in = dres_in + dres2_in
                 dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, dres_in, gn_w, gn_b, film_t, film_a, mean, rstd,
                                                          sc, sh, seed, salt, p_drop, act, gacc)
             else:
-                dx = dA if dres_in is None else dA + dres_in
-        elif dxp is not None and need[0]:
-            dx = dxp
+                dx = dA
+                for extra in (dres_in, dres2_in):
+                    if extra is not None:
+                        dx = dx + extra
+        elif need[0] and (dxp is not None or dxp2 is not None):
+            dx = dxp if dxp2 is None else (dxp2 if dxp is None else dxp + dxp2)
         if ctx.has_res and need[7]:
             dres = dy
         return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None
@@ -492,15 +506,16 @@ class _FusedConv(torch.autograd.Function):
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None,
                passthrough=False):
-    """passthrough=True returns (y, x'): x' aliases x, and gradients sent to x' (the residual / shortcut
-    branch of a ResBlock) are added to dx inside this op's GroupNorm backward kernel."""
+    """passthrough = 1 / 2 returns (y, x') / (y, x', x''): the extra outputs alias x, and gradients sent to
+    them (the residual / shortcut branch of a ResBlock, a skip connection) are added to dx inside this
+    op's GroupNorm backward kernel (or its data-gradient epilogue)."""
     if passthrough and os.environ.get('IDF_PASSTHROUGH', '1') == '0':
-        return fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed), x
+        return (fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed),) + (x,) * int(passthrough)
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
     slots = None
     if torch.is_grad_enabled():
         slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
-    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, passthrough)
+    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, int(passthrough))
 
 
 # ------------------------------------------- ResBlock entry on a skip concatenation

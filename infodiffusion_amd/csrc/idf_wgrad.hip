@@ -218,157 +218,6 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   }
 }
 
-
-// ---- all nine taps in one block: 64 couts x 32 cins x 3x3 (stride 1).  The input tile carries a one-pixel
-// halo in BOTH directions ((R+2) x (W+2) pixels x 32 channels, pitch 96 B: eight consecutive pixels x 32 B
-// tile the 64 banks), dy is staged once for all taps: 142 FLOP per staged byte instead of 94, and no
-// kernel-row blocks re-reading the same a / dy tiles.
-constexpr int PX = 48;                    // input-tile pixel pitch in elements (32 channels + pad)
-
-// BIG: 256-pixel tiles (R*W = 256) -- twice the MFMA work per staged tile / per load round trip.
-template <bool BIG>
-__device__ __forceinline__ void wgrad9_block(const WgP& p, int bx, const int by) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int W = p.W, R = p.R, WH = W + 2;
-  const int npix_h = (R + 2) * WH;
-  const int KT = R * W;
-  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Ds = Xs + (size_t)npix_h * PX;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = (bx % p.c_tiles) * 32, n0 = (bx / p.c_tiles) * 64;
-  const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 16;
-  const int tiles_per_img = p.H / R;
-  const int t_beg = by * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
-
-  f32x4_t acc[3][3][2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[a][b][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int v4 = tid & 3, v8 = tid & 7;
-  float dbs[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
-  const bool do_db = p.db != nullptr && c0 == 0;
-  const bool cvalid = (c0 + v4 * 8) < p.Cin, nvalid = (n0 + v8 * 8) < p.Cout;
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-
-  constexpr int XV = BIG ? 7 : 5, DV = BIG ? 8 : 4;
-  uint4 xreg[XV], dreg[DV];
-  const bf16_t* asrc = p.a + c0;
-  int apitch = p.Cin;
-  if (p.a2) {
-    if (c0 < p.C1) apitch = p.C1;
-    else { asrc = p.a2 + (c0 - p.C1); apitch = p.Cin - p.C1; }
-  }
-  auto load_tile = [&](int t) {
-    const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
-#pragma unroll
-    for (int k = 0; k < XV; ++k) {
-      int idx = tid + k * 256;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (idx < npix_h * 4) {
-        int pix = idx >> 2;
-        int hy = pix / WH, hx = pix - hy * WH;
-        int iy = oy0 + hy - 1, ix = hx - 1;
-        if (cvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
-          val = *reinterpret_cast<const uint4*>(asrc + ((size_t)(b * p.H + iy) * W + ix) * apitch + v4 * 8);
-      }
-      xreg[k] = val;
-    }
-#pragma unroll
-    for (int k = 0; k < DV; ++k) {
-      int idx = tid + k * 256;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (idx < KT * 8 && nvalid)
-        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + (idx >> 3)) * p.Cout + n0 + v8 * 8);
-      dreg[k] = val;
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int k = 0; k < XV; ++k) {
-      int idx = tid + k * 256;
-      if (idx < npix_h * 4) *reinterpret_cast<uint4*>(Xs + (size_t)(idx >> 2) * PX + v4 * 8) = xreg[k];
-    }
-#pragma unroll
-    for (int k = 0; k < DV; ++k) {
-      int idx = tid + k * 256;
-      if (idx < KT * 8) {
-        *reinterpret_cast<uint4*>(Ds + (size_t)(idx >> 3) * PITCH + v8 * 8) = dreg[k];
-        if (do_db) {
-          uint32_t w4[4] = {dreg[k].x, dreg[k].y, dreg[k].z, dreg[k].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            dbs[2 * e] += __uint_as_float(w4[e] << 16);
-            dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
-          }
-        }
-      }
-    }
-  };
-
-  if (t_beg < t_end) load_tile(t_beg);
-  for (int t = t_beg; t < t_end; ++t) {
-    store_tile();
-    __syncthreads();
-    if (t + 1 < t_end) load_tile(t + 1);
-    for (int ks = 0; ks < KT; ks += 32) {
-      bf16x8_t nf[2];
-      const int pixA = ks + 4 * g + q, pixB = pixA + 16;
-      {
-        const bf16_t* d0 = Ds + (size_t)pixA * PITCH + wn0 + 4 * pp;
-        const bf16_t* d1 = Ds + (size_t)pixB * PITCH + wn0 + 4 * pp;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
-      }
-      const int oyA = pixA / W, oxA = pixA - oyA * W, oyB = pixB / W, oxB = pixB - oyB * W;
-      const bf16_t* x0 = Xs + (size_t)(oyA * WH + oxA) * PX + wc0 + 4 * pp;
-      const bf16_t* x1 = Xs + (size_t)(oyB * WH + oxB) * PX + wc0 + 4 * pp;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int off = (ky * WH + kx) * PX;
-          bf16x8_t cf = mkfrag(tr_read(x0 + off), tr_read(x1 + off));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[ky][kx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf, acc[ky][kx][i], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-  }
-
-  const int c = c0 + wc0 + (lane & 15);
-  if (c < p.Cin) {
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
-            if (n < p.Cout) atomicAdd(p.dW + ((size_t)n * 9 + ky * 3 + kx) * p.Cin + c, acc[ky][kx][i][r]);
-          }
-  }
-  if (do_db) {
-    float* red = reinterpret_cast<float*>(smem);   // [32][64]
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
-    __syncthreads();
-    if (tid < 64 && n0 + tid < p.Cout) {
-      float s = 0.f;
-      for (int k = 0; k < 32; ++k) s += red[k * 64 + tid];
-      atomicAdd(p.db + n0 + tid, s);
-    }
-  }
-}
-
 template <int KW, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
   wgrad_block<KW, MODE>(p, blockIdx.x, blockIdx.y);
@@ -380,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
 // problem can use fewer pixel splits (= fewer atomic bytes) because the others fill the chip.
 struct WgDesc {
   WgP p;
-  int blk0, gx, gy, xcd;   // xcd & 1: blocks [blk0, blk0 + gx * roundup8(gy)) in XCD-major order; xcd & 2: nine-tap blocks
+  int blk0, gx, gy, xcd;   // xcd = 1: blocks [blk0, blk0 + gx * roundup8(gy)) in XCD-major order
 };
 
 template <int KW, int MODE>
@@ -394,37 +243,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
   const WgDesc* d = tab + lo;
   const WgP p = d->p;
   const int local = bid - d->blk0, gx = d->gx;
-  const bool nine = KW == 3 && MODE == 0 && (d->xcd & 2);
-  if (d->xcd & 1) {
+  if (d->xcd) {
     // workgroups go round-robin over the 8 XCDs: give XCD x the pixel splits x, x + 8, ... and ALL the
     // (kernel row, cout tile, cin tile) blocks of each, so the gx blocks that read the same a / dy tiles
     // share one L2 instead of fetching them over the fabric gx times
     const int x = local & 7, j = local >> 3;
     const int by = x + 8 * (j / gx);
     if (by >= d->gy) return;
-    if (nine) { if (d->xcd & 4) wgrad9_block<true>(p, j % gx, by); else wgrad9_block<false>(p, j % gx, by); }
-    else wgrad_block<KW, MODE>(p, j % gx, by);
+    wgrad_block<KW, MODE>(p, j % gx, by);
   } else {
     if (local >= gx * d->gy) return;      // alignment padding
-    if (nine) { if (d->xcd & 4) wgrad9_block<true>(p, local % gx, local / gx); else wgrad9_block<false>(p, local % gx, local / gx); }
-    else wgrad_block<KW, MODE>(p, local % gx, local / gx);
+    wgrad_block<KW, MODE>(p, local % gx, local / gx);
   }
 }
 
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
-            int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
-            bool nine = false, bool big = false) {
+            int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
              Cout, taps, mode);
-  int R = (mode == 1 ? 64 : (big ? 256 : 128)) / W;
+  int R = (mode == 1 ? 64 : 128) / W;
   if (R > H) R = H;
-  if (big) {
-    if (R < 1 || (H % R) || ((R * W) % 32) || (R + 2) * (W + 2) * 4 > 7 * 256 || R * W > 256)
-      IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable (256-pixel tiles)", H, W);
-  } else if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
+  if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not tileable", H, W);
   if (a2 && (C1 <= 0 || C1 >= Cin || (C1 % 64) || mode != 0))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: two-source input needs C1 %% 64 == 0 (C1 %d) and stride 1", C1);
@@ -434,10 +276,10 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
   p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
   p.tiles = B * (H / R);
-  p.c_tiles = nine ? idf_cdiv(Cin, 32) : idf_cdiv(Cin, 64);
+  p.c_tiles = idf_cdiv(Cin, 64);
   p.n_tiles = idf_cdiv(Cout, 64);
   const int kh = taps == 9 ? 3 : 1;
-  gx = nine ? p.c_tiles * p.n_tiles : p.c_tiles * p.n_tiles * kh;
+  gx = p.c_tiles * p.n_tiles * kh;
   if (target_blocks <= 0) {
     // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
     // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
@@ -455,8 +297,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.tiles_per_blk = idf_cdiv(p.tiles > 0 ? p.tiles : 1, split);
   gy = idf_cdiv(p.tiles, p.tiles_per_blk);
   const int sx = mode == 1 ? 2 : 1;
-  if (nine) lds = (size_t)(R + 2) * (W + 2) * PX * 2 + (size_t)R * W * PITCHB;
-  else lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
+  lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
   if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
   return IDF_OK;
 }
@@ -508,19 +349,15 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   size_t lds;
   static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
   if (forced > 0) target_blocks = forced;
-  static const int nine_env = getenv("IDF_WGRAD_NINE") ? atoi(getenv("IDF_WGRAD_NINE")) : 1;
-  const bool nine = nine_env && taps == 9 && mode == 0 && W <= 64 && (Cin % 32) == 0;
-  static const int big_env = getenv("IDF_WGRAD_BIG") ? atoi(getenv("IDF_WGRAD_BIG")) : 1;
-  const bool big = big_env && nine && H * W >= 256 && (H % (256 / W)) == 0 && (256 / W + 2) * (W + 2) * 4 <= 7 * 256;
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128,
-                   a2, C1, nine, big);
+                   a2, C1);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;
-  d.xcd = ((xcd && (blk0 % 8) == 0 && d.gy >= 8) ? 1 : 0) | (nine ? 2 : 0) | (big ? 4 : 0);
+  d.xcd = (xcd && (blk0 % 8) == 0 && d.gy >= 8) ? 1 : 0;
   memcpy((char*)host_table + (size_t)index * sizeof(WgDesc), &d, sizeof(d));
-  *blocks_out = (d.xcd & 1) ? d.gx * ((d.gy + 7) / 8 * 8) : d.gx * d.gy;
-  if (!(d.xcd & 1) && (*blocks_out % 8)) *blocks_out += 8 - *blocks_out % 8;     // keep later entries 8-aligned
+  *blocks_out = d.xcd ? d.gx * ((d.gy + 7) / 8 * 8) : d.gx * d.gy;
+  if (!d.xcd && (*blocks_out % 8)) *blocks_out += 8 - *blocks_out % 8;     // keep later entries 8-aligned
   *lds_out = (int)lds;
   return IDF_OK;
 }

@@ -6,6 +6,8 @@ missing or a kernel rejects its arguments, this raises.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch ships, not load a second one
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libinfodiff_hip.so')
 

@@ -1,6 +1,7 @@
 // 3x3 convolution for bf16 NHWC activations on MFMA (gfx950), halo-tile form.
 // Forward and data-gradient of every stride-1-shaped 3x3 conv on the path:
 //   MODE 0  plain stride-1 conv (also the data gradient of one, with the flipped shadow)
+//   MODE 1  stride-2 conv (DownSample, modules.py:63-75): the halo tile holds (2R+1) x (2W+1) source pixels
 //   MODE 2  nearest-x2 upsample fused into the read (UpSample, modules.py:89-92)
 //   MODE 3  zero-stuffed x2 input = transposed stride-2 (data gradient of DownSample)
 //
@@ -32,7 +33,7 @@ struct C3P {
   unsigned wh_magic;    // (pix * wh_magic) >> 16 == pix / (W + 2*halo) for every halo pixel index (checked on the host)
 };
 
-constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048;   // (R+2)*(W+2)*4 budget per block size
+constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 = 1536;   // (R+2)*(W+2)*4 budget per block size
 constexpr int CK = 32;
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
@@ -51,8 +52,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   constexpr int WV = (BN * TAPS * 4 + NT - 1) / NT; // weight vectors per thread per chunk
   constexpr int BM = NWM * TM * 16;           // pixels per block
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int W = p.W, R = p.R, WH = W + 2 * HALO;
-  const int npix_h = (R + 2 * HALO) * WH;
+  constexpr int ST = MODE == 1 ? 2 : 1;       // output stride in the staged tile
+  const int W = p.W, R = p.R;
+  const int WH = MODE == 1 ? 2 * W + 1 : W + 2 * HALO;
+  const int npix_h = (MODE == 1 ? 2 * R + 1 : R + 2 * HALO) * WH;
   const int KT = R * W;                       // valid pixels of the tile (<= BM)
   unsigned char* Xs = smem;                   // [npix_h][64 B]
   unsigned char* Ws = smem + (size_t)npix_h * 64;   // [TAPS][BN][64 B]
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     int pl = wm0 + i * 16 + fr;
     if (pl >= KT) pl = 0;
     int oy = pl >> p.wshift, ox = pl & (W - 1);
-    hbase[i] = oy * WH + ox;
+    hbase[i] = ST * (oy * WH + ox);
   }
   int wbase[TN];
 #pragma unroll
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     wbase[a] = n * 64 + swz(n, fq) * 16;
   }
 
-  constexpr int HV = (NWM == 4 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256) / NT;   // halo vectors per thread
+  constexpr int HV = (NWM == 4 ? HALO_VEC_MAX_512 : (MODE == 1 ? HALO_VEC_MAX_S2 : HALO_VEC_MAX_256)) / NT;   // halo vectors per thread
   f32x4_t acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     if (idx < npix_h * 4) {
       int pix = idx >> 2, ch = idx & 3;
       int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
-      int iy = oy0 + hy - HALO, ix = hx - HALO;
-      bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+      int iy = ST * oy0 + hy - HALO, ix = hx - HALO;
+      bool ok = (unsigned)iy < (unsigned)(ST * p.H) && (unsigned)ix < (unsigned)(ST * W);
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
-      if (MODE != 0) { iy >>= 1; ix >>= 1; }
+      if (MODE >= 2) { iy >>= 1; ix >>= 1; }
       if (ok) hoff[k] = DUAL ? (((b * p.Hs + iy) * p.Ws + ix) * 4 + ch)           // pixel index, vector slot
                              : ((b * p.Hs + iy) * p.Ws + ix) * p.Cin + ch * 8;
       hlds[k] = pix * 64 + swz(pix, ch) * 16;
@@ -246,7 +249,8 @@ inline unsigned wh_magic(int WH, int npix) {
 
 template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false>
 void launch(const C3P& p, hipStream_t st) {
-  size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
+  size_t lds = ((MODE == 1 ? (size_t)(2 * p.R + 1) * (2 * p.W + 1) : (size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2))) +
+                KS * KS * BN) * 64;
   size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
   auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL>;
@@ -256,20 +260,21 @@ void launch(const C3P& p, hipStream_t st) {
 
 }  // namespace
 
-// mode: 0 stride 1, 2 nearest-x2-upsampled input, 3 zero-stuffed x2 input (transposed stride 2).
+// mode: 0 stride 1, 1 stride 2 (H, W <= 32 out), 2 nearest-x2-upsampled input, 3 zero-stuffed x2 input
+// (transposed stride 2).
 // H, W = OUTPUT dims.  Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (the
 // caller falls back to idf_conv2d_fwd).
 extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
                                 int H, int W, int Cin, int Cout, int mode, void* stream) {
-  if ((mode != 0 && mode != 2 && mode != 3) || (Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 ||
-      (mode != 0 && ((H | W) & 1)))
+  if (mode < 0 || mode > 3 || (Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (mode >= 2 && ((H | W) & 1)) ||
+      (mode == 1 && (W > 32 || Cout <= 32)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: B%d H%d W%d Cin%d Cout%d mode%d not covered", B, H, W, Cin, Cout, mode);
   if (B == 0) return IDF_OK;
   C3P p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
   p.x2 = nullptr; p.C1 = Cin;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.Hs = mode ? H / 2 : H; p.Ws = mode ? W / 2 : W;
+  p.Hs = mode == 1 ? 2 * H : (mode ? H / 2 : H); p.Ws = mode == 1 ? 2 * W : (mode ? W / 2 : W);
   int ws = 0;
   while ((1 << ws) < W) ++ws;
   p.wshift = ws;
@@ -280,6 +285,7 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   // 512-thread blocks (256 pixels share one weight slab) once the grid still covers the chip
   if ((M / 256) * idf_cdiv(Cout, 64) >= 256 && H * W >= 256 && Cout > 32) BM = 256;
   if (force_bm && H * W >= force_bm && !(force_bm == 256 && Cout <= 32)) BM = force_bm;
+  if (mode == 1) BM = 64;                       // the stride-2 halo tile is 4x the output tile
   int R;
   for (;;) {
     R = BM / W;
@@ -289,9 +295,11 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
     if (BM == 256 && (R + 2) * (W + 2) * 4 > HALO_VEC_MAX_512) { BM = 128; continue; }
     break;
   }
-  if ((R + 2) * (W + 2) * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
+  const int hrows = mode == 1 ? 2 * R + 1 : R + 2, hcols = mode == 1 ? 2 * W + 1 : W + 2;
+  if (hrows * hcols * 4 > (BM == 256 ? HALO_VEC_MAX_512 : (mode == 1 ? HALO_VEC_MAX_S2 : HALO_VEC_MAX_256)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
   p.R = R; p.tiles_per_img = H / R;
-  p.wh_magic = wh_magic(W + 2, (R + 2) * (W + 2));
+  p.wh_magic = wh_magic(hcols, hrows * hcols);
   if (!p.wh_magic || (long)B * p.Hs * p.Ws * Cin >= (1L << 31) || (long)Cout * 9 * Cin >= (1L << 31))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
@@ -303,6 +311,7 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
     else { if (BM == 256) launch<MODE, 4, 64, 4>(p, st); else if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); } \
   } while (0)
   if (mode == 0) IDF_C3_LAUNCH(0);
+  else if (mode == 1) launch<1, 2, 64>(p, st);
   else if (mode == 2) IDF_C3_LAUNCH(2);
   else IDF_C3_LAUNCH(3);
 #undef IDF_C3_LAUNCH

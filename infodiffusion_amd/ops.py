@@ -85,6 +85,16 @@ def out_hw(mode, H, W):
     return H, W
 
 
+def _halo_fits_s2(H, W):
+    """Stride-2 forward through the halo kernel: 64-pixel output tiles, (2R+1) x (2W+1) staged pixels."""
+    if W > 32:
+        return False
+    R = max(1, min(H, 64 // W))
+    while H % R:
+        R -= 1
+    return (2 * R + 1) * (2 * W + 1) * 4 <= 1536
+
+
 def _halo_fits(H, W, B, Cout):
     BM = 128 if (B * H * W // 128 * -(-Cout // 64) >= 256 and H * W >= 128) else 64
     if B * H * W // 256 * -(-Cout // 64) >= 256 and H * W >= 256 and Cout > 32:
@@ -101,8 +111,11 @@ def _halo_fits(H, W, B, Cout):
 
 def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
     """True when conv_raw routes to conv3x3_halo_bf16 (idf_conv3x3.hip)."""
-    return (dtype == torch.bfloat16 and taps == 9 and act == 0 and mode != S2 and Cin % 32 == 0
-            and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _halo_fits(Ho, Wo, B, Cout))
+    if dtype != torch.bfloat16 or taps != 9 or act != 0 or Cin % 32 or not (4 <= Wo <= 128) or (Wo & (Wo - 1)):
+        return False
+    if mode == S2:
+        return Cout > 32 and _halo_fits_s2(Ho, Wo)
+    return _halo_fits(Ho, Wo, B, Cout)
 
 
 _CONV1X1 = os.environ.get('IDF_CONV1X1', '1') != '0'
@@ -125,7 +138,7 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
         return y
     if uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
         call('idf_conv3x3_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout,
-             {S1: 0, UP2: 2, T2: 3}[mode], _st())
+             {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], _st())
         return y
     call('idf_conv2d_fwd', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), _p(sc), _p(sh), _p(seed),
          salt, float(p_drop), B, Hs, Ws, Cin, Ho, Wo, Cout, mode, taps, act, _dt(x), _st())

@@ -607,7 +607,8 @@ bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
   if (!best) return false;
   // big batches of big samples (DDIM sampling at B = 256): slices this narrow (<= 32-byte segments) run at
   // ~2.4 TB/s, the fully coalesced three-launch path at ~4 TB/s, and launch costs no longer matter
-  if (best * (VE == 8 ? 2 : 4) <= 32 && (long)B * HW * C * (VE == 8 ? 2 : 4) >= (64L << 20)) return false;
+  // (not for a two-source input: there the alternative is materialising the concatenation first)
+  if (C1 == 0 && best * (VE == 8 ? 2 : 4) <= 32 && (long)B * HW * C * (VE == 8 ? 2 : 4) >= (64L << 20)) return false;
   plan->VS = lanes_for(best);
   const int vectors = HW * plan->VS;
   int nt = ((vectors + 1) / 2 + 63) / 64 * 64;

@@ -94,6 +94,17 @@ class FusedClipAdamW(torch.optim.Optimizer):
         torch.autograd.graph.increment_version([p for p, _, _, _ in items])
         return None
 
+    def refresh_lr(self):
+        """Push the param group's learning rate to the device scalar the kernels read.  step() does it when
+        it runs in Python; call this after an LR-scheduler step when step() is replayed from a hipGraph."""
+        if self._lr is not None:
+            lr = self.param_groups[0]['lr']
+            if torch.is_tensor(lr):
+                self._lr.copy_(lr.reshape(1))
+            else:
+                self._lr.fill_(float(lr))
+                self._lr_host = lr
+
     def total_norm(self):
         """Gradient norm before clipping of the last step (device scalar)."""
         return self._state[4]

@@ -20,6 +20,7 @@ import torch.distributed as dist
 from infodiffusion_amd.data import get_dataset, get_dataset_config
 from infodiffusion_amd.dist import GradSync, shard_range
 from infodiffusion_amd.optim import FusedClipAdamW
+from infodiffusion_amd.trainer import GraphedTrainStep
 from infodiffusion_amd.models import Diff, InfoDiff
 from infodiffusion_amd.sampling import DiffusionProcess, LatentDiffusionProcess, TwoPhaseDiffusionProcess
 from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter,
@@ -67,6 +68,7 @@ def parse_args(argv=None):
     # extras
     p.add_argument('--act_dtype', default='fp32', choices=['fp32', 'bf16'])
     p.add_argument('--steps_per_epoch', type=int, default=100)
+    p.add_argument('--graph', type=int, default=1, help='replay the train step from a captured hipGraph')
     return p.parse_args(argv)
 
 
@@ -110,23 +112,18 @@ def _fit(args, model, batches, world, rank, latent=False):
         sync.broadcast_parameters()
     losses = AverageMeter('Loss', ':.4f')
     progress = ProgressMeter(args.epochs, [losses], prefix='Epoch ')
+    step = GraphedTrainStep(model, args, opt, sync, use_graph=bool(args.graph))
     for epoch in range(args.epochs):
         total, n = torch.zeros((), device=model.device), 0      # accumulated on the device: no per-step host sync
         for data in batches:
             x = data[0] if isinstance(data, (tuple, list)) else data
-            x = x.to(device=model.device)
-            loss = model.loss_fn(args=args, x=x, curr_epoch=epoch)
-            opt.zero_grad()
-            loss.backward()
-            if sync is not None:
-                sync.all_reduce_grads()
-            opt.step()                                  # global-norm clip at 1.0 + AdamW
-            total += loss.detach()
+            total += step(x.to(device=model.device), epoch)     # loss_fn, backward, [all-reduce], clip + AdamW
             n += 1
         losses.update(float(total) / max(n - 1, 1))   # reference divides by the last index (run.py:205)
         if rank == 0:
             progress.display(epoch)
         warm.step()
+        opt.refresh_lr()        # the captured optimizer step reads the rate from device memory
         losses.reset()
         if (epoch + 1) % args.save_epochs == 0 and rank == 0:
             save_model(args, epoch + 1, model, latent)

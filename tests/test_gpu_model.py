@@ -561,3 +561,36 @@ def test_up_block_reads_skip_pair_in_place():
     for n in ga:
         if gb[n].abs().max() > 1e-3:
             assert rel(ga[n], gb[n]) < 2e-2, n
+
+
+def test_graphed_train_step_replays_and_follows_lr_changes():
+    import numpy as np
+    """trainer.GraphedTrainStep: two eager warm-up steps, then the whole step (loss_fn, zero_grad, backward,
+    deferred weight gradients, fused clip + AdamW) replayed from one hipGraph; every replay draws fresh
+    noise / dropout, updates the weights, and reads the learning rate from device memory (refresh_lr)."""
+    import oracle.infodiff_oracle as O
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    model, args, sd = make_infodiff(cfg, DEV, torch.bfloat16, 'manifest_fmnist')
+    model.train()
+    opt = FusedClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    step = GraphedTrainStep(model, args, opt)
+    x = gold('model_fmnist')['x'].to(DEV)
+    w = model.backbone.head.weight
+    losses, norms = [], []
+    for i in range(7):
+        losses.append(float(step(x, 0)))
+        norms.append(float(w.detach().float().norm()))
+    assert step.graph is not None                      # captured at step 3
+    assert all(np.isfinite(losses)) and len(set(losses)) == len(losses)      # fresh randomness per replay
+    assert len(set(norms)) == len(norms)               # weights move every step (shadows re-packed in-graph)
+    assert losses[-1] < losses[0]
+    opt.param_groups[0]['lr'] = 0.0
+    opt.param_groups[0]['weight_decay'] = 0.0
+    opt.refresh_lr()
+    before = w.detach().clone()
+    step(x, 0)
+    assert torch.equal(w.detach(), before)             # lr = 0 reached the replayed kernels
+    short = x[:2]                                      # a short last batch runs eagerly, same optimizer
+    assert np.isfinite(float(step(short, 0)))

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // registers; likewise its backward (S1/S2 sums, k1/k0, FiLM / gamma / beta gradients, dx).
 // Groups are independent, so a sample is cut along channels into slices of whole groups
 // (grid = B x C/CS): one block per sample would leave 7/8 of the CUs idle at B = 32.
-constexpr int SNV = 8;        // 16-byte vectors per thread
+constexpr int SNV = 8;        // 16-byte vectors per thread (template NV: 8, or 16 for the largest samples)
+constexpr int SNV_MAX = 16;
 
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
@@ -352,7 +353,7 @@ __device__ __forceinline__ void small_reduce(float (&s)[VE], float (&q)[VE], flo
   }
 }
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, const T* __restrict__ x2, int C1,
                                                      T* __restrict__ out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -381,16 +382,19 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
     if (sc0 < C1) spitch = C1;
     else { src = x2; spitch = C - C1; sc0 -= C1; }
   }
-  float xv[SNV][VE], s[VE], q[VE];
+  uint4 xr[NV];                 // the sample's slice stays in registers, packed
+  float s[VE], q[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) s[e] = q[e] = 0.f;
 #pragma unroll
-  for (int k = 0; k < SNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
     if (p < HW && live) {
-      Vec16<T>::load(src + ((size_t)b * HW + p) * spitch + sc0, xv[k]);
+      xr[k] = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
+      float xv[VE];
+      unpack16<T>(xr[k], xv);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) { s[e] += xv[k][e]; q[e] += xv[k][e] * xv[k][e]; }
+      for (int e = 0; e < VE; ++e) { s[e] += xv[e]; q[e] += xv[e] * xv[e]; }
     }
   }
   small_reduce<VE>(s, q, red, vs, CS, v);
@@ -429,22 +433,24 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
     shv[e] = live ? cof[(v * VE + e) * 2 + 1] : 0.f;
   }
 #pragma unroll
-  for (int k = 0; k < SNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
     if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
       const int l0 = (int)(e0 & 7);
+      float xv[VE];
+      unpack16<T>(xr[k], xv);
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
-        float u = xv[k][e] * scv[e] + shv[e];
+        float u = xv[e] * scv[e] + shv[e];
         if (act == 2) {
           u = silu_f(u);
           if (seed) u = idf_keep_h(h, l0 + e, thr) ? u * dscale : 0.f;
         }
-        xv[k][e] = u;
+        xv[e] = u;
       }
-      Vec16<T>::store(out + e0, xv[k]);
+      Vec16<T>::store(out + e0, xv);
     }
   }
 }
@@ -489,9 +495,9 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     if (sc0 < C1) spitch = C1;
     else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
   }
-  constexpr int NV = KEEP > 0 ? KEEP : SNV;
+  constexpr int NV = KEEP > 0 ? KEEP : (KEEP < 0 ? SNV_MAX : SNV);
   uint4 xr[NV];                 // packed x stays in registers
-  float duk[KEEP > 0 ? KEEP : 1][VE];
+  float duk[KEEP > 0 ? KEEP : 1][VE];      // KEEP < 0: SNV_MAX vectors per thread, du recomputed
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
@@ -601,7 +607,7 @@ bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
   for (int cs = unit; cs <= C; cs *= 2) {
     const int vs = lanes_for(cs);
     if (C % cs || vs > 64) continue;
-    if ((long)HW * vs > 1024L * SNV) break;
+    if ((long)HW * vs > 1024L * SNV_MAX) break;
     if (!best || (long)B * (C / cs) >= want) best = cs;
   }
   if (!best) return false;
@@ -756,12 +762,14 @@ extern "C" int idf_gn_fused_fwd(const void* x, const void* x2, int C1, void* out
   size_t lds = ((size_t)(sp.NT / 64) * sp.CS * 2 + sp.CS * 2 + G * 2 + sp.CS * 2) * sizeof(float);
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_small_fwd<float>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const float*)x, (const float*)x2, C1, (float*)out, gamma, beta, film_t,
-                       film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale);
-  else
-    hipLaunchKernelGGL(gn_small_fwd<bf16_t>, dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)out, gamma, beta,
-                       film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale);
+  const int nvt_f = idf_cdiv((long)HW * sp.VS, sp.NT);           // vectors per thread
+#define IDF_GN_FWD(T, N)                                                                                          \
+  hipLaunchKernelGGL((gn_small_fwd<T, N>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)x, (const T*)x2, C1, \
+                     (T*)out, gamma, beta, film_t, film_a, ld_t, ld_a, eps, mean, rstd, sc, sh, HW, C, sp.CS, sp.VS, \
+                     act, sd, salt, thr, dscale)
+  if (dtype == IDF_F32) { if (nvt_f > SNV) IDF_GN_FWD(float, SNV_MAX); else IDF_GN_FWD(float, SNV); }
+  else { if (nvt_f > SNV) IDF_GN_FWD(bf16_t, SNV_MAX); else IDF_GN_FWD(bf16_t, SNV); }
+#undef IDF_GN_FWD
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -793,8 +801,8 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
                      (const T*)x2, C1, (const T*)dres, (const T*)dres2, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
                      dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale)
-  if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else IDF_GN_BWD(float, 0); }
-  else { if (keep) IDF_GN_BWD(bf16_t, 4); else IDF_GN_BWD(bf16_t, 0); }
+  if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else if (nvt > SNV) IDF_GN_BWD(float, -1); else IDF_GN_BWD(float, 0); }
+  else { if (keep) IDF_GN_BWD(bf16_t, 4); else if (nvt > SNV) IDF_GN_BWD(bf16_t, -1); else IDF_GN_BWD(bf16_t, 0); }
 #undef IDF_GN_BWD
   IDF_CHECK_LAUNCH();
   return IDF_OK;

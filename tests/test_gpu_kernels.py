@@ -327,3 +327,49 @@ def test_wgrad_bf16_batched_matches_single_launches():
     for (rW, rb), (oW, ob) in zip(refs, outs):
         assert arena.holds(oW) and arena.holds(ob)
         assert rel(oW.cpu(), rW.cpu()) < 1e-5 and rel(ob.cpu(), rb.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('C1,C2,H', [(128, 128, 16), (128, 64, 32), (64, 64, 64), (128, 64, 64), (256, 256, 8)])
+def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
+    """The (x, x2) pair read in place == the same kernels on the materialised concatenation: one-launch
+    GroupNorm forward / backward (dx split into dx1, dx2), 1x1 conv, and the 1x1 weight gradient."""
+    from infodiffusion_amd.grad_arena import GradArena, slot_of
+    B, C = 3, C1 + C2
+    x1 = rnd(1, B, C1, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    x2 = rnd(2, B, C2, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL)
+    gam, bet = (1 + 0.1 * rnd(3, C)).to(DEV), (0.1 * rnd(4, C)).to(DEV)
+    assert ops.gn_small_ok(x1, x2) and ops.gn_small_ok(xc)
+    a2, m2, r2, sc2, sh2 = ops.gn_fused_fwd_raw(x1, gam, bet, None, None, None, 0, 0.0, 2, x2=x2)
+    a1, m1, r1, sc1, sh1 = ops.gn_fused_fwd_raw(xc, gam, bet, None, None, None, 0, 0.0, 2)
+    assert torch.equal(a1, a2) and torch.equal(m1, m2) and torch.equal(sc1, sc2)
+    dA = rnd(5, B, C, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dres = rnd(6, B, C, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    (dx1, dx2), dg2, db2, _, _ = ops.gn_fused_bwd_raw(dA, x1, gam, bet, None, None, m1, r1, sc1, sh1, None, 0, 0.0, 2,
+                                                     dres=dres, x2=x2)
+    dxc, dg1, db1, _, _ = ops.gn_fused_bwd_raw(dA, xc, gam, bet, None, None, m1, r1, sc1, sh1, None, 0, 0.0, 2,
+                                               dres=dres)
+    assert torch.equal(dx1, dxc[:, :C1]) and torch.equal(dx2, dxc[:, C1:])
+    assert rel(dg2, dg1) < 1e-6 and rel(db2, db1) < 1e-6
+    # 1x1 conv over the pair
+    Cout = 128
+    w = (rnd(7, Cout, C, 1, 1) / C ** 0.5).to(DEV)
+    bias = rnd(8, Cout).to(DEV)
+    wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
+    y1 = ops.conv_raw(xc, wf, bias, None, None, None, None, 0, 0.0, ops.S1, 1, 0, Cout)
+    y2 = ops.empty_nhwc(B, Cout, H, H, torch.bfloat16, x1.device)
+    ops.call('idf_conv1x1_bf16', x1.data_ptr(), x2.data_ptr(), C1, wf.data_ptr(), bias.data_ptr(), None, y2.data_ptr(),
+             B, H, H, C, Cout, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(y1, y2)
+    # weight gradient over the pair (table-driven launch, arena slots)
+    dy = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    ref_dW, ref_db = ops.conv_wgrad_bias_raw(xc, dy, ops.S1, 1, True)
+    wp = torch.nn.Parameter(torch.zeros(Cout, C, 1, 1, device=DEV))
+    bp = torch.nn.Parameter(torch.zeros(Cout, device=DEV))
+    arena = GradArena([wp, bp])
+    ops.WgradBatch.pending.append(None)
+    got = ops._defer_or_launch_wgrad(x1, dy, slot_of(wp), slot_of(bp), 1, a2=x2)
+    ops.WgradBatch.pending.pop(0)
+    assert got is not None
+    ops.WgradBatch.flush()
+    assert rel(got[0], ref_dW) < 1e-5 and rel(got[1], ref_db) < 1e-5

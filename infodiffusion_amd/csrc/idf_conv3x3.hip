@@ -239,6 +239,171 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   }
 }
 
+
+// ---------------------------------------------------------------- direct-to-LDS variant
+// Same tile, LDS image and MFMA loop as conv3x3_halo_bf16<MODE 0, TM 4, BN 64, NWM 4>, but a chunk is
+// fetched with global_load_lds_dwordx4: each wave instruction moves one 1-KB group (16 LDS rows) from 64
+// per-lane global addresses straight into LDS (lane l lands at group base + 16 l, so the lane picks the
+// (row, channel-slot) whose swizzled home that is).  No staging registers and no ds_write phase: the kernel
+// fits 128 VGPRs, TWO 512-thread blocks share a CU, and one block's MFMA phase covers the other's load
+// latency (a block itself does not prefetch: its single LDS image is in use until the chunk's last read).
+__device__ uint4 g_zero16;      // zero page: out-of-image halo pixels and padding rows load from here
+
+template <int KS>
+__global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
+  constexpr int TM = 4, BN = 64, NWM = 4, NT = 512, TN = 2;
+  constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = p.W, R = p.R, WH = W + 2 * HALO;
+  const int npix_h = (R + 2 * HALO) * WH;
+  const int hgroups = (npix_h + 15) >> 4;            // 1-KB groups of the halo image (padded to 16 rows)
+  constexpr int WGROUPS = TAPS * BN / 16;            // weight slab groups
+  const int KT = R * W;
+  unsigned char* Xs = smem;
+  unsigned char* Ws = smem + (size_t)hgroups * 1024;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
+  const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  int hbase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+    if (pl >= KT) pl = 0;
+    int oy = pl >> p.wshift, ox = pl & (W - 1);
+    hbase[i] = oy * WH + ox;
+  }
+  int wbase[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    int n = wn0 + a * 16 + fr;
+    wbase[a] = n * 64 + swz(n, fq) * 16;
+  }
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // group plan: wave w fetches groups w, w + 8, ...; per group this lane's global element offset
+  // (relative to the chunk's first channel) or -1 for the zero page
+  constexpr int MAXG = 9;                            // ceil((hgroups + WGROUPS) / 8) for every supported tile
+  const int ngroups = hgroups + WGROUPS;
+  int goff[MAXG];
+  const bf16_t* gsrc[MAXG];
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k) {
+    const int gi = wave + k * 8;
+    goff[k] = -1; gsrc[k] = p.x;
+    if (gi < ngroups) {
+      const int prow = lane >> 2, pslot = lane & 3;
+      if (gi < hgroups) {
+        const int pix = gi * 16 + prow;
+        const int ch = pslot ^ (((pix >> 2) & 1) << 1);          // inverse of swz(): XOR is an involution
+        if (pix < npix_h) {
+          int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
+          int iy = oy0 + hy - HALO, ix = hx - HALO;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+            goff[k] = ((b * p.H + iy) * W + ix) * p.Cin + ch * 8;
+        }
+      } else {
+        const int r = (gi - hgroups) * 16 + prow;
+        const int tap = r / BN, n = r - tap * BN;
+        const int ch = pslot ^ (((n >> 2) & 1) << 1);
+        gsrc[k] = p.w;
+        if (n0 + n < p.Cout) goff[k] = ((n0 + n) * TAPS + tap) * p.Cin + ch * 8;
+      }
+    }
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+
+  const int nchunks = p.Cin / CK;
+  for (int ck = 0; ck < nchunks; ++ck) {
+    const int c0 = ck * CK;
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k) {
+      const int gi = wave + k * 8;
+      if (gi < ngroups) {
+        const bf16_t* src = goff[k] >= 0 ? gsrc[k] + goff[k] + c0 : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (size_t)gi * 1024), 16, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                   // the direct loads are counted by vmcnt
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int toff = (tap / KS) * WH + (tap % KS);
+      bf16x8_t wf[TN], xf[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Ws + tap * BN * 64 + wbase[a]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int h = hbase[i] + toff;
+        xf[i] = *reinterpret_cast<const bf16x8_t*>(Xs + h * 64 + swz(h, fq) * 16);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue through LDS (as conv3x3_halo_bf16; Cout % 8 == 0 is a launch condition)
+  const int ncols = min(BN, p.Cout - n0);
+  constexpr int OPF = BN + 4;
+  float* Os = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      int nl = wn0 + a * 16 + fq * 4;
+      *reinterpret_cast<float4*>(Os + pl * OPF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  for (int idx = tid; idx < BM * CPR; idx += NT) {
+    int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
+    if (pl >= KT || cc >= ncols) continue;
+    float o[8];
+    float4 v0 = *reinterpret_cast<const float4*>(Os + pl * OPF + cc);
+    float4 v1 = *reinterpret_cast<const float4*>(Os + pl * OPF + cc + 4);
+    o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+    size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
+    if (p.bias) {
+      float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
+      float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
+      o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+    }
+    if (p.res) {
+      float r[8];
+      Vec16<bf16_t>::load(p.res + e, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r[k];
+    }
+    Vec16<bf16_t>::store(p.y + e, o);
+  }
+}
+
+template <int KS>
+void launch_dlds(const C3P& p, hipStream_t st) {
+  const int HALO = KS / 2;
+  const int npix_h = (p.R + 2 * HALO) * (p.W + 2 * HALO);
+  size_t lds = ((size_t)((npix_h + 15) / 16) * 16 + KS * KS * 64) * 64;
+  size_t olds = (size_t)256 * (64 + 4) * sizeof(float);
+  if (olds > lds) lds = olds;
+  auto kern = conv_dlds_bf16<KS>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
+}
+
 // magic multiplier for the division by the halo-row width; 0 when not exact over [0, npix)
 inline unsigned wh_magic(int WH, int npix) {
   unsigned m = 65536u / (unsigned)WH + 1u;
@@ -310,7 +475,11 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
     if (bn32) { if (BM == 128) launch<MODE, 4, 32>(p, st); else launch<MODE, 2, 32>(p, st); } \
     else { if (BM == 256) launch<MODE, 4, 64, 4>(p, st); else if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); } \
   } while (0)
-  if (mode == 0) IDF_C3_LAUNCH(0);
+  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 1;
+  // direct-to-LDS variant: pays once two of its blocks share every CU (it does not prefetch within a block)
+  if (mode == 0 && BM == 256 && !bn32 && dlds && (Cout & 7) == 0 && (long)B * p.tiles_per_img * p.n_tiles >= 512 &&
+      ((R + 2) * (W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3>(p, st);
+  else if (mode == 0) IDF_C3_LAUNCH(0);
   else if (mode == 1) launch<1, 2, 64>(p, st);
   else if (mode == 2) IDF_C3_LAUNCH(2);
   else IDF_C3_LAUNCH(3);
@@ -350,7 +519,9 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
   if (!p.wh_magic || (long)B * H * W * Cin >= (1L << 31))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
-  if (x2) {
+  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 1;
+  if (!x2 && BM == 256 && dlds && (long)B * p.tiles_per_img * nt >= 512) launch_dlds<1>(p, st);
+  else if (x2) {
     if (BM == 256) launch<0, 4, 64, 4, 1, true>(p, st);
     else if (BM == 128) launch<0, 4, 64, 2, 1, true>(p, st);
     else launch<0, 2, 64, 2, 1, true>(p, st);

@@ -475,9 +475,10 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
     if (bn32) { if (BM == 128) launch<MODE, 4, 32>(p, st); else launch<MODE, 2, 32>(p, st); } \
     else { if (BM == 256) launch<MODE, 4, 64, 4>(p, st); else if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); } \
   } while (0)
-  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 1;
+  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
+  static const long dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
   // direct-to-LDS variant: pays once two of its blocks share every CU (it does not prefetch within a block)
-  if (mode == 0 && BM == 256 && !bn32 && dlds && (Cout & 7) == 0 && (long)B * p.tiles_per_img * p.n_tiles >= 512 &&
+  if (mode == 0 && BM == 256 && !bn32 && (dlds & 1) && (Cout & 7) == 0 && (long)B * p.tiles_per_img * p.n_tiles >= dlds_min &&
       ((R + 2) * (W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3>(p, st);
   else if (mode == 0) IDF_C3_LAUNCH(0);
   else if (mode == 1) launch<1, 2, 64>(p, st);
@@ -519,8 +520,9 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
   if (!p.wh_magic || (long)B * H * W * Cin >= (1L << 31))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
-  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 1;
-  if (!x2 && BM == 256 && dlds && (long)B * p.tiles_per_img * nt >= 512) launch_dlds<1>(p, st);
+  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
+  static const long dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
+  if (!x2 && BM == 256 && (dlds & 2) && (long)B * p.tiles_per_img * nt >= dlds_min) launch_dlds<1>(p, st);
   else if (x2) {
     if (BM == 256) launch<0, 4, 64, 4, 1, true>(p, st);
     else if (BM == 128) launch<0, 4, 64, 2, 1, true>(p, st);

@@ -36,6 +36,8 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
     # 1x1 through the halo pipeline (bf16): 64 / 128 / 256-pixel tiles, ragged cout tile, tiny images
     (3, 128, 16, 16, 128, 1, ops.S1), (33, 64, 64, 64, 128, 1, ops.S1), (5, 192, 32, 32, 64, 1, ops.S1),
     (2, 64, 4, 4, 72, 1, ops.S1), (40, 128, 16, 16, 384, 1, ops.S1),
+    # >= 1536 tiles: the direct-to-LDS variant (global_load_lds, two blocks per CU), 3x3 and 1x1
+    (96, 64, 64, 64, 64, 9, ops.S1), (48, 128, 64, 64, 128, 1, ops.S1),
     # stride 2 through the halo kernel: 32 / 16 / 4-wide outputs
     (3, 64, 64, 64, 64, 9, ops.S2), (2, 128, 32, 32, 128, 9, ops.S2), (2, 128, 8, 8, 128, 9, ops.S2),
 ])

@@ -496,16 +496,17 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
   }
   constexpr int NV = KEEP > 0 ? KEEP : (KEEP < 0 ? SNV_MAX : SNV);
-  uint4 xr[NV];                 // packed x stays in registers
-  float duk[KEEP > 0 ? KEEP : 1][VE];      // KEEP < 0: SNV_MAX vectors per thread, du recomputed
+  uint4 xr[KEEP < 0 ? 1 : NV];  // packed x stays in registers (KEEP < 0: nothing kept, x and dA are re-read)
+  float duk[KEEP > 0 ? KEEP : 1][VE];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
     if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
-      xr[k] = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
+      const uint4 xraw = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
+      if (KEEP >= 0) xr[k] = xraw;
       float xv[VE], dav[VE], du[VE];
-      unpack16<T>(xr[k], xv);
+      unpack16<T>(xraw, xv);
       Vec16<T>::load(dA + e0, dav);
       du_vec<T>(dav, xv, scv, shv, act, seed, salt, thr, dscale, e0, du);
 #pragma unroll
@@ -563,7 +564,12 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     if (p < HW && live) {
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       float xv[VE], du[VE], o[VE];
-      unpack16<T>(xr[k], xv);
+      if (KEEP < 0) {
+        const uint4 xraw = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
+        unpack16<T>(xraw, xv);
+      } else {
+        unpack16<T>(xr[KEEP < 0 ? 0 : k], xv);
+      }
       if (KEEP > 0) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) du[e] = duk[k][e];

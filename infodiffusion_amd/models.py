@@ -28,7 +28,7 @@ class _UNetSkeleton(nn.Module):
     """Down / middle / up scaffolding common to AuxiliaryUNet, Encoder and UNet
     (models.py:248-284, 432-468, 16-52).  `make(in_ch, out_ch, attn)` builds a block."""
 
-    def _build(self, make, ch, ch_mult, attn, num_res_blocks, in_ch, out_ch):
+    def _build(self, make, ch, ch_mult, attn, num_res_blocks, in_ch, out_ch, make_mid=None):
         assert all([i < len(ch_mult) for i in attn]), 'attn index out of bound'
         self.head = nn.Conv2d(in_ch, ch, kernel_size=3, stride=1, padding=1)
         self.downblocks = nn.ModuleList()
@@ -41,7 +41,8 @@ class _UNetSkeleton(nn.Module):
             if level != len(ch_mult) - 1:
                 self.downblocks.append(DownSample(now))
                 widths.append(now)
-        self.middleblocks = nn.ModuleList([make(now, now, True), make(now, now, False)])
+        make_mid = make_mid or make
+        self.middleblocks = nn.ModuleList([make_mid(now, now, True), make_mid(now, now, False)])
         self.upblocks = nn.ModuleList()
         for level, mult in reversed(list(enumerate(ch_mult))):
             for _ in range(num_res_blocks + 1):
@@ -71,10 +72,10 @@ class _UNetSkeleton(nn.Module):
         self._cfg_head = _cfg(_Shadows(self.head), ops.S1, 9, _ACT_NONE)
         self._cfg_tail = _cfg(_Shadows(self.tail[-1]), ops.S1, 9, _ACT_SILU)
         self._shadow_set = ShadowSet(self)
-        blocks = self._res_blocks()
-        for which in ('t', 'a'):
-            if blocks and hasattr(blocks[0], 'temb_proj' if which == 't' else 'aemb_proj'):
-                film_groups(blocks, which)      # parameter groups must exist before an optimizer lays out its arena
+        for which in ('t', 'a'):        # parameter groups must exist before an optimizer lays out its arena
+            blocks = [m for m in self._res_blocks() if hasattr(m, 'temb_proj' if which == 't' else 'aemb_proj')]
+            if blocks:
+                film_groups(blocks, which)
 
     def _res_blocks(self):
         return [m for m in list(self.downblocks) + list(self.middleblocks) + list(self.upblocks)
@@ -178,6 +179,40 @@ class AuxiliaryUNet(_UNetSkeleton):
         return self._run(x, lambda blk, h, **kw: blk(h, temb, aemb, **kw))
 
 
+class BottleneckAuxUNet(_UNetSkeleton):
+    """models.py:329-421 (--is_bottleneck): t-conditioned ResBlocks on the down / up paths, the latent `a`
+    enters only through the two middle AuxResBlocks; fc_a = Sequential(SiLU, Linear), He-initialised."""
+
+    def __init__(self, T, ch=64, ch_mult=[1, 2, 4, 8], attn=[2], num_res_blocks=2, dropout=0.1, a_dim=32,
+                 shape=None):
+        super().__init__()
+        tdim = ch * 4
+        self.a_dim = a_dim
+        self.time_embedding = TimeEmbedding(T, ch, tdim)
+        self.fc_a = nn.Sequential(nn.SiLU(), nn.Linear(self.a_dim, tdim))
+        self._build(lambda i, o, at: ResBlock(in_ch=i, out_ch=o, tdim=tdim, dropout=dropout, attn=at),
+                    ch, ch_mult, attn, num_res_blocks, shape[0], shape[0],
+                    make_mid=lambda i, o, at: AuxResBlock(i, o, tdim, dropout, attn=at, crossattn=False))
+        self.initialize()
+        self._post()
+
+    def initialize(self):
+        self._init_ends()
+        init.kaiming_normal_(self.fc_a[1].weight, a=0, nonlinearity='relu')
+        self._init_tail()
+
+    def forward(self, x, t, a):
+        x = self._prep(x)
+        aemb = ops.linear(a, self.fc_a[1].weight, self.fc_a[1].bias, silu_in=True)
+        temb = self.time_embedding(t)
+        blocks = self._res_blocks()
+        batched_film(blocks, temb, 't')
+        mids = [m for m in blocks if isinstance(m, AuxResBlock)]
+        batched_film(mids, aemb, 'a')
+        return self._run(x, lambda blk, h, **kw: (blk(h, temb, aemb, **kw) if isinstance(blk, AuxResBlock)
+                                                  else blk(h, temb, **kw)))
+
+
 class Encoder(_UNetSkeleton):
     """models.py:424-518: UNet-shaped encoder -> 1 channel -> fc -> (a, a_q, mu, log_var)."""
 
@@ -230,10 +265,9 @@ class InfoDiff(nn.Module):
         self.device = device
         self.alpha_bars, self.betas, self.alphas, self.alpha_prev_bars = _schedule(args, device)
         ch_mult = [1, 2, 4] if args.input_size == 28 else [1, 2, 2, 2]
-        if getattr(args, 'is_bottleneck', False):
-            raise NotImplementedError('--is_bottleneck (BottleneckAuxUNet) is outside the hot path (SURVEY.md 8f)')
-        self.backbone = AuxiliaryUNet(ch_mult=ch_mult, T=args.diffusion_steps, ch=args.unets_channels,
-                                      a_dim=args.a_dim, shape=shape)
+        net = BottleneckAuxUNet if getattr(args, 'is_bottleneck', False) else AuxiliaryUNet     # models.py:623-626
+        self.backbone = net(ch_mult=ch_mult, T=args.diffusion_steps, ch=args.unets_channels,
+                            a_dim=args.a_dim, shape=shape)
         self.encoder = Encoder(ch_mult=ch_mult, ch=args.encoder_channels, a_dim=args.a_dim, shape=shape)
         self.mmd_weight: float = args.mmd_weight
         self.kld_weight: float = args.kld_weight

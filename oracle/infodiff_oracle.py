@@ -284,6 +284,26 @@ def aux_unet(sd, p, x, t, a, ch, ch_mult, drop=None):
                       lambda q, h, at: aux_res_block(sd, q, h, temb, aemb, at, drop))
 
 
+def bottleneck_unet(sd, p, x, t, a, ch, ch_mult, drop=None):
+    """BottleneckAuxUNet.forward, models.py:383-421: t-only ResBlocks on the down / up paths, the two
+    AuxResBlocks (conditioned on a) in the middle only; fc_a = Sequential(SiLU, Linear) (models.py:336-339)."""
+    drop = drop or Drop(None)
+    aemb = _lin(sd, p + '.fc_a.1', F.silu(a))
+    temb = time_embedding(sd, p + '.time_embedding', t)
+
+    def block(q, h, at):
+        if '.middleblocks.' in q:
+            return aux_res_block(sd, q, h, temb, aemb, at, drop)
+        return res_block(sd, q, h, temb, at, drop)
+    return _unet_body(sd, p, x, unet_layout(ch, ch_mult), block)
+
+
+def backbone(sd, cfg, x, idx, a, drop=None):
+    """InfoDiff.backbone as constructed by models.py:623-626."""
+    fn = bottleneck_unet if getattr(cfg, 'is_bottleneck', False) else aux_unet
+    return fn(sd, 'backbone', x, idx, a, cfg.unets_channels, ch_mult_for(cfg), drop)
+
+
 def vanilla_unet(sd, p, x, t, ch, ch_mult, drop=None):
     """UNet.forward, models.py:62-88 (as it would run without the stray kwarg)."""
     drop = drop or Drop(None)
@@ -355,7 +375,7 @@ def kld(mu, log_var):
 def infodiff_eps(sd, cfg, x, t_int, a):
     """InfoDiff.forward sampling path (idx given, a given), models.py:705-723."""
     idx = torch.full((x.size(0),), int(t_int), dtype=torch.long)
-    return aux_unet(sd, 'backbone', x, idx, a, cfg.unets_channels, ch_mult_for(cfg))
+    return backbone(sd, cfg, x, idx, a)
 
 
 def infodiff_train_forward(sd, cfg, x, idx, eps, sched, drop=None, reparam_noise=None):
@@ -366,8 +386,7 @@ def infodiff_train_forward(sd, cfg, x, idx, eps, sched, drop=None, reparam_noise
     a, a_q, mu, log_var = encoder(sd, 'encoder', x, cfg.encoder_channels, ch_mult_for(cfg),
                                   drop, reparam_noise)
     use_q = cfg.kld_weight != 0   # models.py:714-721
-    out = aux_unet(sd, 'backbone', x_tilde, idx, a_q if use_q else a,
-                   cfg.unets_channels, ch_mult_for(cfg), drop)
+    out = backbone(sd, cfg, x_tilde, idx, a_q if use_q else a, drop)
     return out, x_tilde, a, a_q, mu, log_var
 
 

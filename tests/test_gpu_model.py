@@ -74,6 +74,7 @@ def _replay(model, cfg, g, seed):
 
 @pytest.mark.parametrize('tag,cfgkw', [('fmnist', dict(a_dim=32, mmd_weight=0.1)),
                                        ('fmnist_kld', dict(a_dim=16, mmd_weight=0.1, kld_weight=0.01)),
+                                       ('fmnist_bneck', dict(a_dim=32, mmd_weight=0.1, is_bottleneck=True)),
                                        ('celeba', dict(a_dim=32, mmd_weight=0.1))])
 def test_train_step_fp32_vs_reference(tag, cfgkw):
     ds = 'celeba' if tag == 'celeba' else 'fmnist'

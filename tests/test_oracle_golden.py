@@ -95,6 +95,12 @@ def test_model_fmnist_kld(gold, manifest):
                 O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01))
 
 
+def test_model_fmnist_bottleneck(gold, manifest):
+    """--is_bottleneck (BottleneckAuxUNet, models.py:329-421): oracle vs the reference fixture."""
+    _model_case(gold, manifest, 'fmnist_bneck',
+                O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1, is_bottleneck=True))
+
+
 def test_model_celeba(gold, manifest):
     _model_case(gold, manifest, 'celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1))
 

@@ -222,7 +222,8 @@ def gen_model(tag, cfg, B, seed, grads=True):
                mmd=terms.get('mmd', torch.zeros(())))
     if grads:
         named = dict(model.named_parameters())
-        pick = ['backbone.head.weight', 'backbone.head.bias', 'backbone.fc_a.weight',
+        pick = ['backbone.head.weight', 'backbone.head.bias', 'backbone.fc_a.weight', 'backbone.fc_a.1.weight',
+                'backbone.middleblocks.0.aemb_proj.1.weight', 'backbone.middleblocks.1.block2.3.weight',
                 'backbone.downblocks.0.block1.2.weight', 'backbone.downblocks.0.block2.0.weight',
                 'backbone.downblocks.0.temb_proj.1.weight', 'backbone.downblocks.0.aemb_proj.1.bias',
                 'backbone.downblocks.3.shortcut.weight', 'backbone.downblocks.2.main.weight',
@@ -288,10 +289,9 @@ def gen_model(tag, cfg, B, seed, grads=True):
             res['ddim.rev_trace'] = torch.stack(rt)
             with torch.no_grad():
                 ro = O.reverse_sample_loop(
-                    sched_s, lambda xx, i: O.aux_unet(syn_s, 'backbone', xx, torch.full((2,), i, dtype=torch.long),
+                    sched_s, lambda xx, i: O.backbone(syn_s, cfg, xx, torch.full((2,), i, dtype=torch.long),
                                                       O.encoder(syn_s, 'encoder', xx, cfg.encoder_channels,
-                                                                O.ch_mult_for(cfg))[0],
-                                                      cfg.unets_channels, O.ch_mult_for(cfg)), xT)
+                                                                O.ch_mult_for(cfg))[0]), xT)
             for k in range(len(rt)):
                 check('%s reverse step%d' % (tag, k), ro[k], rt[k], 5e-5)
     save('model_' + tag, **res)
@@ -443,7 +443,7 @@ def gen_vanilla_twophase():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'celeba']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'celeba']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -459,6 +459,8 @@ if __name__ == '__main__':
     if 'fmnist' in which:
         gen_model('fmnist', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1), B=4, seed=64)
         gen_model('fmnist_kld', O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01), B=3, seed=65)
+    if 'bneck' in which:
+        gen_model('fmnist_bneck', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1, is_bottleneck=True), B=3, seed=66)
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     print('ALL ORACLE-vs-REFERENCE CHECKS PASSED')

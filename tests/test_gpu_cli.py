@@ -36,3 +36,25 @@ def test_cli_train_checkpoint_eval(tmp_path):
     assert npy
     img = np.load(npy[0])
     assert img.shape == (16, 1, 32, 32) and np.isfinite(img).all()
+
+
+def test_cli_latent_pipeline(tmp_path):
+    """Config-5 flow of the reference (run.py:415-443, 482-526, eval_fid.sh): train -> save_latent (the
+    `{model}_{exp}_latent.npz` wire format) -> train_latent_ddim on it -> eval_fid --is_latent (latent DDIM
+    samples `a`, the image sampler decodes it)."""
+    tmp = str(tmp_path)
+    _run(tmp, '--mode', 'train')
+    _run(tmp, '--mode', 'save_latent')
+    npz = glob.glob(os.path.join(tmp, 'diff_*_latent.npz'))
+    assert len(npz) == 1
+    z = np.load(npz[0])
+    assert z['all_a'].ndim == 2 and z['all_a'].shape[1] == 32 and np.isfinite(z['all_a']).all()
+    out = _run(tmp, '--mode', 'train_latent_ddim', '--is_latent')
+    assert 'Epoch' in out
+    assert glob.glob(os.path.join(tmp, 'models', '*_latent', 'model-2.pth'))
+    out = _run(tmp, '--mode', 'eval_fid', '--is_latent', '--sampling_number', '8')
+    assert 'DONE' in out
+    npy = glob.glob(os.path.join(tmp, 'imgs', '*', 'eval-fid-latent', 'sample-*.npy'))
+    assert npy
+    img = np.load(npy[0])
+    assert img.shape == (8, 1, 32, 32) and np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0

@@ -172,6 +172,11 @@ int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum,
                  float scale, int dtype, void* stream);
 
 /* ---- elementwise / reductions */
+/* Input pipeline on the device (reference data.py:149-171, ToTensor -> RandomHorizontalFlip -> Normalize):
+ * uint8 NHWC image bytes -> fp32 NHWC-dense (x / 255 - 0.5) / 0.5, bit-identical to the torchvision chain;
+ * flip [B] (or NULL): non-zero mirrors that sample horizontally.  The batch crosses PCIe as bytes. */
+int idf_prep_u8(const uint8_t* src, const uint8_t* flip, float* dst, int B, int H, int W, int C, void* stream);
+
 /* q_sample, models.py:702-704: xt = sqrt_ab[idx[b]]*x + sqrt_1mab[idx[b]]*eps; the two [T] tables
  * hold sqrt(alpha_bar), sqrt(1-alpha_bar) (host torch CPU ops => bit-exact gathers and fp32 result) */
 int idf_qsample(const float* x, const float* eps, const long* idx, const float* sqrt_ab, const float* sqrt_1mab,

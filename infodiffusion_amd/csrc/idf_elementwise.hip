@@ -36,6 +36,25 @@ __global__ void qsample_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// Input pipeline on the device (reference data.py:149-171: ToTensor -> RandomHorizontalFlip -> Normalize(0.5, 0.5)):
+// uint8 NHWC image bytes -> fp32 NHWC-dense activations (x / 255 - 0.5) / 0.5, each op rounded separately
+// (this file is compiled with -ffp-contract=off), so the result is bit-identical to the torchvision chain;
+// flip[b] != 0 mirrors sample b horizontally.
+__global__ void prep_u8_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ flip,
+                               float* __restrict__ dst, int H, int W, int C, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long pix = i / C;
+    int c = (int)(i - pix * C);
+    long row = pix / W;
+    int w = (int)(pix - row * W);
+    long b = row / H;
+    long j = i;
+    if (flip && flip[b]) j = (row * W + (W - 1 - w)) * C + c;
+    float v = __fdiv_rn((float)src[j], 255.0f);
+    dst[i] = __fdiv_rn(__fsub_rn(v, 0.5f), 0.5f);
+  }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ table, const long* __restrict__ idx,
                                    float* __restrict__ out, int D, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -335,6 +354,16 @@ extern "C" int idf_qsample(const float* x, const float* eps, const long* idx, co
   else
     hipLaunchKernelGGL(qsample_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, ST, x, eps, idx, sqrt_ab, sqrt_1mab,
                        xt32, (bf16_t*)xt, per_sample, n);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+extern "C" int idf_prep_u8(const uint8_t* src, const uint8_t* flip, float* dst, int B, int H, int W, int C,
+                           void* stream) {
+  long n = (long)B * H * W * C;
+  if (n == 0) return IDF_OK;
+  if (!src || !dst) IDF_FAIL(IDF_ERR_BADARG, "prep_u8: null buffer");
+  hipLaunchKernelGGL(prep_u8_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, src, flip, dst, H, W, C, n);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

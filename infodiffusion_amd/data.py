@@ -36,6 +36,7 @@ class _Batches:
             self.array = arr
             self.n = len(arr) // (self.bs * world)
         self.seed = getattr(args, 'r_seed', 0)
+        self.augment = args.dataset in ('celeba', 'ffhq') and getattr(args, 'mode', 'train') == 'train'   # data.py:165-166
 
     def __len__(self):
         return self.n
@@ -49,6 +50,13 @@ class _Batches:
             else:
                 lo = (i * self.world + self.rank) * self.bs
                 a = torch.from_numpy(np.ascontiguousarray(self.array[lo:lo + self.bs]))
+                if a.dtype == torch.uint8 and torch.device(self.device).type == 'cuda':
+                    # bytes cross PCIe; ToTensor / RandomHorizontalFlip / Normalize run on the GPU (idf_prep_u8)
+                    from . import ops
+                    flip = (torch.rand(self.bs, generator=g) < 0.5).to(torch.uint8) if self.augment else None
+                    x = ops.prep_u8(a.pin_memory().to(self.device, non_blocking=True), flip)
+                    yield (x, torch.zeros(self.bs, dtype=torch.long))
+                    continue
                 if a.dtype == torch.uint8:
                     a = a.permute(0, 3, 1, 2).float() / 255.0
                 x = (a.float() - 0.5) / 0.5

@@ -783,6 +783,22 @@ def linear(x, weight, bias=None, silu_in=False):
     return _Linear.apply(x, weight, bias, silu_in, slots)
 
 
+# ------------------------------------------------------------ input pipeline
+def prep_u8(img_u8, flip=None):
+    """uint8 NHWC image batch [B, H, W, C] on the GPU -> fp32 activations (x / 255 - 0.5) / 0.5, logical
+    [B, C, H, W] in NHWC-dense memory (what q_sample and the encoder read without a layout copy);
+    flip: optional uint8 [B], non-zero = mirror horizontally (reference data.py:149-171)."""
+    if not img_u8.is_cuda or img_u8.dtype != torch.uint8 or img_u8.dim() != 4:
+        raise RuntimeError('prep_u8 wants a uint8 [B, H, W, C] tensor on the GPU')
+    img_u8 = img_u8.contiguous()
+    B, H, W, Cc = img_u8.shape
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=img_u8.device).contiguous(memory_format=CL)
+    if flip is not None:
+        flip = flip.to(device=img_u8.device, dtype=torch.uint8).contiguous()
+    call('idf_prep_u8', _p(img_u8), _p(flip), _p(out), B, H, W, Cc, _st())
+    return out
+
+
 # --------------------------------------------------------- gather / q_sample
 def gather_rows(table, idx):
     idx = idx.contiguous()

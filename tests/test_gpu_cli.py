@@ -24,6 +24,10 @@ def _run(tmp, *extra):
 
 def test_cli_train_checkpoint_eval(tmp_path):
     tmp = str(tmp_path)
+    # a real-data style input: uint8 NHWC bytes in <data_dir>/<dataset>.npy, normalised on the GPU (idf_prep_u8)
+    os.makedirs(os.path.join(tmp, 'data'), exist_ok=True)
+    rng = np.random.default_rng(0)
+    np.save(os.path.join(tmp, 'data', 'fmnist.npy'), rng.integers(0, 256, (48, 32, 32, 1), dtype=np.uint8))
     out = _run(tmp, '--mode', 'train')
     assert 'Epoch' in out and 'Loss' in out                      # ProgressMeter line per epoch (run.py:206)
     ckpt = glob.glob(os.path.join(tmp, 'models', '*', 'model-2.pth'))

@@ -375,3 +375,18 @@ def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     assert got is not None
     ops.WgradBatch.flush()
     assert rel(got[0], ref_dW) < 1e-5 and rel(got[1], ref_db) < 1e-5
+
+
+def test_prep_u8_matches_torchvision_chain_bitwise():
+    """idf_prep_u8 == ToTensor -> RandomHorizontalFlip -> Normalize(0.5, 0.5) of reference data.py:149-171,
+    bit for bit, landing directly in the NHWC-dense layout the model reads."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (5, 16, 12, 3), generator=g, dtype=torch.uint8)       # [B, H, W, C]
+    flip = torch.tensor([0, 1, 1, 0, 1], dtype=torch.uint8)
+    ref = img.permute(0, 3, 1, 2).float() / 255.0
+    ref = torch.where(flip.bool()[:, None, None, None], ref.flip(-1), ref)
+    ref = (ref - 0.5) / 0.5
+    out = ops.prep_u8(img.to(DEV), flip)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=CL)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(ops.prep_u8(img.to(DEV)).cpu(), (img.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5)

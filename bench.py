@@ -241,7 +241,9 @@ def main():
 
     g = torch.Generator(device='cpu')
     g.manual_seed(64 + rank)
-    pool = [(torch.rand(a.batch, 3, 64, 64, generator=g) * 2 - 1).to(dev) for _ in range(8)]
+    # synthetic batches in the layout the input pipeline delivers (data.py / idf_prep_u8: NHWC-dense fp32)
+    pool = [(torch.rand(a.batch, 3, 64, 64, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
+            for _ in range(8)]
     xbuf = pool[0].clone()
 
     def fwd_bwd():

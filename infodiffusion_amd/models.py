@@ -247,6 +247,33 @@ class Encoder(_UNetSkeleton):
         return a, a_q, mu, log_var
 
 
+class Decoder(_UNetSkeleton):
+    """models.py:521-603: fc_a(a) viewed as an image -> the UNet skeleton of ResBlock_encoder blocks ->
+    reconstruction.  fc_a keeps nn.Linear's default initialisation (models.py:564-568 touches head/tail only)."""
+
+    def __init__(self, ch=64, ch_mult=[1, 2, 4, 8], attn=[2], num_res_blocks=2, dropout=0.1, a_dim=10,
+                 shape=None):
+        super().__init__()
+        self.a_dim = a_dim
+        self.shape = shape
+        self._build(lambda i, o, at: ResBlock_encoder(in_ch=i, out_ch=o, dropout=dropout, attn=at),
+                    ch, ch_mult, attn, num_res_blocks, shape[0], shape[0])
+        self.fc_a = nn.Linear(self.a_dim, self.shape[0] * self.shape[1] * self.shape[2])
+        self.initialize()
+        self._post()
+
+    def initialize(self):
+        self._init_ends()
+        self._init_tail()
+
+    def forward(self, a):
+        if not a.is_cuda:
+            raise RuntimeError('infodiffusion_amd runs on the GPU only: the HIP kernels have no CPU fallback')
+        aemb = ops.linear(a.float(), self.fc_a.weight, self.fc_a.bias)
+        h = aemb.reshape(a.shape[0], self.shape[0], self.shape[1], self.shape[2])
+        return self._run(self._prep(h), lambda blk, hh, **kw: blk(hh, **kw))
+
+
 def _schedule(args, device):
     """models.py:615-618: identical torch CPU ops => bitwise-identical tables."""
     T = args.diffusion_steps
@@ -380,3 +407,50 @@ class Diff(nn.Module):
             x_tilde = x
         output = self.backbone(x_tilde, idx)
         return (output, epsilon) if get_target else output
+
+
+class VAE(nn.Module):
+    """models.py:781-833 (--model vae baseline): Encoder -> latent -> Decoder, both with the [1,2,4,8] widths."""
+
+    def __init__(self, args, device, shape):
+        super().__init__()
+        self.device = device
+        ch_mult = [1, 2, 4] if args.input_size == 28 else [1, 2, 4, 8]
+        self.encoder = Encoder(ch_mult=ch_mult, ch=args.encoder_channels, a_dim=args.a_dim, shape=shape)
+        self.decoder = Decoder(ch_mult=ch_mult, ch=args.encoder_channels, a_dim=args.a_dim, shape=shape)
+        self.mmd_weight: float = args.mmd_weight
+        self.kld_weight: float = args.kld_weight
+        self.verbose = getattr(args, 'verbose_loss', False)
+        self.set_act_dtype(_act_dtype(args))
+        self.to(device)
+
+    def set_act_dtype(self, dtype):
+        self.act_dtype = dtype
+        self.encoder.ctx.act_dtype = dtype
+        self.decoder.ctx.act_dtype = dtype
+
+    def loss_fn(self, args, x, curr_epoch=0):
+        reconstruction, a_q, mu, log_var = self.forward(x, get_target=True)
+        loss = ops.diff_loss(reconstruction, x, x, 1.0, 0.0, 0.0)[0]        # mean((rec - x)^2), models.py:796
+        if self.verbose:
+            print('reconstruction loss:', loss)
+        if args.mmd_weight != 0:
+            true_samples = torch.randn_like(a_q, device=self.device)
+            loss = loss + args.mmd_weight * compute_mmd(true_samples, a_q)
+        elif args.kld_weight != 0:
+            # a batch MEAN here (models.py:807), unlike InfoDiff's sum
+            kld_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+            if args.use_C:
+                self.C_max = torch.FloatTensor([args.C_max]).to(device=self.device)
+                C = torch.clamp(self.C_max / args.epochs * curr_epoch,
+                                torch.FloatTensor([0]).to(device=self.device), self.C_max)
+                loss = loss + args.kld_weight * (kld_loss - C.squeeze(dim=0)).abs()
+            else:
+                loss = loss + args.kld_weight * kld_loss
+        return loss
+
+    def forward(self, x, get_target=False):
+        a, a_q, mu, log_var = self.encoder(x)
+        z = a if (self.mmd_weight == 0 and self.kld_weight == 0) else a_q      # models.py:824-831
+        reconstruction = self.decoder(z)
+        return (reconstruction, a_q, mu, log_var) if get_target else reconstruction

@@ -326,6 +326,49 @@ def encoder(sd, p, x, ch, ch_mult, drop=None, reparam_noise=None):
     return a, a_q, mu, log_var
 
 
+def decoder(sd, p, a, ch, ch_mult, shape, drop=None):
+    """Decoder.forward, models.py:570-603: fc_a(a) reshaped to an image (NCHW order) -> the UNet
+    skeleton of ResBlock_encoder blocks -> reconstruction with shape[0] channels."""
+    drop = drop or Drop(None)
+    h = _lin(sd, p + '.fc_a', a).reshape(a.shape[0], shape[0], shape[1], shape[2])
+    return _unet_body(sd, p, h, unet_layout(ch, ch_mult),
+                      lambda q, hh, at: res_block_encoder(sd, q, hh, at, drop))
+
+
+def vae_forward(sd, cfg, x, drop=None, reparam_noise=None):
+    """VAE.forward(get_target=True), models.py:821-833.  Encoder and decoder both use the
+    [1,2,4,8] widths (models.py:785-790); the decoder reads `a` only when both weights are 0."""
+    drop = drop or Drop(None)
+    mult = ch_mult_for(cfg, vanilla=True)
+    a, a_q, mu, log_var = encoder(sd, 'encoder', x, cfg.encoder_channels, mult, drop, reparam_noise)
+    z = a if (cfg.mmd_weight == 0 and cfg.kld_weight == 0) else a_q
+    rec = decoder(sd, 'decoder', z, cfg.encoder_channels, mult, cfg.shape, drop)
+    return rec, a_q, mu, log_var
+
+
+def vae_loss(sd, cfg, x, prior=None, drop=None, reparam_noise=None, curr_epoch=0):
+    """VAE.loss_fn, models.py:793-819.  MMD is taken on a_q; the KL term is a batch MEAN here
+    (models.py:807) where InfoDiff's is a sum; with both weights non-zero only MMD is added."""
+    rec, a_q, mu, log_var = vae_forward(sd, cfg, x, drop, reparam_noise)
+    terms = {}
+    loss = (rec - x).square().mean()
+    terms['recon'] = loss
+    if cfg.mmd_weight != 0:
+        terms['mmd'] = cfg.mmd_weight * compute_mmd(prior, a_q)
+        loss = loss + terms['mmd']
+    elif cfg.kld_weight != 0:
+        k = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+        if cfg.use_C:
+            cmax = torch.tensor([cfg.C_max])
+            C = torch.clamp(cmax / cfg.epochs * curr_epoch, torch.tensor([0.0]), cmax)
+            terms['kld'] = cfg.kld_weight * (k - C.squeeze(0)).abs()
+        else:
+            terms['kld'] = cfg.kld_weight * k
+        loss = loss + terms['kld']
+    terms.update(rec=rec, a_q=a_q, mu=mu, log_var=log_var)
+    return loss, terms
+
+
 def latent_unet(sd, p, x, t, a_dim, num_layers=10, drop=None, time_ch=64):
     """LatentUNet.forward, models.py:223-234 with MLPLNAct.forward 147-163."""
     drop = drop or Drop(None)

@@ -21,7 +21,7 @@ from infodiffusion_amd.data import get_dataset, get_dataset_config
 from infodiffusion_amd.dist import GradSync, shard_range
 from infodiffusion_amd.optim import FusedClipAdamW
 from infodiffusion_amd.trainer import GraphedTrainStep
-from infodiffusion_amd.models import Diff, InfoDiff
+from infodiffusion_amd.models import VAE, Diff, InfoDiff
 from infodiffusion_amd.sampling import DiffusionProcess, LatentDiffusionProcess, TwoPhaseDiffusionProcess
 from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter,
                                      generate_exp_string, seed_everything)
@@ -87,7 +87,9 @@ def _dist_setup():
 
 def _model_root(args, latent=False):
     root = args.model_folder
-    if args.model == 'vanilla':
+    if args.model == 'vae':
+        root = os.path.join(root, 'vae')
+    elif args.model == 'vanilla':
         root = os.path.join(root, 'diff')
     root = os.path.join(root, generate_exp_string(args))
     return root + '_latent' if latent else root
@@ -129,11 +131,14 @@ def _fit(args, model, batches, world, rank, latent=False):
             save_model(args, epoch + 1, model, latent)
 
 
+_MODELS = {'diff': InfoDiff, 'vanilla': Diff, 'vae': VAE}      # reference run.py:171-176
+
+
 def train(args):
     world, rank, dev = _dist_setup()
     seed_everything(args.r_seed + rank)
     shape = get_dataset_config(args)
-    model = (InfoDiff if args.model == 'diff' else Diff)(args, dev, shape)
+    model = _MODELS[args.model](args, dev, shape)
     model.train()
     _fit(args, model, get_dataset(args, shape, dev, rank, world), world, rank)
 
@@ -155,11 +160,25 @@ def evaluate(args):
         return
     seed_everything(args.r_seed + rank)
     shape = get_dataset_config(args)
-    model = (InfoDiff if args.model == 'diff' else Diff)(args, dev, shape)
+    model = _MODELS[args.model](args, dev, shape)
     _load(model, os.path.join(_model_root(args), 'model-%d.pth' % args.epochs), dev, strict=False)
     model.eval()
-    out_root = os.path.join(args.img_folder, generate_exp_string(args))
-    if args.mode == 'eval':
+    out_root = os.path.join(args.img_folder, 'vae' if args.model == 'vae' else '', generate_exp_string(args))
+    if args.model == 'vae' and args.mode in ('eval', 'eval_fid'):
+        # reference run.py:261-263, 297-300: images are decoder(randn) -- no diffusion process
+        sub = 'eval' if args.mode == 'eval' else ('eval-fid-latent' if args.is_latent else 'eval-fid-fast')
+        os.makedirs(os.path.join(out_root, sub), exist_ok=True)
+        lo, hi = shard_range(args.sampling_number, rank, world)
+        step = args.sampling_number if args.mode == 'eval' else args.batch_size
+        with torch.no_grad():
+            for n in range(lo, hi, step):
+                a = torch.randn([min(step, hi - n), args.a_dim]).to(device=dev)
+                img = model.decoder(a).float()
+                if args.mode == 'eval_fid':
+                    img = (torch.clip(img, min=-1, max=1) + 1) / 2
+                np.save(os.path.join(out_root, sub, 'sample-%06d.npy' % n), img.cpu().numpy())
+        print('DONE')
+    elif args.mode == 'eval':
         proc = DiffusionProcess(args, model, dev, shape)
         os.makedirs(os.path.join(out_root, 'eval'), exist_ok=True)
         for n in range(0, args.sampling_number, args.batch_size):
@@ -203,8 +222,6 @@ def evaluate(args):
 
 if __name__ == '__main__':
     args = parse_args()
-    if args.model == 'vae':
-        raise NotImplementedError('--model vae is a baseline outside the hot path (SURVEY.md 2, row 3)')
     if args.mode == 'train':
         train(args)
     else:

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp, *extra):
-    cmd = [sys.executable, os.path.join(ROOT, 'run.py'), '--model', 'diff', '--prior', 'regular', '--dataset', 'fmnist',
+def _run(tmp, *extra, model='diff'):
+    cmd = [sys.executable, os.path.join(ROOT, 'run.py'), '--model', model, '--prior', 'regular', '--dataset', 'fmnist',
            '--a_dim', '32', '--epochs', '2', '--save_epochs', '2', '--batch_size', '8', '--steps_per_epoch', '3',
            '--diffusion_steps', '40', '--act_dtype', 'bf16', '--model_folder', os.path.join(tmp, 'models'),
            '--img_folder', os.path.join(tmp, 'imgs'), '--data_dir', os.path.join(tmp, 'data')] + list(extra)
@@ -62,3 +62,25 @@ def test_cli_latent_pipeline(tmp_path):
     assert npy
     img = np.load(npy[0])
     assert img.shape == (8, 1, 32, 32) and np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0
+
+
+def test_cli_vae_baseline(tmp_path):
+    """--model vae (reference run.py:175-176, 261-263, 297-300): train in bf16 through the graphed step,
+    checkpoint under models/vae/, eval and eval_fid images = decoder(randn)."""
+    tmp = str(tmp_path)
+    out = _run(tmp, '--mode', 'train', model='vae')
+    assert 'Epoch' in out and 'Loss' in out
+    ckpt = glob.glob(os.path.join(tmp, 'models', 'vae', '*', 'model-2.pth'))
+    assert len(ckpt) == 1
+    sd = torch.load(ckpt[0], map_location='cpu')
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    assert any(k.startswith('decoder.fc_a') for k in sd) and any(k.startswith('encoder.') for k in sd)
+    _run(tmp, '--mode', 'eval', '--sampling_number', '8', model='vae')
+    img = np.load(glob.glob(os.path.join(tmp, 'imgs', 'vae', '*', 'eval', 'sample-*.npy'))[0])
+    assert img.shape == (8, 1, 32, 32) and np.isfinite(img).all()
+    out = _run(tmp, '--mode', 'eval_fid', '--sampling_number', '12', model='vae')
+    assert 'DONE' in out
+    files = sorted(glob.glob(os.path.join(tmp, 'imgs', 'vae', '*', 'eval-fid-fast', 'sample-*.npy')))
+    assert len(files) == 2          # batches of 8 + 4
+    img = np.load(files[1])
+    assert img.shape == (4, 1, 32, 32) and img.min() >= 0.0 and img.max() <= 1.0

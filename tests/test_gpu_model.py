@@ -595,3 +595,47 @@ def test_graphed_train_step_replays_and_follows_lr_changes():
     assert torch.equal(w.detach(), before)             # lr = 0 reached the replayed kernels
     short = x[:2]                                      # a short last batch runs eagerly, same optimizer
     assert np.isfinite(float(step(short, 0)))
+
+
+@pytest.mark.parametrize('tag,kw', [('fmnist_vae', dict(a_dim=32, mmd_weight=0.1)),
+                                    ('fmnist_vae_kld', dict(a_dim=32, mmd_weight=0.0, kld_weight=0.01))])
+def test_vae_baseline_vs_reference(tag, kw):
+    """--model vae (models.py:521-603, 781-833): loss, reconstruction, gradients and decoder(a) against the
+    reference fixture; widths run up to 8*ch with 4x4 feature maps, i.e. the kernels' small-map paths."""
+    from infodiffusion_amd.models import VAE
+    cfg = O.dataset_cfg('fmnist', **kw)
+    g = gold('model_' + tag)
+    args = args_of(cfg, act_dtype='fp32')
+    model = VAE(args, DEV, cfg.shape)
+    model.load_state_dict(O.synth_state_dict(manifest('manifest_' + tag)), strict=True)
+    model.eval()
+    draws = iter([g['reparam'], g['prior']])
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: next(draws).to(t.device)
+    try:
+        loss = model.loss_fn(args, g['x'].to(DEV))
+    finally:
+        torch.randn_like = orig
+    assert rel(loss, g['loss']) < 1e-4, (float(loss), float(g['loss']))
+    loss.backward()
+    named = dict(model.named_parameters())
+    gn = sum(float(p.grad.double().pow(2).sum()) for p in named.values() if p.grad is not None) ** 0.5
+    assert abs(gn - float(g['grad_norm'])) / float(g['grad_norm']) < 1e-3
+    n = 0
+    for k in g:
+        if k.startswith('g.'):
+            assert named[k[2:]].grad is not None, k
+            e = rel(named[k[2:]].grad, g[k])
+            assert e < 2e-3, (k, e)
+            n += 1
+    assert n >= 8
+    with torch.no_grad():
+        draws = iter([g['reparam']])
+        torch.randn_like = lambda t, **k: next(draws).to(t.device)
+        try:
+            rec = model(g['x'].to(DEV))
+        finally:
+            torch.randn_like = orig
+        dec = model.decoder(g['dec_a'].to(DEV))
+    assert rel(rec, g['rec']) < 1e-4
+    assert rel(dec, g['dec_out']) < 1e-4

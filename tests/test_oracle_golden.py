@@ -1,5 +1,6 @@
 """CPU: the oracle restatement against the fixtures the reference produced
 (tools/gen_golden.py).  This is what pins the oracle."""
+import pytest
 import torch
 
 from oracle import infodiff_oracle as O
@@ -99,6 +100,22 @@ def test_model_fmnist_bottleneck(gold, manifest):
     """--is_bottleneck (BottleneckAuxUNet, models.py:329-421): oracle vs the reference fixture."""
     _model_case(gold, manifest, 'fmnist_bneck',
                 O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1, is_bottleneck=True))
+
+
+@pytest.mark.parametrize('tag,kw', [('fmnist_vae', dict(a_dim=32, mmd_weight=0.1)),
+                                    ('fmnist_vae_kld', dict(a_dim=32, mmd_weight=0.0, kld_weight=0.01))])
+def test_model_vae(gold, manifest, tag, kw):
+    """--model vae (VAE + Decoder, models.py:521-603, 781-833): oracle vs the reference fixture."""
+    cfg = O.dataset_cfg('fmnist', **kw)
+    g = gold('model_' + tag)
+    sd = O.synth_state_dict(manifest('manifest_' + tag))
+    with torch.no_grad():
+        loss, terms = O.vae_loss(sd, cfg, g['x'], prior=g['prior'], reparam_noise=g['reparam'])
+        dec = O.decoder(sd, 'decoder', g['dec_a'], cfg.encoder_channels, O.ch_mult_for(cfg, vanilla=True), cfg.shape)
+    assert rel(terms['rec'], g['rec']) < 2e-5
+    assert rel(terms['a_q'], g['a_q']) < 2e-5
+    assert rel(loss, g['loss']) < 1e-5
+    assert rel(dec, g['dec_out']) < 2e-5
 
 
 def test_model_celeba(gold, manifest):

@@ -297,6 +297,62 @@ def gen_model(tag, cfg, B, seed, grads=True):
     save('model_' + tag, **res)
 
 
+# ------------------------------------------------------------------ VAE baseline
+def gen_vae(tag, cfg, B, seed):
+    """models.py:781-833 + Decoder 521-603: loss terms, reconstruction, picked gradients, decoder(a)."""
+    a = args_for(cfg)
+    shape = cfg.shape
+    torch.manual_seed(0)
+    model = R_models.VAE(a, 'cpu', shape)
+    man, syn = load_synth(model)
+    with open(os.path.join(GOLD, 'manifest_%s.json' % tag), 'w') as f:
+        json.dump([(k, list(s)) for k, s in man], f)
+    model.eval()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    x = torch.rand(B, *shape, generator=g) * 2 - 1
+    torch.manual_seed(seed)     # draw order in loss_fn: reparam noise (encoder), then the prior samples
+    reparam = torch.randn(B, cfg.a_dim)
+    prior = torch.randn(B, cfg.a_dim)
+    torch.manual_seed(seed)
+    model.zero_grad()
+    loss = quiet(model.loss_fn, args=a, x=x)
+    loss.backward()
+    lo, terms = O.vae_loss(syn, cfg, x, prior=prior, reparam_noise=reparam)
+    check(tag + ' loss', lo, loss.detach(), 1e-5)
+    torch.manual_seed(seed)
+    rec, a_q, mu, lv = model.forward(x, get_target=True)
+    check(tag + ' rec', terms['rec'], rec.detach())
+    check(tag + ' a_q', terms['a_q'], a_q.detach())
+    res = dict(x=x, reparam=reparam, prior=prior, loss=loss.detach(), rec=rec.detach(), a_q=a_q.detach(),
+               mu=mu.detach(), log_var=lv.detach(), recon=terms['recon'],
+               mmd=terms.get('mmd', torch.zeros(())), kld=terms.get('kld', torch.zeros(())))
+    named = dict(model.named_parameters())
+    gn = 0.0
+    for k, prm in named.items():
+        if prm.grad is not None:
+            gn += float(prm.grad.double().pow(2).sum())
+    res['grad_norm'] = torch.tensor(gn ** 0.5)
+    for k in ['decoder.fc_a.weight', 'decoder.head.weight', 'decoder.downblocks.0.block1.2.weight',
+              'decoder.middleblocks.0.attn.proj.weight', 'decoder.upblocks.0.shortcut.weight',
+              'decoder.upblocks.11.main.weight', 'decoder.tail.2.weight', 'decoder.tail.0.bias',
+              'encoder.head.weight', 'encoder.fc_a.weight', 'encoder.fc_mu.weight', 'encoder.fc_var.bias',
+              'encoder.downblocks.3.block2.3.weight', 'encoder.tail.2.weight']:
+        if k in named and named[k].grad is not None:
+            res['g.' + k] = named[k].grad.detach()
+    nograd = [k for k, prm in named.items() if prm.requires_grad and prm.grad is None]
+    with open(os.path.join(GOLD, 'nograd_%s.json' % tag), 'w') as f:
+        json.dump(nograd, f)
+    # generation path used by run.py:261-263: decoder(randn)
+    a_in = rnd(seed + 1, B, cfg.a_dim)
+    with torch.no_grad():
+        dec = model.decoder(a_in)
+    check(tag + ' decoder(a)', O.decoder(syn, 'decoder', a_in, cfg.encoder_channels,
+                                         O.ch_mult_for(cfg, vanilla=True), shape), dec)
+    res.update(dec_a=a_in, dec_out=dec)
+    save('model_' + tag, **res)
+
+
 # ------------------------------------------------------------ stub samplers
 def gen_sampler_stub():
     out = {}
@@ -443,7 +499,7 @@ def gen_vanilla_twophase():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'celeba']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'celeba']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -461,6 +517,9 @@ if __name__ == '__main__':
         gen_model('fmnist_kld', O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01), B=3, seed=65)
     if 'bneck' in which:
         gen_model('fmnist_bneck', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1, is_bottleneck=True), B=3, seed=66)
+    if 'vae' in which:
+        gen_vae('fmnist_vae', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1), B=3, seed=67)
+        gen_vae('fmnist_vae_kld', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.0, kld_weight=0.01), B=2, seed=68)
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     print('ALL ORACLE-vs-REFERENCE CHECKS PASSED')

@@ -5,9 +5,9 @@
         --batch_size 32 --save_epochs 5 --deterministic --prior regular --r_seed 64        # reference run.sh:3
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run.py ... (data parallel)
 
-Modes on the hot path: train, eval, eval_fid, save_latent, train_latent_ddim.  The analysis modes
-(disentangle / interpolate / latent_quality / plot_latent / save_original_img) are outside it
-(SURVEY.md 2, row 7).  Extra flags: --act_dtype {fp32,bf16}, --steps_per_epoch N (synthetic data).
+Modes: train, eval, eval_fid, save_latent, train_latent_ddim, and the latent-editing callers of the samplers
+(interpolate / disentangle / latent_quality).  plot_latent / save_original_img need matplotlib / image files
+and are not provided.  Extra flags: --act_dtype {fp32,bf16}, --steps_per_epoch N (synthetic data).
 Images are written as .npy (torchvision is not available in this image).
 """
 import argparse
@@ -23,7 +23,7 @@ from infodiffusion_amd.optim import FusedClipAdamW
 from infodiffusion_amd.trainer import GraphedTrainStep
 from infodiffusion_amd.models import VAE, Diff, InfoDiff
 from infodiffusion_amd.sampling import DiffusionProcess, LatentDiffusionProcess, TwoPhaseDiffusionProcess
-from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter,
+from infodiffusion_amd.utils import (AverageMeter, GradualWarmupScheduler, LatentDataset, ProgressMeter, cos,
                                      generate_exp_string, seed_everything)
 
 
@@ -148,6 +148,59 @@ def _load(model, path, dev, strict):
     model.load_state_dict(torch.load(path, map_location=dev), strict=strict)
 
 
+def _pick_batch(args, shape, dev, rank, world, index):
+    for i, data in enumerate(get_dataset(args, shape, dev, rank, world)):
+        if i == index:
+            break
+    return data[0].to(dev)
+
+
+def _latent_edit(args, model, dev, shape, out_root, rank, world):
+    """The callers that invert an image and re-generate it under an edited latent (reference run.py:310-337
+    latent_quality, 366-414 disentangle, 444-481 interpolate): encoder -> reverse_sampling (DDIM inversion,
+    the encoder is re-run on x_t every step as in sampling.py:84) -> sampling(xT=..., a=...)."""
+    vae = args.model == 'vae'
+    proc = None if vae else DiffusionProcess(args, model, dev, shape)
+    data = _pick_batch(args, shape, dev, rank, world, 10 if args.mode == 'latent_quality' else args.img_id)
+    with torch.no_grad():
+        a, _, mu, log_var = model.encoder(data)
+    if args.kld_weight != 0:
+        a = mu + torch.exp(0.5 * log_var) if args.mode == 'latent_quality' else mu
+    a = a.float()
+    out_dir = os.path.join(out_root, args.mode)
+    os.makedirs(out_dir, exist_ok=True)
+
+    def emit(sample, k=0):
+        np.save(os.path.join(out_dir, 'sample%05d.npy' % k), sample.float().cpu().numpy())
+
+    if args.mode == 'latent_quality':
+        # same latent, fresh x_T draws: how much of the image the latent alone pins down
+        xT = proc.reverse_sampling(data, a)
+        n = args.sampling_number
+        batch = proc.sampling(xT=torch.randn_like(xT.repeat(n, 1, 1, 1)), a=a.repeat(n, 1))
+        emit((torch.clip(batch.float(), min=-1, max=1) + 1) / 2)
+    elif args.mode == 'disentangle':
+        eta = [-1.5, -1.2, -0.9, -0.6, -0.3, 0.0, 0.3, 0.6, 0.9, 1.2, 1.5]
+        xT = None if vae else proc.reverse_sampling(data, a).repeat(len(eta), 1, 1, 1)
+        for k in range(args.a_dim):
+            rows = a[:1].repeat(len(eta), 1)
+            rows[:, k] = torch.tensor(eta, device=dev)         # traverse one latent coordinate
+            with torch.no_grad():
+                emit(model.decoder(rows) if vae else proc.sampling(xT=xT, a=rows), k)
+    else:
+        eta = [0.0, 0.11, 0.22, 0.33, 0.44, 0.55, 0.66, 0.77, 0.88, 1.0]
+        intp_a = torch.stack([np.cos(e * np.pi / 2) * a[0] + np.sin(e * np.pi / 2) * a[1] for e in eta])
+        if vae:
+            with torch.no_grad():
+                emit(model.decoder(intp_a))
+            return
+        xT = proc.reverse_sampling(data, a).float().contiguous()
+        theta = torch.arccos(cos(xT[0], xT[1]))     # spherical interpolation of the two inverted x_T
+        intp_x = torch.stack([(torch.sin((1 - e) * theta) * xT[0] + torch.sin(e * theta) * xT[1]) / torch.sin(theta)
+                              for e in eta])
+        emit(proc.sampling(xT=intp_x, a=intp_a))
+
+
 def evaluate(args):
     world, rank, dev = _dist_setup()
     if args.mode == 'train_latent_ddim':
@@ -216,8 +269,10 @@ def evaluate(args):
             all_a.append((mu if args.kld_weight != 0 else a).cpu().numpy())
         np.savez('%s_%s_latent' % (args.model, generate_exp_string(args).replace('.', '_')),
                  all_a=np.concatenate(all_a), all_attr=np.zeros(len(all_a)))
+    elif args.mode in ('interpolate', 'disentangle', 'latent_quality'):
+        _latent_edit(args, model, dev, shape, out_root, rank, world)
     else:
-        raise NotImplementedError('mode %s is analysis tooling outside the hot path (SURVEY.md 2, row 7)' % args.mode)
+        raise NotImplementedError('mode %s needs matplotlib / image files (SURVEY.md 2, row 7)' % args.mode)
 
 
 if __name__ == '__main__':

@@ -84,3 +84,21 @@ def test_cli_vae_baseline(tmp_path):
     assert len(files) == 2          # batches of 8 + 4
     img = np.load(files[1])
     assert img.shape == (4, 1, 32, 32) and img.min() >= 0.0 and img.max() <= 1.0
+
+
+def test_cli_latent_editing_modes(tmp_path):
+    """interpolate / disentangle / latent_quality (reference run.py:310-337, 366-414, 444-481): encoder ->
+    DDIM inversion -> sampling(xT=, a=) with edited latents, through the CLI on a trained checkpoint."""
+    tmp = str(tmp_path)
+    _run(tmp, '--mode', 'train')
+    _run(tmp, '--mode', 'interpolate', '--deterministic')
+    img = np.load(glob.glob(os.path.join(tmp, 'imgs', '*', 'interpolate', 'sample*.npy'))[0])
+    assert img.shape == (10, 1, 32, 32) and np.isfinite(img).all()
+    _run(tmp, '--mode', 'latent_quality', '--deterministic', '--sampling_number', '4')
+    img = np.load(glob.glob(os.path.join(tmp, 'imgs', '*', 'latent_quality', 'sample*.npy'))[0])
+    assert img.shape == (4, 1, 32, 32) and img.min() >= 0.0 and img.max() <= 1.0
+    _run(tmp, '--mode', 'disentangle', '--deterministic', '--diffusion_steps', '40')
+    files = sorted(glob.glob(os.path.join(tmp, 'imgs', '*', 'disentangle', 'sample*.npy')))
+    assert len(files) == 32                                   # one traversal per latent coordinate
+    img = np.load(files[5])
+    assert img.shape == (11, 1, 32, 32) and np.isfinite(img).all()

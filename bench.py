@@ -334,7 +334,7 @@ def main():
         # dominant kernel: the halo 3x3 conv (forward + data-gradient launches)
         tm = ConvTimer()
         tm.install()
-        step_eager(0)
+        fwd_bwd()       # every conv launch of a step; no exchange / optimizer: the other ranks are not in this block
         tm.remove()
         torch.cuda.synchronize()
         nrep = 1

@@ -12,7 +12,7 @@ gradients move as dense memory), and each bucket's all-reduce is issued on a sid
 stream as soon as it is packed, so packing bucket k+1 overlaps the wire time of
 bucket k.  Gradients that already live in the optimizer's gradient arena (grad_arena.py: every
 conv / GroupNorm gradient the kernels accumulated in place) need no packing at all: the arena's flat
-buffer is all-reduced in place, in bucket-sized pieces.  Parameters that never receive a gradient (the dead `crossattn.*`
+buffer is all-reduced in place as one collective.  Parameters that never receive a gradient (the dead `crossattn.*`
 weights, `encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are
 skipped.
 """
@@ -104,17 +104,15 @@ class GradSync:
         if self.arena is not None and any(self.arena.holds(g) for g in grads):
             # zero-copy part: the arena itself, piecewise (slots nobody wrote this step hold zeros)
             grads = [g for g in grads if not self.arena.holds(g)]
+            # ONE collective over the whole arena: nothing is left to overlap with once backward has ended, and a
+            # ring over point-to-point xGMI links is per-link bound -- fewer, larger messages
             flat = self.arena.flat
-            step = max(1, self.bucket_bytes // 4)
             if use_side:
                 self._side.wait_stream(cur)
-            for off in range(0, flat.numel(), step):
-                piece = flat[off:off + step]
-                if use_side:
-                    with torch.cuda.stream(self._side):
-                        self._reduce_mean(piece)
-                else:
-                    self._reduce_mean(piece)
+                with torch.cuda.stream(self._side):
+                    self._reduce_mean(flat)
+            else:
+                self._reduce_mean(flat)
         plan = self._make_plan(grads) if grads else []
         i = 0
         for flat, views, n in plan:

@@ -5,13 +5,24 @@ Each step = one network evaluation + ONE fused update kernel (`idf_sampler_step`
 that gathers the step's scalars from a table built once with the reference's own fp32
 expressions and applies them in the reference's operation order, so no host scalar math, no tiny-op swarm and no
 per-step H2D copies remain.  The state `x` is kept in fp32.
+
+Small batches (the reference's own eval / interpolate / disentangle flows run 10-16 images) are host-bound when
+every step's ~250 launches are issued from Python, so there ONE step (timestep read from a device counter that
+the step itself advances) is captured into a hipGraph and replayed for the inner steps; first and last step run
+eagerly.  Large batches are GPU-bound and stay eager (a capture would only cost its private memory pool).
 """
+import os
+import sys
+
 import torch
 
 from . import ops
 
 _DDPM, _DDIM, _REV = 0, 1, 2
 ETA = 0.01     # sampling.py:45
+GRAPH = os.environ.get('IDF_SAMPLER_GRAPH', '1') != '0'
+GRAPH_MIN_STEPS = 8
+GRAPH_MAX_PIXELS = 64 * 64 * 64      # batch x H x W up to which a step is launch-bound (64 CelebA images)
 
 
 def _tables(args, device):
@@ -53,8 +64,72 @@ class _ProcessBase:
         xo, _ = ops.sampler_step(x, eps_hat, noise, self._steps[idx:idx + 1], self._coef[mode], mode)
         return xo
 
+    def _update_t(self, x, eps_hat, idx_t, mode, noise):
+        """As _update with the timestep in a 1-element device tensor."""
+        x = x.float()
+        if x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+            eps_hat = eps_hat.contiguous(memory_format=torch.channels_last)
+            if noise is not None:
+                noise = noise.float().contiguous(memory_format=torch.channels_last)
+        else:
+            x, eps_hat = x.contiguous(), eps_hat.contiguous()
+        return ops.sampler_step(x, eps_hat, noise, idx_t, self._coef[mode], mode)[0]
+
+    def _graph_ok(self, x, steps):
+        if not (GRAPH and x.is_cuda) or torch.is_grad_enabled() or '_randn_like' in self.__dict__:
+            return False
+        per = x[0].numel() // (x.shape[1] if x.dim() == 4 else 1)
+        return steps >= GRAPH_MIN_STEPS and x.shape[0] * per <= GRAPH_MAX_PIXELS \
+            and not torch.cuda.is_current_stream_capturing()
+
+    def _graphed(self, x, eps_fn, mode, first, delta, count):
+        """Generator over `count` steps idx = first, first+delta, ...: the step is captured once and replayed.
+        x must come from an eagerly executed step (weight shadows / allocator already warm)."""
+        xs = x.float().clone()
+        if xs.dim() == 4:
+            xs = xs.contiguous(memory_format=torch.channels_last)
+        idx_t = torch.full((1,), first, dtype=torch.long, device=xs.device)
+        n = xs.shape[0]
+
+        def body():
+            t = idx_t.expand(n).contiguous()
+            if mode == _DDPM:
+                noise = torch.randn_like(xs)          # reference order: noise before the network call
+                eps_hat = eps_fn(xs, t)
+            else:
+                eps_hat = eps_fn(xs, t)
+                noise = torch.randn_like(xs) if mode == _DDIM else None
+            xs.copy_(self._update_t(xs, eps_hat, idx_t, mode, noise))
+            idx_t.add_(delta)
+
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                body()
+        except Exception as e:  # noqa: BLE001
+            print('sampler step capture failed (%s: %s); stepping eagerly' % (type(e).__name__, str(e)[:200]),
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            g = None
+            idx_t.fill_(first)
+        for _ in range(count):
+            if g is not None:
+                g.replay()
+            else:
+                body()
+            yield xs.clone()
+
     def _loop(self, x, eps_fn, deterministic):
-        for idx in reversed(range(len(self.alpha_bars))):
+        T = len(self.alpha_bars)
+        mode = _DDIM if deterministic else _DDPM
+        graphed = self._graph_ok(x, T - 2)
+        for idx in reversed(range(T)):
+            if graphed and idx == T - 2:
+                for x in self._graphed(x, eps_fn, mode, idx, -1, T - 2):      # steps T-2 ... 1
+                    yield x
+            if graphed and 0 < idx < T - 1:
+                continue
             if deterministic:
                 eps_hat = eps_fn(x, idx)
                 noise = None if idx == 0 else self._randn_like(x)
@@ -66,7 +141,14 @@ class _ProcessBase:
             yield x
 
     def _reverse_loop(self, x, eps_fn):
-        for idx in range(len(self.alpha_bars) - 1):
+        T = len(self.alpha_bars)
+        graphed = self._graph_ok(x, T - 3)
+        for idx in range(T - 1):
+            if graphed and idx == 2:
+                for x in self._graphed(x, eps_fn, _REV, idx, 1, T - 3):       # steps 2 ... T-2
+                    yield x
+            if graphed and idx >= 2:
+                continue
             if idx > 0:
                 x = self._update(x, eps_fn(x, idx), idx, _REV, None)
             yield x

@@ -639,3 +639,52 @@ def test_vae_baseline_vs_reference(tag, kw):
         dec = model.decoder(g['dec_a'].to(DEV))
     assert rel(rec, g['rec']) < 1e-4
     assert rel(dec, g['dec_out']) < 1e-4
+
+
+def test_graphed_sampler_steps_match_eager_steps():
+    """Small batches replay ONE captured step (device-side timestep counter) for the inner steps of the DDPM /
+    DDIM / reverse-DDIM loops: same trajectory as stepping eagerly, for InfoDiff, the vanilla model pair and
+    the latent sampler."""
+    from infodiffusion_amd import sampling as S
+    from infodiffusion_amd.sampling import DiffusionProcess
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1, diffusion_steps=24, deterministic=True)
+    model, args, sd = make_infodiff(cfg, DEV, 'fp32')
+    model.eval()
+    used = []
+    orig = S._ProcessBase._graphed
+
+    def counting(self, *a, **k):
+        used.append(a[2])
+        return orig(self, *a, **k)
+    S._ProcessBase._graphed = counting
+    try:
+        g = torch.Generator(device='cpu')
+        g.manual_seed(3)
+        x0 = (torch.rand(4, *cfg.shape, generator=g) * 2 - 1).to(DEV)
+        xT = torch.randn(4, *cfg.shape, generator=g).to(DEV)
+        a = torch.randn(4, 32, generator=g).to(DEV)
+        out = {}
+        for graph in (False, True):
+            S.GRAPH = graph
+            for det in (True, False):
+                args.deterministic = det
+                proc = DiffusionProcess(args, model, DEV, cfg.shape)
+                torch.manual_seed(11)
+                out[graph, 'fwd', det] = proc.sampling(xT=xT, a=a)
+                with torch.no_grad():
+                    torch.manual_seed(11)
+                    out[graph, 'trace', det] = list(proc._one_diffusion_step(xT, a, det))
+            out[graph, 'rev'] = proc.reverse_sampling(x0)
+        assert used.count(S._DDIM) == 2 and used.count(S._DDPM) == 2 and used.count(S._REV) == 1
+        # the inversion has no noise term: the replayed steps are the eager steps, bit for bit
+        assert torch.equal(out[True, 'rev'], out[False, 'rev'])
+        for det in (True, False):
+            tr_e, tr_g = out[False, 'trace', det], out[True, 'trace', det]
+            assert len(tr_e) == len(tr_g) == 24
+            # the noise draws come from the same Philox stream either way (same seed, same draw sizes)
+            for k in range(24):
+                assert rel(tr_g[k], tr_e[k]) < 1e-5, (det, k, rel(tr_g[k], tr_e[k]))
+            assert rel(out[True, 'fwd', det], out[False, 'fwd', det]) < 1e-5
+    finally:
+        S._ProcessBase._graphed = orig
+        S.GRAPH = True

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--sampling', action='store_true', help='also time DDIM-100 sampling (B=256)')
     ap.add_argument('--sampling-batch', type=int, default=256)
+    ap.add_argument('--no-large-batch', action='store_true', help='skip the supplementary B=128 training rate')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -203,6 +204,38 @@ class ConvTimer:
             by += count * (x.numel() + y.numel() + (residual.numel() if residual is not None else 0)
                            + w_fwd.numel()) * x.element_size()
         return n, tot_ms, fl, by
+
+
+def large_batch_rate(a, margs, dev, batch=128, steps=10):
+    """Supplementary, NOT `value`: the same training step at a per-GPU batch of 128 through the product's own
+    `GraphedTrainStep` (run.py's path) -- at B = 32 most launches are one wave of workgroups and the ~3.3 us
+    per-launch floor is a fifth of the step; this shows the kernels with four times the work per launch."""
+    import copy
+    from infodiffusion_amd.models import InfoDiff
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    args = copy.copy(margs)
+    args.batch_size = batch
+    torch.manual_seed(65)
+    model = InfoDiff(args, dev, (3, 64, 64)).train()
+    opt = FusedClipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, max_norm=1.0)
+    step = GraphedTrainStep(model, args, opt, use_graph=bool(a.graph))
+    g = torch.Generator(device='cpu')
+    g.manual_seed(65)
+    pool = [(torch.rand(batch, 3, 64, 64, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
+            for _ in range(2)]
+    for i in range(5):
+        step(pool[i % 2], 0)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(steps):
+        step(pool[i % 2], 0)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    del step, opt, model
+    torch.cuda.empty_cache()
+    return {'per_gpu_batch': batch, 'value': round(batch * steps / dt, 2), 'unit': 'images/s',
+            'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'note': 'supplementary; value above is B=32'}
 
 
 def main():
@@ -368,6 +401,8 @@ def main():
         out['sampling'] = {'metric': 'DDIM-100 sampling images/sec (B=%d, 100 network evaluations)' % a.sampling_batch,
                            'value': round(a.sampling_batch / ds, 2), 'unit': 'images/s', 'seconds': round(ds, 3)}
 
+    if rank == 0 and world == 1 and not a.no_large_batch:
+        out['large_batch'] = large_batch_rate(a, margs, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(margs)
     if rank == 0:

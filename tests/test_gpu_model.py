@@ -450,9 +450,10 @@ def test_fused_optimizer_and_graph_replay_track_the_reference_optimizer():
         assert abs(a - b) / abs(b) < 2e-4, (graph, ref)
 
 
-@pytest.mark.parametrize('ds,a_dim,B', [('celeba', 256, 2), ('cifar10', 32, 3)])
+@pytest.mark.parametrize('ds,a_dim,B', [('celeba', 256, 2), ('cifar10', 32, 3), ('chairs', 32, 1)])
 def test_other_configs_vs_oracle(ds, a_dim, B):
-    """BASELINE configs[3] (CelebA a_dim=256 train step) and configs[4] (CIFAR-10 32x32 shape):
+    """BASELINE configs[3] (CelebA a_dim=256 train step) and configs[4] (CIFAR-10 32x32 shape), plus the
+    3D-chairs shape of data.py:96-99 (64x64 images on 32-wide nets: one channel per GroupNorm group) at batch 1:
     loss + gradient norm of a train step and a sampling-path epsilon vs the CPU oracle."""
     cfg = O.dataset_cfg(ds, a_dim=a_dim, mmd_weight=0.1)
     model, args, sd = make_infodiff(cfg, DEV, 'fp32')

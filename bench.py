@@ -17,6 +17,7 @@ timed), `cpu_baseline` (the CPU oracle on the host cores, rank 0 at N = 1),
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -243,6 +244,13 @@ def main():
     if a.cpu_baseline_worker:
         cpu_baseline_worker(a.a_dim, a.cpu_baseline_worker)
         return
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the one-process-per-GPU job as a CHILD (nothing here has touched
+        # the GPU yet) and leave with its exit code
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', os.environ.get('MASTER_PORT', '29541'),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

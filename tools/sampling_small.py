@@ -16,7 +16,7 @@ cfg = O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1, diffusion_steps=100, det
 args = args_of(cfg, act_dtype='bf16')
 model = InfoDiff(args, torch.device('cuda'), cfg.shape).eval()
 proc = S.DiffusionProcess(args, model, torch.device('cuda'), cfg.shape)
-for B in (1, 16, 32, 64, 128, 256):
+for B in ([int(v) for v in sys.argv[1:]] or [1, 16, 32, 64, 128, 256]):
     row = []
     for graph in (False, True):
         S.GRAPH = graph

@@ -11,8 +11,7 @@ from torch.nn import init
 
 from . import ops
 from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
-                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, film_groups,
-                      timestep_embedding)
+                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, film_groups)
 from .utils import compute_mmd, gaussian_mixture, swiss_roll
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,

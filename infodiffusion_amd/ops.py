@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import call, F32, BF16
-from .grad_arena import slot_of, ParamGroup
+from .grad_arena import slot_of, ParamGroup  # noqa: F401  (modules.py reaches ParamGroup through ops)
 
 GN_EPS = 1e-5
 S1, S2, UP2, T2 = 0, 1, 2, 3

@@ -4,7 +4,7 @@ kernel launches over a device-side chunk table -- same arithmetic as
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import ops
 from .grad_arena import GradArena
 from ._lib import call
 

@@ -6,8 +6,8 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run.py ... (data parallel)
 
 Modes: train, eval, eval_fid, save_latent, train_latent_ddim, and the latent-editing callers of the samplers
-(interpolate / disentangle / latent_quality).  plot_latent / save_original_img need matplotlib / image files
-and are not provided.  Extra flags: --act_dtype {fp32,bf16}, --steps_per_epoch N (synthetic data).
+(interpolate / disentangle / latent_quality), plot_latent (matplotlib scatter) and save_original_img.
+Extra flags: --act_dtype {fp32,bf16}, --steps_per_epoch N (synthetic data), --graph {0,1}.
 Images are written as .npy (torchvision is not available in this image).
 """
 import argparse
@@ -271,13 +271,35 @@ def evaluate(args):
                  all_a=np.concatenate(all_a), all_attr=np.zeros(len(all_a)))
     elif args.mode in ('interpolate', 'disentangle', 'latent_quality'):
         _latent_edit(args, model, dev, shape, out_root, rank, world)
+    elif args.mode == 'plot_latent':
+        # reference run.py:338-365: scatter of the first two latent coordinates, coloured by the batch's labels
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+        all_a, all_attr = [], []
+        for data in get_dataset(args, shape, dev, rank, world):
+            with torch.no_grad():
+                a, _, mu, _ = model.encoder(data[0].to(dev))
+            use_mu = args.kld_weight != 0 and args.mmd_weight == 0
+            all_a.append((mu if use_mu else a).float().cpu().numpy())
+            all_attr.append(np.asarray(data[1]))
+        all_a, all_attr = np.concatenate(all_a), np.concatenate(all_attr)
+        plt.scatter(all_a[:, 0], all_a[:, 1], c=all_attr, cmap='tab10', s=5)
+        os.makedirs(out_root, exist_ok=True)
+        plt.savefig(os.path.join(out_root, 'latent.png'))
     else:
-        raise NotImplementedError('mode %s needs matplotlib / image files (SURVEY.md 2, row 7)' % args.mode)
+        raise NotImplementedError('mode %s' % args.mode)
 
 
 if __name__ == '__main__':
     args = parse_args()
-    if args.mode == 'train':
+    if args.mode == 'save_original_img':
+        # reference run.py:540-549: the dataset's images in [0, 1] (here as .npy batches; no model, no GPU kernels)
+        out = './%s_imgs/' % args.dataset
+        os.makedirs(out, exist_ok=True)
+        for i, data in enumerate(get_dataset(args, get_dataset_config(args), 'cpu')):
+            np.save(os.path.join(out, '%06d.npy' % i), ((data[0] + 1) / 2).numpy())
+    elif args.mode == 'train':
         train(args)
     else:
         if args.mode in ('disentangle', 'latent_quality'):

@@ -52,3 +52,27 @@ def test_synthetic_batches_are_normalised_and_sharded():
     assert len(b0) == 3 and b0[0].shape == (4, 3, 8, 8)
     assert float(b0[0].min()) >= -1 and float(b0[0].max()) <= 1
     assert not torch.equal(b0[0], b1[0])
+
+
+def test_save_original_img_mode_runs_without_a_gpu(tmp_path):
+    """--mode save_original_img (reference run.py:540-549): dataset images in [0, 1], no model involved."""
+    import glob
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(tmp_path / 'data')
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, (8, 32, 32, 1), dtype=np.uint8)
+    np.save(tmp_path / 'data' / 'fmnist.npy', raw)
+    r = subprocess.run([sys.executable, os.path.join(root, 'run.py'), '--model', 'diff', '--mode', 'save_original_img',
+                        '--prior', 'regular', '--dataset', 'fmnist', '--a_dim', '32', '--batch_size', '4',
+                        '--data_dir', str(tmp_path / 'data')], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(glob.glob(str(tmp_path / 'fmnist_imgs' / '*.npy')))
+    assert len(files) == 2
+    img = np.load(files[0])
+    assert img.shape == (4, 1, 32, 32)
+    assert np.allclose(img, raw[:4].transpose(0, 3, 1, 2) / 255.0, atol=1e-6)

@@ -97,6 +97,8 @@ def test_cli_latent_editing_modes(tmp_path):
     _run(tmp, '--mode', 'latent_quality', '--deterministic', '--sampling_number', '4')
     img = np.load(glob.glob(os.path.join(tmp, 'imgs', '*', 'latent_quality', 'sample*.npy'))[0])
     assert img.shape == (4, 1, 32, 32) and img.min() >= 0.0 and img.max() <= 1.0
+    _run(tmp, '--mode', 'plot_latent')
+    assert os.path.getsize(glob.glob(os.path.join(tmp, 'imgs', '*', 'latent.png'))[0]) > 1000
     _run(tmp, '--mode', 'disentangle', '--deterministic', '--diffusion_steps', '40')
     files = sorted(glob.glob(os.path.join(tmp, 'imgs', '*', 'disentangle', 'sample*.npy')))
     assert len(files) == 32                                   # one traversal per latent coordinate

@@ -689,3 +689,25 @@ def test_graphed_sampler_steps_match_eager_steps():
     finally:
         S._ProcessBase._graphed = orig
         S.GRAPH = True
+
+
+def test_kl_capacity_branch_vs_reference():
+    """--use_C (models.py:662-671): |KL - C(epoch)| with C = clamp(C_max / epochs * epoch) at epoch 3, both
+    auxiliary weights non-zero (MMD on mu + KL): loss and the encoder-head gradients vs the reference fixture."""
+    cfg = O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01, use_C=True, C_max=25.0, epochs=20)
+    g = gold('priors_capacity')
+    model, args, sd = make_infodiff(cfg, DEV, 'fp32', 'manifest_fmnist_kld')
+    model.eval()
+    draws = iter([g['eps'], g['reparam'], g['prior']])
+    orig_randn_like, orig_randint = torch.randn_like, torch.randint
+    torch.randn_like = lambda t, **kw: next(draws).to(t.device)
+    torch.randint = lambda *a, **kw: g['idx'].clone()
+    try:
+        loss = model.loss_fn(args_of(cfg), g['x'].to(DEV), curr_epoch=int(g['epoch']))
+    finally:
+        torch.randn_like, torch.randint = orig_randn_like, orig_randint
+    assert rel(loss, g['loss']) < 1e-4, (float(loss), float(g['loss']))
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in ('encoder.fc_mu.weight', 'encoder.fc_var.bias'):
+        assert rel(named[k].grad, g['g.' + k]) < 2e-3, k

@@ -353,6 +353,44 @@ def gen_vae(tag, cfg, B, seed):
     save('model_' + tag, **res)
 
 
+# ------------------------------------------------------------------ priors / KL capacity
+def gen_priors_and_capacity():
+    """utils.py:11-40 (the '10mix' / 'roll' priors, host numpy RNG) and the --use_C branch of
+    InfoDiff.loss_fn (models.py:662-671) at a non-zero epoch."""
+    np.random.seed(5)
+    mix = R_utils.gaussian_mixture(6, 8)
+    np.random.seed(6)
+    roll = R_utils.swiss_roll(7)
+    res = dict(mix=mix, roll=roll)
+    cfg = O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01, use_C=True, C_max=25.0, epochs=20)
+    a = args_for(cfg)
+    torch.manual_seed(0)
+    model = R_models.InfoDiff(a, 'cpu', cfg.shape)
+    man, syn = load_synth(model)
+    model.eval()
+    B, seed, epoch = 2, 71, 3
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    x = torch.rand(B, *cfg.shape, generator=g) * 2 - 1
+    torch.manual_seed(seed)
+    idx = torch.randint(0, cfg.diffusion_steps, (B,))
+    eps = torch.randn_like(x)
+    reparam = torch.randn(B, cfg.a_dim)
+    prior = torch.randn(B, cfg.a_dim)
+    torch.manual_seed(seed)
+    loss = quiet(model.loss_fn, args=a, x=x, curr_epoch=epoch)
+    loss.backward()
+    sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+    lo, terms = O.infodiff_loss(syn, cfg, x, idx, eps, sched, prior=prior, reparam_noise=reparam, curr_epoch=epoch)
+    check('use_C loss', lo, loss.detach(), 1e-5)
+    named = dict(model.named_parameters())
+    res.update(x=x, idx=idx, eps=eps, reparam=reparam, prior=prior, loss=loss.detach(), kld=terms['kld'],
+               epoch=torch.tensor(epoch))
+    res['g.encoder.fc_mu.weight'] = named['encoder.fc_mu.weight'].grad
+    res['g.encoder.fc_var.bias'] = named['encoder.fc_var.bias'].grad
+    save('priors_capacity', **res)
+
+
 # ------------------------------------------------------------ stub samplers
 def gen_sampler_stub():
     out = {}
@@ -499,7 +537,7 @@ def gen_vanilla_twophase():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'celeba']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'celeba']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -520,6 +558,8 @@ if __name__ == '__main__':
     if 'vae' in which:
         gen_vae('fmnist_vae', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1), B=3, seed=67)
         gen_vae('fmnist_vae_kld', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.0, kld_weight=0.01), B=2, seed=68)
+    if 'priors' in which:
+        gen_priors_and_capacity()
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     print('ALL ORACLE-vs-REFERENCE CHECKS PASSED')

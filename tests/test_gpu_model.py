@@ -711,3 +711,28 @@ def test_kl_capacity_branch_vs_reference():
     named = dict(model.named_parameters())
     for k in ('encoder.fc_mu.weight', 'encoder.fc_var.bias'):
         assert rel(named[k].grad, g['g.' + k]) < 2e-3, k
+
+
+@pytest.mark.parametrize('tag,kw', [('plain', dict(mmd_weight=0.0, kld_weight=0.0)),
+                                    ('kld_only', dict(mmd_weight=0.0, kld_weight=0.01))])
+def test_loss_branches_vs_reference(tag, kw):
+    """The two remaining branches of InfoDiff.loss_fn / forward (models.py:648-696, 714-721): no auxiliary term
+    (backbone conditioned on a, fc_mu / fc_var get no gradient) and KL only (backbone on a_q)."""
+    cfg = O.dataset_cfg('fmnist', a_dim=16, **kw)
+    g = gold('loss_branches')
+    model, args, sd = make_infodiff(cfg, DEV, 'fp32', 'manifest_fmnist_kld')
+    model.eval()
+    draws = iter([g[tag + '.eps'], g[tag + '.reparam']])
+    orig_randn_like, orig_randint = torch.randn_like, torch.randint
+    torch.randn_like = lambda t, **k: next(draws).to(t.device)
+    torch.randint = lambda *a, **k: g[tag + '.idx'].clone()
+    try:
+        loss = model.loss_fn(args_of(cfg), g[tag + '.x'].to(DEV))
+    finally:
+        torch.randn_like, torch.randint = orig_randn_like, orig_randint
+    assert rel(loss, g[tag + '.loss']) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in ('encoder.fc_a.weight', 'backbone.fc_a.weight'):
+        assert rel(named[k].grad, g['%s.g.%s' % (tag, k)]) < 2e-3, k
+    assert (named['encoder.fc_mu.weight'].grad is not None) == bool(g[tag + '.has_mu_grad'])

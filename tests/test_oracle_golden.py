@@ -173,3 +173,17 @@ def test_priors_and_kl_capacity(gold, manifest):
         loss, terms = O.infodiff_loss(sd, cfg, g['x'], g['idx'], g['eps'], sched, prior=g['prior'],
                                       reparam_noise=g['reparam'], curr_epoch=int(g['epoch']))
     assert rel(loss, g['loss']) < 1e-5 and rel(terms['kld'], g['kld']) < 1e-5
+
+
+@pytest.mark.parametrize('tag,kw', [('plain', dict(mmd_weight=0.0, kld_weight=0.0)),
+                                    ('kld_only', dict(mmd_weight=0.0, kld_weight=0.01))])
+def test_loss_branches(gold, manifest, tag, kw):
+    """models.py:648-696 / 714-721 without an auxiliary term and with the KL term alone (backbone on a_q)."""
+    g = gold('loss_branches')
+    cfg = O.dataset_cfg('fmnist', a_dim=16, **kw)
+    sd = O.synth_state_dict(manifest('manifest_fmnist_kld'))
+    sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+    with torch.no_grad():
+        loss, terms = O.infodiff_loss(sd, cfg, g[tag + '.x'], g[tag + '.idx'], g[tag + '.eps'], sched, prior=None,
+                                      reparam_noise=g[tag + '.reparam'])
+    assert rel(loss, g[tag + '.loss']) < 1e-5 and rel(terms['out'], g[tag + '.out']) < 2e-5

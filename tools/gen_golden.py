@@ -391,6 +391,43 @@ def gen_priors_and_capacity():
     save('priors_capacity', **res)
 
 
+# ------------------------------------------------------------------ remaining loss / forward branches
+BRANCHES = [('plain', dict(mmd_weight=0.0, kld_weight=0.0)), ('kld_only', dict(mmd_weight=0.0, kld_weight=0.01))]
+
+
+def gen_branches():
+    """models.py:648-696 / 714-721: no auxiliary term (backbone on a), KL only (backbone on a_q)."""
+    res = {}
+    for tag, kw in BRANCHES:
+        cfg = O.dataset_cfg('fmnist', a_dim=16, **kw)
+        a = args_for(cfg)
+        torch.manual_seed(0)
+        model = R_models.InfoDiff(a, 'cpu', cfg.shape)
+        man, syn = load_synth(model)
+        model.eval()
+        B, seed = 2, 81
+        g = torch.Generator(device='cpu')
+        g.manual_seed(seed)
+        x = torch.rand(B, *cfg.shape, generator=g) * 2 - 1
+        torch.manual_seed(seed)
+        idx = torch.randint(0, cfg.diffusion_steps, (B,))
+        eps = torch.randn_like(x)
+        reparam = torch.randn(B, cfg.a_dim)
+        torch.manual_seed(seed)
+        loss = quiet(model.loss_fn, args=a, x=x)
+        loss.backward()
+        sched = O.noise_schedule(cfg.beta1, cfg.betaT, cfg.diffusion_steps)
+        lo, terms = O.infodiff_loss(syn, cfg, x, idx, eps, sched, prior=None, reparam_noise=reparam)
+        check(tag + ' loss', lo, loss.detach(), 1e-5)
+        named = dict(model.named_parameters())
+        res.update({tag + '.x': x, tag + '.idx': idx, tag + '.eps': eps, tag + '.reparam': reparam,
+                    tag + '.loss': loss.detach(), tag + '.out': terms['out'],
+                    tag + '.g.encoder.fc_a.weight': named['encoder.fc_a.weight'].grad,
+                    tag + '.g.backbone.fc_a.weight': named['backbone.fc_a.weight'].grad})
+        res[tag + '.has_mu_grad'] = torch.tensor(named['encoder.fc_mu.weight'].grad is not None)
+    save('loss_branches', **res)
+
+
 # ------------------------------------------------------------ stub samplers
 def gen_sampler_stub():
     out = {}
@@ -537,7 +574,7 @@ def gen_vanilla_twophase():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'celeba']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'celeba']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -560,6 +597,8 @@ if __name__ == '__main__':
         gen_vae('fmnist_vae_kld', O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.0, kld_weight=0.01), B=2, seed=68)
     if 'priors' in which:
         gen_priors_and_capacity()
+    if 'branches' in which:
+        gen_branches()
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     print('ALL ORACLE-vs-REFERENCE CHECKS PASSED')

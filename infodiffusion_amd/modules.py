@@ -199,11 +199,20 @@ class TimeEmbedding(nn.Module):
         return ops.linear(e, l2.weight, l2.bias, silu_in=True)
 
 
+_freq_cache = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000):
-    """modules.py:41-60 ([cos..., sin...]); host-side torch, used by LatentUNet only."""
+    """modules.py:41-60 ([cos..., sin...]), used by LatentUNet only.  The frequency table is evaluated with the
+    reference's CPU expression once per (device, dim) and kept on the device: no H2D copy per call, so a denoise
+    step can be captured into a graph."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) /
-                      half).to(device=timesteps.device)
+    key = (timesteps.device, half, max_period)
+    freqs = _freq_cache.get(key)
+    if freqs is None:
+        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) /
+                          half).to(device=timesteps.device)
+        _freq_cache[key] = freqs
     ang = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
     if dim % 2:

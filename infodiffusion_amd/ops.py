@@ -307,8 +307,8 @@ def _pad_channels(t, mult=8):
     Cp = -(-C // mult) * mult
     if Cp == C:
         return t
-    out = torch.zeros((t.shape[0], Cp, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device).contiguous(
-        memory_format=CL)
+    out = torch.empty((t.shape[0], Cp, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=CL)
+    out.zero_()
     out[:, :C] = t
     return out
 

@@ -106,34 +106,34 @@ class ProgressMeter:
 
 
 class GradualWarmupScheduler(_LRScheduler):
-    """utils.py:133-160: linear warm-up to multiplier*lr over `warm_epoch` epochs,
-    then hand over to `after_scheduler` (stepped per epoch, run.py:209)."""
+    """utils.py:133-160: the rate climbs linearly from lr to multiplier*lr over `warm_epoch` epochs, then
+    `after_scheduler` takes over with multiplier*lr as its base (stepped per epoch, run.py:209).  Same attribute
+    names and the same float expressions as the reference, so the rate sequence is bit-identical
+    (tests/test_cli_host.py pins it, the overshoot at the hand-over epoch included)."""
 
     def __init__(self, optimizer, multiplier, warm_epoch, after_scheduler=None):
-        self.multiplier = multiplier
-        self.total_epoch = warm_epoch
-        self.after_scheduler = after_scheduler
-        self.finished = False
-        self.last_epoch = None
-        self.base_lrs = None
+        self.multiplier, self.total_epoch = multiplier, warm_epoch
+        self.after_scheduler, self.finished = after_scheduler, False
+        self.last_epoch = self.base_lrs = None          # filled in by the base class
         super().__init__(optimizer)
 
+    def _scaled(self, factor):
+        return [lr * factor for lr in self.base_lrs]
+
     def get_lr(self):
-        if self.last_epoch > self.total_epoch:
-            if self.after_scheduler:
-                if not self.finished:
-                    self.after_scheduler.base_lrs = [lr * self.multiplier for lr in self.base_lrs]
-                    self.finished = True
-                return self.after_scheduler.get_lr()
-            return [lr * self.multiplier for lr in self.base_lrs]
-        k = (self.multiplier - 1.) * self.last_epoch / self.total_epoch + 1.
-        return [lr * k for lr in self.base_lrs]
+        if self.last_epoch <= self.total_epoch:          # still warming up
+            return self._scaled((self.multiplier - 1.) * self.last_epoch / self.total_epoch + 1.)
+        if not self.after_scheduler:
+            return self._scaled(self.multiplier)
+        if not self.finished:                            # hand-over: the follower starts from the warmed-up rate
+            self.after_scheduler.base_lrs = self._scaled(self.multiplier)
+            self.finished = True
+        return self.after_scheduler.get_lr()
 
     def step(self, epoch=None, metrics=None):
-        if self.finished and self.after_scheduler:
-            self.after_scheduler.step(None if epoch is None else epoch - self.total_epoch)
-        else:
-            return super(GradualWarmupScheduler, self).step(epoch)
+        if not (self.finished and self.after_scheduler):
+            return super().step(epoch)
+        self.after_scheduler.step(epoch if epoch is None else epoch - self.total_epoch)
 
 
 class LatentDataset(Dataset):

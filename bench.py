@@ -359,6 +359,10 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    # integrity of the timed region: the last step's global gradient norm (device scalar of the fused optimizer)
+    gnorm = float(opt.total_norm()) if a.fused_opt else None
+    if gnorm is not None and not (gnorm == gnorm and gnorm < 1e6):
+        raise RuntimeError('bench: non-finite gradient norm %r in the timed training step' % gnorm)
     imgs = a.batch * world * a.steps
     out = {
         'metric': 'training images/sec, CelebA 64x64 (InfoDiff loss_fn fwd+bwd+clip+AdamW)',
@@ -369,7 +373,8 @@ def main():
                                'train step, random-pixel batches, random-init weights' % a.a_dim,
                    'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                    'parallelism': 'dp%d' % world, 'hipgraph': used_graph,
-                   'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW'},
+                   'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW',
+                   'last_grad_norm': None if gnorm is None else round(gnorm, 4)},
     }
 
     if rank == 0 and not a.no_roofline:

@@ -129,3 +129,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int idf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Zero n floats with a KERNEL.  Not hipMemsetAsync: a memset node recorded while the caller captures the stream
+// into a hipGraph did not clear the buffer reliably on replay (ROCm 7.2, gfx950 -- the weight-gradient buffers
+// of the image / epsilon convs kept garbage, the gradient norm overflowed and a replayed training step stopped
+// learning), while kernel nodes replay exactly as recorded.
+static __global__ void idf_zero_f32_kernel(float* __restrict__ p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = 0.f;
+}
+static inline hipError_t idf_zero_f32(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(idf_zero_f32_kernel, dim3(blocks), dim3(256), 0, st, p, n);
+  return hipGetLastError();
+}

@@ -492,7 +492,7 @@ extern "C" int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const 
   p.B = B; p.Hs = Hs; p.Ws = Ws; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.mode = mode; p.taps = taps; p.act = act; p.M = B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * taps * Cin * sizeof(float), st);
+  hipError_t e = idf_zero_f32(dW, (size_t)Cout * taps * Cin, st);     // a kernel, not a memset node (idf_common.h)
   if (e != hipSuccess) IDF_FAIL((int)e, "wgrad: memset failed: %s", hipGetErrorString(e));
   if (p.M == 0) return IDF_OK;
   if (dtype == IDF_F32) return launch_wgrad<float, 3>(p, dW, st);

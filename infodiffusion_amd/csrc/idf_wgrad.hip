@@ -319,12 +319,12 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
   const size_t nW = (size_t)Cout * taps * Cin;
   hipError_t e = hipSuccess;
   if (accumulate) {}                     // dW / db already hold zeros or a running sum (gradient arena)
-  else if (db == dW + nW) e = hipMemsetAsync(dW, 0, (nW + Cout) * sizeof(float), st);   // caller packed dW | db
+  else if (db == dW + nW) e = idf_zero_f32(dW, nW + Cout, st);   // caller packed dW | db: one launch
   else {
-    e = hipMemsetAsync(dW, 0, nW * sizeof(float), st);
-    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
+    e = idf_zero_f32(dW, nW, st);
+    if (e == hipSuccess && db) e = idf_zero_f32(db, (size_t)Cout, st);
   }
-  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: memset failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: zero fill failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
   dim3 g(gx, gy);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<1, 0>), g, dim3(256), lds, st, p);

@@ -736,3 +736,39 @@ def test_loss_branches_vs_reference(tag, kw):
     for k in ('encoder.fc_a.weight', 'backbone.fc_a.weight'):
         assert rel(named[k].grad, g['%s.g.%s' % (tag, k)]) < 2e-3, k
     assert (named['encoder.fc_mu.weight'].grad is not None) == bool(g[tag + '.has_mu_grad'])
+
+
+def test_graph_replayed_training_keeps_learning_on_fresh_input_tensors():
+    """Regression: the replayed step must keep every gradient finite and track the eager loop when each batch
+    arrives in a NEW device tensor (as a data loader delivers it).  A hipMemsetAsync recorded inside the capture
+    (zeroing the padded weight-gradient buffers of the Cout = 1 / 3 tail convs) once left those buffers uncleared
+    on replay whenever the GPU had gone idle between replays: the global gradient norm overflowed, the clip factor
+    became 0 and training silently stopped (the library now zero-fills with a kernel; this test fails on the old one)."""
+    import time
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    curves = {}
+    for graph in (True, False):
+        torch.manual_seed(5)
+        model, args, sd = make_infodiff(cfg, DEV, 'bf16')
+        model.train()
+        opt = FusedClipAdamW(model.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
+        step = GraphedTrainStep(model, args, opt, use_graph=graph)
+        g = torch.Generator(device='cpu')
+        g.manual_seed(9)
+        losses, norms = [], []
+        for i in range(60):
+            x = (torch.rand(16, *cfg.shape, generator=g) * 2 - 1).to(DEV)       # a fresh device tensor every step
+            torch.cuda.synchronize()
+            time.sleep(0.01)                 # the GPU idles between replays, as behind a slow input pipeline
+            losses.append(step(x, 0).clone())
+            norms.append(opt.total_norm().clone())
+        assert (step.graph is not None) == graph
+        norms = torch.stack(norms).cpu()
+        assert torch.isfinite(norms).all() and float(norms.max()) < 1e3, norms
+        curves[graph] = torch.stack(losses).float().cpu()
+    head = lambda c: float(c[:10].mean())
+    tail = lambda c: float(c[-10:].mean())
+    assert tail(curves[True]) < 0.8 * head(curves[True]), curves[True]
+    assert abs(tail(curves[True]) - tail(curves[False])) < 0.15 * tail(curves[False])

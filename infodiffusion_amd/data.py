@@ -44,8 +44,14 @@ class _Batches:
     def __iter__(self):
         g = torch.Generator(device='cpu')
         g.manual_seed(self.seed + self.rank)
+        on_gpu = torch.device(self.device).type == 'cuda'
+        if on_gpu and self.array is None:
+            gd = torch.Generator(device=self.device)          # random pixels are drawn where they are consumed:
+            gd.manual_seed(self.seed + self.rank)             # a host draw + H2D copy costs more than a training step
         for i in range(self.n):
-            if self.array is None:
+            if self.array is None and on_gpu:
+                x = torch.rand(self.bs, *self.shape, generator=gd, device=self.device) * 2 - 1
+            elif self.array is None:
                 x = torch.rand(self.bs, *self.shape, generator=g) * 2 - 1
             else:
                 lo = (i * self.world + self.rank) * self.bs

@@ -22,12 +22,23 @@ g = torch.Generator(device='cpu')
 g.manual_seed(64)
 pool = [(torch.rand(32, 3, 64, 64, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
         for _ in range(8)]
+sync_mode = os.environ.get('IDF_FORCE_SYNC') == '1'      # 1-rank RCCL group: the whole data-parallel code path on one GPU
+if sync_mode:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 for dt in ('bf16', 'fp32'):
     args = args_of(cfg, act_dtype=dt, batch_size=32)
     torch.manual_seed(64)
     model = InfoDiff(args, dev, cfg.shape).train()
     opt = FusedClipAdamW(model.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
-    step = GraphedTrainStep(model, args, opt)
+    sync = None
+    if sync_mode:
+        from infodiffusion_amd.dist import GradSync
+        sync = GradSync(model, 1, force=True, arena=opt.arena)
+        sync.broadcast_parameters()
+    step = GraphedTrainStep(model, args, opt, sync)
     hist = []
     acc = torch.zeros((), device=dev)
     for i in range(steps):
@@ -35,5 +46,5 @@ for dt in ('bf16', 'fp32'):
         if (i + 1) % 50 == 0:
             hist.append(float(acc) / 50)
             acc.zero_()
-    print(dt, 'mean loss per 50 steps:', ' '.join('%.4f' % v for v in hist))
+    print(dt + (' +sync' if sync_mode else ''), 'mean loss per 50 steps:', ' '.join('%.4f' % v for v in hist))
     assert all(v == v for v in hist) and hist[-1] < 0.5 * hist[0], hist

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Checkpoint interchange with the REAL reference, both halves of the round trip:
+
+  make  (GPU box):        train the product for a few steps, save `model.state_dict()` the way run.py does, plus a
+                          probe (x_t, t, a) and the product's eps-hat / encoder outputs for it (fp32 activations).
+  check (build container): load that file into the reference's own InfoDiff (strict=True, CPU) and compare the
+                          reference's outputs on the probe with the product's.
+
+    gpurun -- python tools/ckpt_interchange.py make gpurun_out/ckpt_probe.pt
+    PYTHONDONTWRITEBYTECODE=1 python tools/ckpt_interchange.py check gpurun_out/ckpt_probe.pt
+"""
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CFG = dict(beta1=1e-5, betaT=1e-2, diffusion_steps=1000, input_size=32, input_channels=1, is_bottleneck=False,
+           unets_channels=32, encoder_channels=32, a_dim=32, mmd_weight=0.1, kld_weight=0.0, prior='regular',
+           batch_size=16, use_C=False, C_max=25.0, epochs=2, deterministic=True, model='diff', split_step=500,
+           mode='train', is_latent=False, dataset='fmnist')
+SHAPE = (1, 32, 32)
+
+
+def make(path):
+    from infodiffusion_amd.models import InfoDiff
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    dev = torch.device('cuda')
+    args = types.SimpleNamespace(act_dtype='fp32', **CFG)
+    torch.manual_seed(12)
+    model = InfoDiff(args, dev, SHAPE).train()
+    opt = FusedClipAdamW(model.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
+    step = GraphedTrainStep(model, args, opt)
+    g = torch.Generator(device=dev)
+    g.manual_seed(13)
+    losses = [float(step(torch.rand(16, *SHAPE, generator=g, device=dev) * 2 - 1, 0)) for _ in range(40)]
+    model.eval()
+    cg = torch.Generator(device='cpu')
+    cg.manual_seed(14)
+    x, a = torch.randn(4, *SHAPE, generator=cg), torch.randn(4, 32, generator=cg)
+    x0 = torch.rand(4, *SHAPE, generator=cg) * 2 - 1
+    with torch.no_grad():
+        eps = model(x.to(dev), 321, a.to(dev)).float().cpu()
+        enc_a = model.encoder(x0.to(dev))[0].float().cpu()
+    torch.save({'state_dict': {k: v.cpu() for k, v in model.state_dict().items()}, 'x': x, 'a': a, 'x0': x0, 't': 321,
+                'eps': eps, 'enc_a': enc_a, 'losses': losses}, path)
+    print('trained 40 steps (loss %.4f -> %.4f); wrote %s (%.1f MB)' % (losses[0], losses[-1], path,
+                                                                      os.path.getsize(path) / 1e6))
+
+
+def check(path):
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, '/root/reference')
+    import models as R_models      # the reference itself
+    blob = torch.load(path, map_location='cpu')
+    ref = R_models.InfoDiff(types.SimpleNamespace(**CFG), 'cpu', SHAPE)
+    ref.load_state_dict(blob['state_dict'], strict=True)          # every key, every shape
+    ref.eval()
+    with torch.no_grad():
+        eps = ref(blob['x'], blob['t'], blob['a'])
+        enc_a = ref.encoder(blob['x0'])[0]
+    rel = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-30))
+    e1, e2 = rel(blob['eps'], eps), rel(blob['enc_a'], enc_a)
+    print('reference loaded the product checkpoint strictly (%d entries)' % len(blob['state_dict']))
+    print('eps-hat(t=321): max rel err product-GPU vs reference-CPU %.2e   encoder a: %.2e' % (e1, e2))
+    assert e1 < 1e-4 and e2 < 1e-4
+    return e1, e2
+
+
+if __name__ == '__main__':
+    {'make': make, 'check': check}[sys.argv[1]](sys.argv[2])

@@ -45,8 +45,24 @@ def make(path):
     with torch.no_grad():
         eps = model(x.to(dev), 321, a.to(dev)).float().cpu()
         enc_a = model.encoder(x0.to(dev))[0].float().cpu()
+    # a 60-step DDIM and DDPM trajectory of the product with the noise draws recorded, for replay in the reference
+    from infodiffusion_amd.sampling import DiffusionProcess
+    traj = {}
+    for det in (True, False):
+        sargs = types.SimpleNamespace(act_dtype='fp32', **{**CFG, 'diffusion_steps': 60, 'deterministic': det})
+        proc = DiffusionProcess(sargs, model, dev, SHAPE)
+        noises = []
+
+        def rec(t, noises=noises):
+            z = torch.randn_like(t)
+            noises.append(z.float().cpu())
+            return z
+        proc._randn_like = rec
+        xT = torch.randn(2, *SHAPE, generator=cg)
+        out = proc.sampling(xT=xT.to(dev), a=a[:2].to(dev)).float().cpu()
+        traj[det] = dict(xT=xT, noises=noises, out=out)
     torch.save({'state_dict': {k: v.cpu() for k, v in model.state_dict().items()}, 'x': x, 'a': a, 'x0': x0, 't': 321,
-                'eps': eps, 'enc_a': enc_a, 'losses': losses}, path)
+                'eps': eps, 'enc_a': enc_a, 'losses': losses, 'traj': traj}, path)
     print('trained 40 steps (loss %.4f -> %.4f); wrote %s (%.1f MB)' % (losses[0], losses[-1], path,
                                                                       os.path.getsize(path) / 1e6))
 
@@ -67,6 +83,22 @@ def check(path):
     print('reference loaded the product checkpoint strictly (%d entries)' % len(blob['state_dict']))
     print('eps-hat(t=321): max rel err product-GPU vs reference-CPU %.2e   encoder a: %.2e' % (e1, e2))
     assert e1 < 1e-4 and e2 < 1e-4
+    import sampling as R_sampling
+    for det, name in ((True, 'DDIM'), (False, 'DDPM')):
+        tr = blob['traj'][det]
+        sargs = types.SimpleNamespace(**{**CFG, 'diffusion_steps': 60, 'deterministic': det})
+        proc = R_sampling.DiffusionProcess(sargs, ref, 'cpu', SHAPE)
+        feed = iter(tr['noises'])
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **k: next(feed)
+        try:
+            with torch.no_grad():
+                out = proc.sampling(xT=tr['xT'], a=blob['a'][:2])
+        finally:
+            torch.randn_like = orig
+        e = rel(tr['out'], out)
+        print('%s, 60 steps, same noise draws: final sample max rel err product-GPU vs reference-CPU %.2e' % (name, e))
+        assert e < 1e-4
     return e1, e2
 
 

@@ -61,8 +61,34 @@ def make(path):
         xT = torch.randn(2, *SHAPE, generator=cg)
         out = proc.sampling(xT=xT.to(dev), a=a[:2].to(dev)).float().cpu()
         traj[det] = dict(xT=xT, noises=noises, out=out)
-    torch.save({'state_dict': {k: v.cpu() for k, v in model.state_dict().items()}, 'x': x, 'a': a, 'x0': x0, 't': 321,
-                'eps': eps, 'enc_a': enc_a, 'losses': losses, 'traj': traj}, path)
+    # five optimisation steps (dropout off, eager) with every random draw recorded, for replay in the reference
+    start = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt2 = FusedClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    draws, opt_losses, opt_norms = [], [], []
+    orig_rl, orig_ri = torch.randn_like, torch.randint
+    for k in range(5):
+        xb = torch.rand(8, *SHAPE, generator=cg) * 2 - 1
+        step_draws = dict(x=xb, idx=torch.randint(0, 1000, (8,), generator=cg), eps=torch.randn(8, *SHAPE, generator=cg),
+                          reparam=torch.randn(8, 32, generator=cg), prior=torch.randn(8, 32, generator=cg))
+        feed = iter([step_draws['eps'], step_draws['reparam'], step_draws['prior']])
+        torch.randn_like = lambda t, **kw: next(feed).to(t.device)
+        torch.randint = lambda *a_, **kw: step_draws['idx'].clone()
+        try:
+            loss = model.loss_fn(args, xb.to(dev))
+        finally:
+            torch.randn_like, torch.randint = orig_rl, orig_ri
+        opt2.zero_grad()
+        loss.backward()
+        opt2.step()
+        draws.append(step_draws)
+        opt_losses.append(float(loss))
+        opt_norms.append(float(opt2.total_norm()))
+    end = {k: model.state_dict()[k].detach().cpu().clone() for k in
+           ('backbone.head.weight', 'backbone.downblocks.0.block1.2.weight', 'backbone.middleblocks.0.attn.proj_q.weight',
+            'backbone.fc_a.weight', 'backbone.tail.2.weight', 'encoder.fc_a.weight', 'encoder.upblocks.3.main.weight')}
+    torch.save({'state_dict': {k: v.cpu() for k, v in start.items()}, 'x': x, 'a': a, 'x0': x0, 't': 321,
+                'eps': eps, 'enc_a': enc_a, 'losses': losses, 'traj': traj,
+                'opt': dict(draws=draws, losses=opt_losses, norms=opt_norms, end=end)}, path)
     print('trained 40 steps (loss %.4f -> %.4f); wrote %s (%.1f MB)' % (losses[0], losses[-1], path,
                                                                       os.path.getsize(path) / 1e6))
 
@@ -99,6 +125,35 @@ def check(path):
         e = rel(tr['out'], out)
         print('%s, 60 steps, same noise draws: final sample max rel err product-GPU vs reference-CPU %.2e' % (name, e))
         assert e < 1e-4
+    # five optimisation steps in the reference (run.py:195-200: loss_fn, zero_grad, backward, clip 1.0, AdamW) on the
+    # recorded draws; dropout off on both sides
+    import contextlib
+    import io
+    o = blob['opt']
+    args = types.SimpleNamespace(**CFG)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+    orig_rl, orig_ri = torch.randn_like, torch.randint
+    for k, d in enumerate(o['draws']):
+        feed = iter([d['eps'], d['reparam'], d['prior']])
+        torch.randn_like = lambda t, **kw: next(feed)
+        torch.randint = lambda *a_, **kw: d['idx'].clone()
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss = ref.loss_fn(args=args, x=d['x'])
+        finally:
+            torch.randn_like, torch.randint = orig_rl, orig_ri
+        ropt.zero_grad()
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        ropt.step()
+        print('step %d  loss reference %.6f product %.6f   grad norm reference %.5f product %.5f' %
+              (k, float(loss), o['losses'][k], float(norm), o['norms'][k]))
+        assert abs(float(loss) - o['losses'][k]) < 1e-4 * abs(float(loss)) + 1e-6
+        assert abs(float(norm) - o['norms'][k]) < 2e-3 * float(norm)
+    sd = ref.state_dict()
+    worst = max(rel(o['end'][k], sd[k]) for k in o['end'])
+    print('weights after 5 steps (7 tensors): max rel err product-GPU vs reference-CPU %.2e' % worst)
+    assert worst < 2e-3
     return e1, e2
 
 

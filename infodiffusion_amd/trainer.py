@@ -62,6 +62,9 @@ class GraphedTrainStep:
                 and (self.xbuf is None or x.shape == self.xbuf.shape)):
             try:
                 self._capture(x, epoch)
+                # the capture's warm-up pass WAS this batch's optimisation step (capturing itself executes nothing):
+                # replaying now would train on the batch a second time
+                return self.loss
             except Exception as e:  # noqa: BLE001
                 print('graph capture failed (%s: %s); training eagerly' % (type(e).__name__, str(e)[:200]),
                       file=sys.stderr)

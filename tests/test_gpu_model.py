@@ -772,3 +772,34 @@ def test_graph_replayed_training_keeps_learning_on_fresh_input_tensors():
     tail = lambda c: float(c[-10:].mean())
     assert tail(curves[True]) < 0.8 * head(curves[True]), curves[True]
     assert abs(tail(curves[True]) - tail(curves[False])) < 0.15 * tail(curves[False])
+
+
+def test_graph_replay_equals_eager_steps_on_a_deterministic_objective():
+    """A step replayed from the hipGraph IS the eager step: on an objective with no random draws (VAE, both auxiliary
+    weights 0, dropout off) two copies of the model -- one stepped eagerly, one through capture + replay, the GPU going
+    idle between steps -- keep the same loss and the same gradient norm step after step.  (Also pins that the batch
+    present at capture time is trained on once, not twice.)"""
+    import time
+    from infodiffusion_amd.models import VAE
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.0)
+    args = args_of(cfg, act_dtype='fp32', batch_size=8)
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = VAE(args, DEV, cfg.shape).eval()
+        opt = FusedClipAdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, max_norm=1.0)
+        runs.append((GraphedTrainStep(model, args, opt, use_graph=graph), opt))
+    g = torch.Generator(device='cpu')
+    g.manual_seed(1)
+    for i in range(10):
+        x = (torch.rand(8, 1, 1, 1, generator=g) * 1.6 - 0.8).expand(8, 1, 32, 32).contiguous().to(DEV)
+        torch.cuda.synchronize()
+        time.sleep(0.005)
+        (se, oe), (sg, og) = runs
+        le, lg = float(se(x, 0)), float(sg(x, 0))
+        ne, ng = float(oe.total_norm()), float(og.total_norm())
+        assert abs(le - lg) <= 2e-5 * abs(le), (i, le, lg)
+        assert abs(ne - ng) <= 2e-3 * abs(ne), (i, ne, ng)
+    assert runs[1][0].graph is not None and runs[0][0].graph is None

@@ -104,3 +104,30 @@ def test_cli_latent_editing_modes(tmp_path):
     assert len(files) == 32                                   # one traversal per latent coordinate
     img = np.load(files[5])
     assert img.shape == (11, 1, 32, 32) and np.isfinite(img).all()
+
+
+def test_cli_two_phase_eval_fid(tmp_path):
+    """Config-5 image flow without a latent model (reference run.py:236-250, 284-309, eval_fid.sh): a vanilla model
+    trained with --model vanilla --mmd_weight 0 lands in ./models/diff/<dataset>_<a_dim>d/, which is exactly where
+    eval_fid looks for the second phase's network; TwoPhaseDiffusionProcess then samples (every step with model 2,
+    as the reference executes it)."""
+    tmp = str(tmp_path)
+    common = ['--prior', 'regular', '--dataset', 'fmnist', '--a_dim', '32', '--epochs', '2', '--save_epochs', '2',
+              '--batch_size', '8', '--steps_per_epoch', '3', '--diffusion_steps', '40', '--act_dtype', 'bf16',
+              '--model_folder', './models', '--img_folder', './imgs', '--data_dir', './data']
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'run.py')] + common + list(extra), cwd=tmp,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return r.stdout
+
+    run('--model', 'vanilla', '--mode', 'train', '--mmd_weight', '0')
+    assert os.path.exists(os.path.join(tmp, 'models', 'diff', 'fmnist_32d', 'model-2.pth'))
+    run('--model', 'diff', '--mode', 'train')
+    out = run('--model', 'diff', '--mode', 'eval_fid', '--deterministic', '--sampling_number', '12')
+    assert 'DONE' in out
+    files = sorted(glob.glob(os.path.join(tmp, 'imgs', '*', 'eval-fid-fast', 'sample-*.npy')))
+    assert len(files) == 2
+    img = np.load(files[0])
+    assert img.shape == (8, 1, 32, 32) and np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0

@@ -10,7 +10,7 @@ def test_cli_flags_match_reference_defaults():
                         '--a_dim', '32', '--save_epoch', '7'])       # prefix matching as eval_fid.sh:9 relies on
     assert (a.mmd_weight, a.kld_weight, a.beta1, a.betaT, a.diffusion_steps) == (0.1, 0, 1e-5, 1e-2, 1000)
     assert a.save_epochs == 7 and a.batch_size == 64 and a.learning_rate == 1e-4 and a.split_step == 500
-    assert not a.deterministic and not a.is_latent and a.act_dtype == 'fp32'
+    assert not a.deterministic and not a.is_latent and a.act_dtype == 'bf16'      # our extra flag: fast path by default
 
 
 def test_dataset_config_and_exp_string():

@@ -103,3 +103,20 @@ def test_checkpoint_interchange_with_reference():
     assert all(torch.equal(ours.state_dict()[k], ref.state_dict()[k]) for k in so)
     # conv masters keep their channels-last memory after loading
     assert ours.backbone.downblocks[0].block1[2].weight.stride()[1] == 1
+
+
+def test_library_sources_issue_kernel_launches_only():
+    """Boundary rule: no allocation, synchronisation, memset or memcpy API call inside the library --
+    a hipMemsetAsync recorded into a training hipGraph once left a gradient buffer uncleared on replay."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'infodiffusion_amd', 'csrc')
+    banned = re.compile(r'\b(hipMemset\w*|hipMemcpy\w*|hipMalloc\w*|hipFree\w*|hipDeviceSynchronize|hipStreamSynchronize)\s*\(')
+    hits = []
+    for path in sorted(glob.glob(os.path.join(root, '*'))):
+        for n, line in enumerate(open(path, errors='replace'), 1):
+            code = line.split('//')[0]
+            if banned.search(code):
+                hits.append('%s:%d %s' % (os.path.basename(path), n, line.strip()))
+    assert not hits, hits

@@ -161,7 +161,7 @@ class ConvTimer:
         self.orig = ops.conv_raw
         timer = self
 
-        def recorded(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
+        def recorded(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None, **kw):
             B, Cin, Hs, Ws = x.shape
             Ho, Wo = out_hw_ if out_hw_ is not None else ops.out_hw(mode, Hs, Ws)
             if ops.uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
@@ -171,7 +171,7 @@ class ConvTimer:
                 else:
                     timer.calls[key] = [1, (x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout,
                                             out_hw_)]
-            return timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_)
+            return timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_, **kw)
         ops.conv_raw = recorded
 
     def remove(self):

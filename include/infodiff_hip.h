@@ -54,19 +54,46 @@ int idf_conv2d_fwd(const void* x, const void* w, const float* bias, const void* 
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int mode, int taps, int act,
                    int dtype, void* stream);
 
-/* bf16 halo-tile form of the 3x3 conv (mode S1 / UP2 / T2, no prologue; H, W = output dims): one
+/* bf16 halo-tile form of the 3x3 conv (mode S1 / S2 / UP2 / T2, no prologue; H, W = output dims): one
  * input read per 32-channel chunk instead of one per tap.  IDF_ERR_UNSUPPORTED for shapes it does
- * not cover (Cin % 32, W not a power of two in 4..128): use idf_conv2d_fwd then. */
+ * not cover (Cin % 32, W not a power of two in 4..128): use idf_conv2d_fwd then.
+ * st_out (optional, Cout % 8 == 0): per-channel GroupNorm statistics partials of the bf16 output y,
+ * [B][T][Cout][2] fp32 = (sum, sum of squares) over each of the T = idf_conv_tiles(...) pixel tiles of an
+ * image -- written by the epilogue (plain stores, fixed order), so the nn.GroupNorm that reads y
+ * (modules.py:214-228, 264-288) needs no statistics pass of its own; consumed by idf_conv_gn_bf16. */
 int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B, int H,
-                     int W, int Cin, int Cout, int mode, void* stream);
+                     int W, int Cin, int Cout, int mode, float* st_out, void* stream);
 /* 1x1 stride-1 convolution (AttnBlock q/k/v and proj, modules.py:136-139; ResBlock shortcuts, modules.py:228,
  * and their data gradients) through the same pipeline without the halo: w [Cout][Cin] bf16, optional
  * fp32 bias and bf16 residual.  IDF_ERR_UNSUPPORTED outside Cin % 32 == 0, Cout % 8 == 0, W a power
  * of two in 4..128 (use idf_bgemm then).  x2 != NULL: the input is the never-materialised channel
  * concatenation x [.., C1] | x2 [.., Cin - C1] of a skip connection (models.py:321 torch.cat), C1 % 32 == 0;
- * the GroupNorm one-launch kernels and the weight-gradient table take the same (x2, C1) pair. */
+ * the GroupNorm one-launch kernels and the weight-gradient table take the same (x2, C1) pair.  st_out: as above. */
 int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* res, void* y,
-                     int B, int H, int W, int Cin, int Cout, void* stream);
+                     int B, int H, int W, int Cin, int Cout, float* st_out, void* stream);
+/* Pixel tiles per image (= T of st_out) of the launch idf_conv3x3_bf16 / idf_conv1x1_bf16 / idf_conv_gn_bf16 make
+ * for this shape (H, W = output dims; taps 9 or 1); -1 when the shape is not covered. */
+int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps);
+
+/* The conv / GroupNorm-SiLU / AdaGN fused block (modules.py:264-288 block1..3, 309-320 AuxResBlock.forward,
+ * 145-150 AttnBlock GroupNorm + q/k/v, models.py:280-284 tail):
+ *   y = conv( dropout( act( GroupNorm32(x) [*(1+s_t)+b_t] [*(1+s_a)+b_a] ) ) ) + bias (+ res)
+ * as ONE launch: stride-1 3x3 (taps 9) or 1x1 (taps 1) over x [B,H,W,Cin] bf16 -- or over the never-materialised
+ * concatenation x [..,C1] | x2 [..,Cin-C1] (models.py:321).  No statistics pass: st1 [B][T1][C1][2]
+ * (st2 [B][T2][Cin-C1][2]) are the partials the producers of x (x2) left behind (st_out above, or
+ * idf_gn_partials); every block folds them with gamma / beta [Cin] and the FiLM pairs film_t / film_a
+ * ([B,2Cin] with row strides ld_t / ld_a, layout and fold as idf_gn_coef_fwd; NULL = absent) into the
+ * per-(image, channel) affine u = x*sc+sh and applies  act 1: u;  act 2: SiLU(u), then dropout(p_drop) when
+ * seed != NULL (keyed by (*seed, salt, element index), as idf_conv2d_fwd)  once per staged element.
+ * Optional outputs (training; NULL otherwise): a_out [B,H,W,Cin] bf16 = the activated tensor (input of the
+ * weight gradient), mean / rstd [B,32] and sc / sh [B,Cin] (all four or none; inputs of idf_gn_fused_bwd /
+ * idf_gn_coef_bwd), st_out as above.  IDF_ERR_UNSUPPORTED for shapes outside idf_conv3x3_bf16 / idf_conv1x1_bf16. */
+int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                     const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                     int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
+                     const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                     float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin, int Cout,
+                     int taps, void* stream);
 
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */
@@ -118,6 +145,11 @@ int idf_gn_workspace_floats(int B, int HW, int C);
 int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,
                     const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd, float* sc, float* sh,
                     float* workspace, int B, int HW, int C, int dtype, void* stream);
+/* Per-channel statistics partials of a tensor x [B,HW,C]: part [B][T][C][2] (sum, sum of squares over T pixel
+ * chunks), T = idf_gn_partials_chunks(B, HW) -- the st_out of the conv entry points, for tensors that were not
+ * produced by one of them (network inputs, fallback paths). */
+int idf_gn_partials_chunks(int B, int HW);
+int idf_gn_partials(const void* x, float* part, int B, int HW, int C, int dtype, void* stream);
 /* a = act(x*sc+sh) materialised once (act 1 affine, 2 SiLU + dropout): GroupNorm-apply + FiLM +
  * SiLU + Dropout of modules.py:264-288, 312-319 as one read + one write */
 int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,

@@ -31,6 +31,23 @@ struct C3P {
   int B, H, W, Hs, Ws, Cin, Cout;
   int R, tiles_per_img, n_tiles, wshift;
   unsigned wh_magic;    // (pix * wh_magic) >> 16 == pix / (W + 2*halo) for every halo pixel index (checked on the host)
+  // ---- statistics epilogue: per-(image, pixel tile, cout) partial (sum y, sum y^2) of the bf16-rounded output,
+  // st_out [B][tiles_per_img][Cout][2].  Each block owns its entries: plain stores, no zeroing, fixed order.
+  float* st_out;
+  int aux_off;          // LDS byte offset of the auxiliary region (coefficients / statistics scratch)
+  // ---- GroupNorm prologue (PRO): the conv input is act(x * sc[b,c] + sh[b,c]) with sc / sh folded in-block from
+  // the producers' statistics partials st1 [B][T1][C1][2] (st2 [B][T2][Cin-C1][2] for the second source)
+  const float* st1; const float* st2;
+  int T1, T2;
+  const float* gamma; const float* beta; const float* film_t; const float* film_a;
+  int ld_t, ld_a;
+  float eps;
+  int act;              // 1: affine only (AttnBlock GroupNorm), 2: SiLU (+ dropout when seed != null)
+  const uint64_t* seed;
+  uint32_t salt, thr;
+  float dscale;
+  bf16_t* a_out;        // training: the activated tensor [B, H, W, Cin] (dense), kept for the weight gradient
+  float* mean_out; float* rstd_out; float* sc_out; float* sh_out;   // training: saved for the GroupNorm backward
 };
 
 constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 = 1536;   // (R+2)*(W+2)*4 budget per block size
@@ -38,13 +55,159 @@ constexpr int CK = 32;
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
 
+// In-block fold of the GroupNorm statistics + gamma / beta + FiLM pairs into cof[c] = (sc, sh) (the fold of
+// idf_groupnorm.hip's gn_finalize, from per-channel partial sums).  One image per block; the partials are summed
+// in a fixed order, so the result does not depend on which block computes it.
+template <int NT>
+__device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool writer, float* cof, float* chs, int tid) {
+  const int C = p.Cin, cpg = C >> 5;
+  for (int c = tid; c < C; c += NT) {
+    const float* st = p.st1;
+    int T = p.T1, Cs = p.C1, cl = c;
+    if (c >= p.C1) { st = p.st2; T = p.T2; Cs = C - p.C1; cl = c - p.C1; }
+    const float2* src = reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    int t = 0;
+    for (; t + 2 <= T; t += 2) {
+      float2 v0 = src[(size_t)t * Cs], v1 = src[(size_t)(t + 1) * Cs];
+      s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
+    }
+    if (t < T) { float2 v = src[(size_t)t * Cs]; s0 += v.x; q0 += v.y; }
+    chs[2 * c] = s0 + s1; chs[2 * c + 1] = q0 + q1;
+  }
+  __syncthreads();
+  const double n = (double)p.H * p.W * cpg;
+  for (int c = tid; c < C; c += NT) {
+    const int g = c / cpg;
+    double a = 0.0, d = 0.0;
+    for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
+    double mu = a / n, var = d / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    float sc = r * ga, sh = be - mf * sc;
+    if (p.film_t) { float f = 1.f + p.film_t[(size_t)b * p.ld_t + c]; sc *= f; sh = sh * f + p.film_t[(size_t)b * p.ld_t + C + c]; }
+    if (p.film_a) { float f = 1.f + p.film_a[(size_t)b * p.ld_a + c]; sc *= f; sh = sh * f + p.film_a[(size_t)b * p.ld_a + C + c]; }
+    cof[2 * c] = sc; cof[2 * c + 1] = sh;
+    if (writer && p.sc_out) {
+      p.sc_out[(size_t)b * C + c] = sc; p.sh_out[(size_t)b * C + c] = sh;
+      if (c == g * cpg) { p.mean_out[b * 32 + g] = mf; p.rstd_out[b * 32 + g] = r; }
+    }
+  }
+  __syncthreads();
+}
+
+// a = act(x * sc + sh) on one 16-byte vector (8 bf16 channels); vec = index of the vector in the dense activated
+// tensor (the dropout key, as idf_groupnorm.hip's gn_apply_kernel / du_vec use it)
+__device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8], const float (&shv)[8], int act, bool drop,
+                                         uint64_t seedv, uint32_t salt, uint32_t thr, float dscale, uint32_t vec) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  const uint32_t h = drop ? idf_vec_hash(seedv, salt, vec) : 0u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float u = v[e] * scv[e] + shv[e];
+    if (act == 2) {
+      u = silu_f(u);
+      if (drop) u = idf_keep_h(h, e, thr) ? u * dscale : 0.f;
+    }
+    v[e] = u;
+  }
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// Epilogue through LDS.  A lane holds couts n..n+3 of one pixel, i.e. 8-byte pieces scattered over 16 pixel rows
+// per store instruction; the fp32 tile goes through LDS (the staging buffers are free now) and is written back as
+// whole 16-byte chunks, consecutive lanes covering one pixel's contiguous couts: full-line HBM writes, coalesced
+// bias / residual reads.  With p.st_out the per-cout (sum, sum of squares) of the block's bf16-rounded outputs are
+// stored too: the GroupNorm that reads y needs no pass of its own over it.
+template <int TM, int TN, int BM, int BN, int NT>
+__device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,
+                                             int n0, int KT, int tid, int wm0, int wn0) {
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int W = p.W, R = p.R;
+  const int ncols = min(BN, p.Cout - n0);          // valid couts of this tile
+  constexpr int PF = BN + 4;                       // fp32 row pitch (floats)
+  float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]; fits: BM*(BN+4)*4 <= (halo + weights) bytes
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      int nl = wn0 + a * 16 + fq * 4;
+      *reinterpret_cast<float4*>(Os + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;                      // 16-byte output chunks per pixel row
+  float ssum[8], ssq[8];                           // statistics of this thread's 8 couts (cc is fixed per thread)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ssum[k] = ssq[k] = 0.f;
+  for (int idx = tid; idx < BM * CPR; idx += NT) {
+    int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
+    if (pl >= KT || cc >= ncols) continue;
+    float o[8];
+    float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc);
+    float4 v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
+    o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+    size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
+    if (p.bias) {
+      float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
+      float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
+      o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+    }
+    if (p.res) {
+      float r[8];
+      Vec16<bf16_t>::load(p.res + e, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += r[k];
+    }
+    if (p.st_out) {                                // statistics of the values a reader of y will see (bf16-rounded)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o[k] = bf16_to_f32(f32_to_bf16(o[k]));
+        ssum[k] += o[k]; ssq[k] += o[k] * o[k];
+      }
+    }
+    Vec16<bf16_t>::store(p.y + e, o);
+  }
+  if (p.st_out) {
+    // lanes CPR apart hold the same couts: fold them, then the waves through LDS (outside the fp32 tile)
+#pragma unroll
+    for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ssum[k] += __shfl_xor(ssum[k], off, 64); ssq[k] += __shfl_xor(ssq[k], off, 64); }
+    float* part = reinterpret_cast<float*>(smem + p.aux_off);     // [waves][BN][2]
+    if (lane < CPR) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        part[(wave * BN + lane * 8 + k) * 2] = ssum[k];
+        part[(wave * BN + lane * 8 + k) * 2 + 1] = ssq[k];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < ncols; c += NT) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + c) * 2]; q += part[(w * BN + c) * 2 + 1]; }
+      reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (oy0 / R)) * p.Cout + n0 + c] = make_float2(a, q);
+    }
+  }
+}
+
 // NWM = waves along the pixel axis (2 -> 256 threads; 4 -> 512 threads: a 256-pixel tile shares one
 // weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
 // KS = 3 (3x3, pad 1) or 1 (1x1: the same pipeline without the halo -- the AttnBlock q/k/v and proj
 // convs, ResBlock shortcuts and their data gradients; MODE 0 only).
 // DUAL: the input is the never-materialised channel concatenation x | x2 (skip connection): a 32-channel
 // chunk is fetched from the tensor it lies in (C1 % 32 == 0).
-template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false>
+// PRO: GroupNorm / FiLM / SiLU / dropout applied to the staged tile (MODE 0 only), coefficients folded in-block.
+template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false>
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
@@ -96,6 +259,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   // (-1 = no slot), computed once so the chunk loop is loads + stores only
   int hoff[HV], woff[WV];      // element offsets (tensors < 2^31 elements: checked on the host)
   int hlds[HV], wlds[WV];
+  unsigned amask = 0;          // PRO: vectors of this block's own pixels (written to a_out by the first cout tile)
 #pragma unroll
   for (int k = 0; k < HV; ++k) {
     int idx = tid + k * NT;
@@ -105,6 +269,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
       int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
       int iy = ST * oy0 + hy - HALO, ix = hx - HALO;
       bool ok = (unsigned)iy < (unsigned)(ST * p.H) && (unsigned)ix < (unsigned)(ST * W);
+      if (PRO && ok && p.a_out && n0 == 0 && (unsigned)(hy - HALO) < (unsigned)R && (unsigned)(hx - HALO) < (unsigned)W)
+        amask |= 1u << k;
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
       if (MODE >= 2) { iy >>= 1; ix >>= 1; }
       if (ok) hoff[k] = DUAL ? (((b * p.Hs + iy) * p.Ws + ix) * 4 + ch)           // pixel index, vector slot
@@ -142,7 +308,28 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     for (int k = 0; k < WV; ++k)
       wreg[k] = woff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.w + woff[k] + c0) : make_uint4(0, 0, 0, 0);
   };
-  auto store_chunk = [&]() {
+  float* cof = reinterpret_cast<float*>(smem + p.aux_off);      // PRO: [Cin][2] (sc, sh)
+  uint64_t seedv = 0;
+  bool drop = false;
+  if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
+  auto store_chunk = [&](int ck) {
+    if (PRO) {
+      const int cb = ck * CK + (tid & 3) * 8;         // this thread's 8 channels of the chunk (idx & 3 == tid & 3)
+      float scv[8], shv[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * cb + 4 * q);
+        scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < HV; ++k)
+        if (hoff[k] >= 0) {
+          const unsigned e0 = DUAL ? (unsigned)(hoff[k] >> 2) * (unsigned)p.Cin + (unsigned)cb
+                                   : (unsigned)(hoff[k] + ck * CK);
+          hreg[k] = pro_vec(hreg[k], scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+          if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.a_out + e0) = hreg[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < HV; ++k)
       if (hlds[k] >= 0) *reinterpret_cast<uint4*>(Xs + hlds[k]) = hreg[k];
@@ -152,8 +339,9 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   };
 
   load_chunk(0);
+  if (PRO) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   for (int ck = 0; ck < nchunks; ++ck) {
-    store_chunk();
+    store_chunk(ck);
     __syncthreads();
     if (ck + 1 < nchunks) load_chunk(ck + 1);
 #pragma unroll
@@ -182,40 +370,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   // covering one pixel's contiguous couts: full-line HBM writes, coalesced bias/residual reads.
   const int ncols = min(BN, p.Cout - n0);          // valid couts of this tile
   if ((p.Cout & 7) == 0) {
-    constexpr int PF = BN + 4;                       // fp32 row pitch (floats)
-    float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]; fits: BM*(BN+4)*4 <= (halo + weights) bytes
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int pl = wm0 + i * 16 + fr;
-#pragma unroll
-      for (int a = 0; a < TN; ++a) {
-        int nl = wn0 + a * 16 + fq * 4;
-        *reinterpret_cast<float4*>(Os + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                      // 16-byte output chunks per pixel row
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-      int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
-      if (pl >= KT || cc >= ncols) continue;
-      float o[8];
-      float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc);
-      float4 v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
-      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-      size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
-      if (p.bias) {
-        float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
-        float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
-        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
-      }
-      if (p.res) {
-        float r[8];
-        Vec16<bf16_t>::load(p.res + e, r);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] += r[k];
-      }
-      Vec16<bf16_t>::store(p.y + e, o);
-    }
+    lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
     return;
   }
   // ragged cout counts (epsilon / latent heads): direct per-lane stores
@@ -249,7 +404,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 // latency (a block itself does not prefetch: its single LDS image is in use until the chunk's last read).
 __device__ uint4 g_zero16;      // zero page: out-of-image halo pixels and padding rows load from here
 
-template <int KS>
+// PRO: the GroupNorm prologue as an in-LDS pass -- once the chunk has landed every thread reads its own vectors
+// back, applies act(x * sc + sh) and writes them in place (one more barrier per chunk); with two blocks per CU the
+// other block's MFMA phase runs beside this VALU phase.
+template <int KS, bool PRO = false>
 __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   constexpr int TM = 4, BN = 64, NWM = 4, NT = 512, TN = 2;
   constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 256;
@@ -262,7 +420,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   unsigned char* Xs = smem;
   unsigned char* Ws = smem + (size_t)hgroups * 1024;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: group indices stay scalar
   const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
   const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
   const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
@@ -293,11 +452,10 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   constexpr int MAXG = 9;                            // ceil((hgroups + WGROUPS) / 8) for every supported tile
   const int ngroups = hgroups + WGROUPS;
   int goff[MAXG];
-  const bf16_t* gsrc[MAXG];
 #pragma unroll
   for (int k = 0; k < MAXG; ++k) {
     const int gi = wave + k * 8;
-    goff[k] = -1; gsrc[k] = p.x;
+    goff[k] = -1;
     if (gi < ngroups) {
       const int prow = lane >> 2, pslot = lane & 3;
       if (gi < hgroups) {
@@ -313,12 +471,23 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
         const int r = (gi - hgroups) * 16 + prow;
         const int tap = r / BN, n = r - tap * BN;
         const int ch = pslot ^ (((n >> 2) & 1) << 1);
-        gsrc[k] = p.w;
         if (n0 + n < p.Cout) goff[k] = ((n0 + n) * TAPS + tap) * p.Cin + ch * 8;
       }
     }
   }
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+
+  // PRO: this thread's vectors of the halo image (logical channel slot tid & 3, as the register-staged kernel)
+  constexpr int HVD = PRO ? 5 : 1;                   // ceil(576 * 4 / 512): the largest halo tile this kernel takes
+  float* cof = reinterpret_cast<float*>(smem + p.aux_off);
+  uint64_t seedv = 0;
+  bool drop = false;
+  if (PRO) {
+    drop = p.act == 2 && p.seed != nullptr;
+    if (drop) seedv = *p.seed;
+    pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
+  }
+  const bool keep_a = PRO && p.a_out && n0 == 0;
 
   const int nchunks = p.Cin / CK;
   for (int ck = 0; ck < nchunks; ++ck) {
@@ -327,13 +496,41 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
     for (int k = 0; k < MAXG; ++k) {
       const int gi = wave + k * 8;
       if (gi < ngroups) {
-        const bf16_t* src = goff[k] >= 0 ? gsrc[k] + goff[k] + c0 : zero;
+        const bf16_t* src = goff[k] >= 0 ? (gi < hgroups ? p.x : p.w) + goff[k] + c0 : zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + (size_t)gi * 1024), 16, 0, 0);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);                   // the direct loads are counted by vmcnt
     __syncthreads();
+    if (PRO) {
+      const int cb = c0 + (tid & 3) * 8;
+      float scv[8], shv[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * cb + 4 * q);
+        scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
+      }
+      // the plan is recomputed per chunk (a magic-number division per vector) rather than kept in registers:
+      // two of these blocks must fit a CU
+#pragma unroll 1
+      for (int k = 0; k < HVD; ++k) {
+        const int pix = (tid + k * NT) >> 2;
+        if (pix < npix_h) {
+          const int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
+          const int iy = oy0 + hy - HALO, ix = hx - HALO;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {      // padding pixels stay zero
+            uint4* slot = reinterpret_cast<uint4*>(Xs + pix * 64 + swz(pix, tid & 3) * 16);
+            const unsigned e0 = (unsigned)(((b * p.H + iy) * W + ix) * p.Cin + cb);
+            const uint4 v = pro_vec(*slot, scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+            *slot = v;
+            if (keep_a && (unsigned)(hy - HALO) < (unsigned)R && (unsigned)(hx - HALO) < (unsigned)W)
+              *reinterpret_cast<uint4*>(p.a_out + e0) = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = (tap / KS) * WH + (tap % KS);
@@ -354,54 +551,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
     __syncthreads();
   }
 
-  // epilogue through LDS (as conv3x3_halo_bf16; Cout % 8 == 0 is a launch condition)
-  const int ncols = min(BN, p.Cout - n0);
-  constexpr int OPF = BN + 4;
-  float* Os = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    int pl = wm0 + i * 16 + fr;
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-      int nl = wn0 + a * 16 + fq * 4;
-      *reinterpret_cast<float4*>(Os + pl * OPF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
-    }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;
-  for (int idx = tid; idx < BM * CPR; idx += NT) {
-    int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
-    if (pl >= KT || cc >= ncols) continue;
-    float o[8];
-    float4 v0 = *reinterpret_cast<const float4*>(Os + pl * OPF + cc);
-    float4 v1 = *reinterpret_cast<const float4*>(Os + pl * OPF + cc + 4);
-    o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-    size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
-    if (p.bias) {
-      float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
-      float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
-      o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
-    }
-    if (p.res) {
-      float r[8];
-      Vec16<bf16_t>::load(p.res + e, r);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] += r[k];
-    }
-    Vec16<bf16_t>::store(p.y + e, o);
-  }
-}
-
-template <int KS>
-void launch_dlds(const C3P& p, hipStream_t st) {
-  const int HALO = KS / 2;
-  const int npix_h = (p.R + 2 * HALO) * (p.W + 2 * HALO);
-  size_t lds = ((size_t)((npix_h + 15) / 16) * 16 + KS * KS * 64) * 64;
-  size_t olds = (size_t)256 * (64 + 4) * sizeof(float);
-  if (olds > lds) lds = olds;
-  auto kern = conv_dlds_bf16<KS>;
-  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
+  // epilogue through LDS (Cout % 8 == 0 is a launch condition)
+  lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
 }
 
 // magic multiplier for the division by the halo-row width; 0 when not exact over [0, npix)
@@ -412,37 +563,48 @@ inline unsigned wh_magic(int WH, int npix) {
   return m;
 }
 
-template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false>
-void launch(const C3P& p, hipStream_t st) {
+inline size_t aux_bytes(const C3P& p, bool pro, int nwaves, int BN) {
+  size_t a = pro ? (size_t)p.Cin * 16 : 0, s = p.st_out ? (size_t)nwaves * BN * 8 : 0;
+  return a > s ? a : s;
+}
+
+template <int KS, bool PRO = false>
+void launch_dlds(C3P& p, hipStream_t st) {
+  const int HALO = KS / 2;
+  const int npix_h = (p.R + 2 * HALO) * (p.W + 2 * HALO);
+  size_t lds = ((size_t)((npix_h + 15) / 16) * 16 + KS * KS * 64) * 64;
+  size_t olds = (size_t)256 * (64 + 4) * sizeof(float);
+  if (olds > lds) lds = olds;
+  p.aux_off = (int)lds;
+  lds += aux_bytes(p, PRO, 8, 64);
+  auto kern = conv_dlds_bf16<KS, PRO>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
+}
+
+template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false, bool PRO = false>
+void launch(C3P& p, hipStream_t st) {
   size_t lds = ((MODE == 1 ? (size_t)(2 * p.R + 1) * (2 * p.W + 1) : (size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2))) +
                 KS * KS * BN) * 64;
   size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
-  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL>;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  p.aux_off = (int)lds;
+  lds += aux_bytes(p, PRO, NWM * 2, BN);
+  auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL, PRO>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
 
-}  // namespace
+void clear_pro(C3P& p) {
+  p.st_out = nullptr; p.aux_off = 0;
+  p.st1 = p.st2 = nullptr; p.T1 = p.T2 = 0;
+  p.gamma = p.beta = p.film_t = p.film_a = nullptr; p.ld_t = p.ld_a = 0; p.eps = 0.f;
+  p.act = 0; p.seed = nullptr; p.salt = 0; p.thr = 0; p.dscale = 1.f;
+  p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr;
+}
 
-// mode: 0 stride 1, 1 stride 2 (H, W <= 32 out), 2 nearest-x2-upsampled input, 3 zero-stuffed x2 input
-// (transposed stride 2).
-// H, W = OUTPUT dims.  Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (the
-// caller falls back to idf_conv2d_fwd).
-extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
-                                int H, int W, int Cin, int Cout, int mode, void* stream) {
-  if (mode < 0 || mode > 3 || (Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (mode >= 2 && ((H | W) & 1)) ||
-      (mode == 1 && (W > 32 || Cout <= 32)))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: B%d H%d W%d Cin%d Cout%d mode%d not covered", B, H, W, Cin, Cout, mode);
-  if (B == 0) return IDF_OK;
-  C3P p;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
-  p.x2 = nullptr; p.C1 = Cin;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.Hs = mode == 1 ? 2 * H : (mode ? H / 2 : H); p.Ws = mode == 1 ? 2 * W : (mode ? W / 2 : W);
-  int ws = 0;
-  while ((1 << ws) < W) ++ws;
-  p.wshift = ws;
+// pixel tile of a 3x3 launch: BM pixels = R rows x W columns; false when the halo tile does not fit
+bool plan3(int B, int H, int W, int Cout, int mode, int* BM_, int* R_) {
   // 128-pixel tiles when the problem is big enough to still fill the chip, else 64
   long M = (long)B * H * W;
   static const int force_bm = getenv("IDF_CONV_BM") ? atoi(getenv("IDF_CONV_BM")) : 0;
@@ -461,49 +623,11 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
     break;
   }
   const int hrows = mode == 1 ? 2 * R + 1 : R + 2, hcols = mode == 1 ? 2 * W + 1 : W + 2;
-  if (hrows * hcols * 4 > (BM == 256 ? HALO_VEC_MAX_512 : (mode == 1 ? HALO_VEC_MAX_S2 : HALO_VEC_MAX_256)))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: halo too large (R%d W%d)", R, W);
-  p.R = R; p.tiles_per_img = H / R;
-  p.wh_magic = wh_magic(hcols, hrows * hcols);
-  if (!p.wh_magic || (long)B * p.Hs * p.Ws * Cin >= (1L << 31) || (long)Cout * 9 * Cin >= (1L << 31))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: tensor too large for 32-bit offsets");
-  hipStream_t st = (hipStream_t)stream;
-  const bool bn32 = Cout <= 32;
-  p.n_tiles = idf_cdiv(Cout, bn32 ? 32 : 64);
-#define IDF_C3_LAUNCH(MODE)                                              \
-  do {                                                                   \
-    if (bn32) { if (BM == 128) launch<MODE, 4, 32>(p, st); else launch<MODE, 2, 32>(p, st); } \
-    else { if (BM == 256) launch<MODE, 4, 64, 4>(p, st); else if (BM == 128) launch<MODE, 4, 64>(p, st); else launch<MODE, 2, 64>(p, st); } \
-  } while (0)
-  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
-  static const long dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
-  // direct-to-LDS variant: pays once two of its blocks share every CU (it does not prefetch within a block)
-  if (mode == 0 && BM == 256 && !bn32 && (dlds & 1) && (Cout & 7) == 0 && (long)B * p.tiles_per_img * p.n_tiles >= dlds_min &&
-      ((R + 2) * (W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3>(p, st);
-  else if (mode == 0) IDF_C3_LAUNCH(0);
-  else if (mode == 1) launch<1, 2, 64>(p, st);
-  else if (mode == 2) IDF_C3_LAUNCH(2);
-  else IDF_C3_LAUNCH(3);
-#undef IDF_C3_LAUNCH
-  IDF_CHECK_LAUNCH();
-  return IDF_OK;
+  *BM_ = BM; *R_ = R;
+  return hrows * hcols * 4 <= (BM == 256 ? HALO_VEC_MAX_512 : (mode == 1 ? HALO_VEC_MAX_S2 : HALO_VEC_MAX_256));
 }
 
-// 1x1 convolution (stride 1) forward / data gradient through the same pipeline (KS = 1): w [Cout][Cin].
-// IDF_ERR_UNSUPPORTED for shapes it does not cover (the caller then uses idf_bgemm).
-extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias,
-                                const void* res, void* y, int B, int H, int W, int Cin, int Cout, void* stream) {
-  if (!x2) C1 = Cin;
-  if ((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: B%d H%d W%d Cin%d (C1 %d) Cout%d not covered", B, H, W, Cin, C1, Cout);
-  if (B == 0) return IDF_OK;
-  C3P p;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
-  p.x2 = (const bf16_t*)x2; p.C1 = C1;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Hs = H; p.Ws = W;
-  int ws = 0;
-  while ((1 << ws) < W) ++ws;
-  p.wshift = ws;
+bool plan1(int B, int H, int W, int Cout, int* BM_, int* R_) {
   const long M = (long)B * H * W;
   const int nt = idf_cdiv(Cout, 64);
   int BM = 64;
@@ -513,23 +637,177 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
   if (R < 1) R = 1;
   if (R > H) R = H;
   while (H % R) --R;
-  if (R * W * 4 > (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tile too large (R%d W%d)", R, W);
-  p.R = R; p.tiles_per_img = H / R; p.n_tiles = nt;
-  p.wh_magic = wh_magic(W, R * W);
-  if (!p.wh_magic || (long)B * H * W * Cin >= (1L << 31))
-    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: tensor too large for 32-bit offsets");
+  *BM_ = BM; *R_ = R;
+  return R * W * 4 <= (BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256);
+}
+
+bool shape3_ok(int H, int W, int Cin, int Cout, int mode) {
+  return !(mode < 0 || mode > 3 || (Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (mode >= 2 && ((H | W) & 1)) ||
+           (mode == 1 && (W > 32 || Cout <= 32)));
+}
+bool shape1_ok(int W, int Cin, int Cout) {
+  return !((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7));
+}
+
+const int g_dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
+const long g_dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
+const long g_dlds_min_pro = getenv("IDF_CONV_DLDS_MIN_PRO") ? atol(getenv("IDF_CONV_DLDS_MIN_PRO")) : 1536;
+
+// dispatch of a 3x3 launch whose C3P is filled in (PRO / DUAL only for mode 0)
+template <bool DUAL, bool PRO>
+void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
+  const bool bn32 = p.Cout <= 32;
+  p.n_tiles = idf_cdiv(p.Cout, bn32 ? 32 : 64);
+#define IDF_C3_LAUNCH(MODE)                                              \
+  do {                                                                   \
+    if (bn32) { if (BM == 128) launch<MODE, 4, 32, 2, 3, DUAL, PRO>(p, st); else launch<MODE, 2, 32, 2, 3, DUAL, PRO>(p, st); } \
+    else { if (BM == 256) launch<MODE, 4, 64, 4, 3, DUAL, PRO>(p, st); else if (BM == 128) launch<MODE, 4, 64, 2, 3, DUAL, PRO>(p, st); else launch<MODE, 2, 64, 2, 3, DUAL, PRO>(p, st); } \
+  } while (0)
+  // direct-to-LDS variant: pays once two of its blocks share every CU (it does not prefetch within a block)
+  const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
+  if (!DUAL && mode == 0 && BM == 256 && !bn32 && (g_dlds & 1) && (p.Cout & 7) == 0 && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min) &&
+      ((p.R + 2) * (p.W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3, PRO>(p, st);
+  else if (mode == 0) IDF_C3_LAUNCH(0);
+  else if constexpr (!DUAL && !PRO) {
+    if (mode == 1) launch<1, 2, 64>(p, st);
+    else if (mode == 2) IDF_C3_LAUNCH(2);
+    else IDF_C3_LAUNCH(3);
+  }
+#undef IDF_C3_LAUNCH
+}
+
+template <bool DUAL, bool PRO>
+void dispatch1(C3P& p, int BM, hipStream_t st) {
+  p.n_tiles = idf_cdiv(p.Cout, 64);
+  const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
+  if (!DUAL && BM == 256 && (g_dlds & 2) && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min)) launch_dlds<1, PRO>(p, st);
+  else if (BM == 256) launch<0, 4, 64, 4, 1, DUAL, PRO>(p, st);
+  else if (BM == 128) launch<0, 4, 64, 2, 1, DUAL, PRO>(p, st);
+  else launch<0, 2, 64, 2, 1, DUAL, PRO>(p, st);
+}
+
+int fill_common(C3P& p, int B, int H, int W, int Cin, int Cout, int mode, int KS, int* BM) {
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Hs = mode == 1 ? 2 * H : (mode >= 2 ? H / 2 : H); p.Ws = mode == 1 ? 2 * W : (mode >= 2 ? W / 2 : W);
+  int ws = 0;
+  while ((1 << ws) < W) ++ws;
+  p.wshift = ws;
+  int R;
+  if (KS == 3) {
+    if (!plan3(B, H, W, Cout, mode, BM, &R)) return 1;
+    const int hrows = mode == 1 ? 2 * R + 1 : R + 2, hcols = mode == 1 ? 2 * W + 1 : W + 2;
+    p.wh_magic = wh_magic(hcols, hrows * hcols);
+  } else {
+    if (!plan1(B, H, W, Cout, BM, &R)) return 1;
+    p.wh_magic = wh_magic(W, R * W);
+  }
+  p.R = R; p.tiles_per_img = H / R;
+  if (!p.wh_magic || (long)B * p.Hs * p.Ws * Cin >= (1L << 31) || (long)Cout * KS * KS * Cin >= (1L << 31) ||
+      (long)B * H * W * Cout >= (1L << 31))
+    return 2;
+  return 0;
+}
+
+}  // namespace
+
+// mode: 0 stride 1, 1 stride 2 (H, W <= 32 out), 2 nearest-x2-upsampled input, 3 zero-stuffed x2 input
+// (transposed stride 2).
+// H, W = OUTPUT dims.  Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (the
+// caller falls back to idf_conv2d_fwd).  st_out: optional statistics partials of y (idf_conv_tiles).
+extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void* res, void* y, int B,
+                                int H, int W, int Cin, int Cout, int mode, float* st_out, void* stream) {
+  if (!shape3_ok(H, W, Cin, Cout, mode))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: B%d H%d W%d Cin%d Cout%d mode%d not covered", B, H, W, Cin, Cout, mode);
+  if (st_out && (Cout & 7)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_bf16: statistics need Cout %% 8 == 0");
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.x2 = nullptr; p.C1 = Cin; p.st_out = st_out;
+  int BM;
+  if (int e = fill_common(p, B, H, W, Cin, Cout, mode, 3, &BM))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv3x3_bf16: halo too large (H%d W%d)" : "conv3x3_bf16: tensor too large for 32-bit offsets", H, W);
+  dispatch3<false, false>(p, mode, BM, (hipStream_t)stream);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// 1x1 convolution (stride 1) forward / data gradient through the same pipeline (KS = 1): w [Cout][Cin].
+// IDF_ERR_UNSUPPORTED for shapes it does not cover (the caller then uses idf_bgemm).
+extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias,
+                                const void* res, void* y, int B, int H, int W, int Cin, int Cout, float* st_out, void* stream) {
+  if (!x2) C1 = Cin;
+  if (!shape1_ok(W, Cin, Cout) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv1x1_bf16: B%d H%d W%d Cin%d (C1 %d) Cout%d not covered", B, H, W, Cin, C1, Cout);
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.x2 = (const bf16_t*)x2; p.C1 = C1; p.st_out = st_out;
+  int BM;
+  if (int e = fill_common(p, B, H, W, Cin, Cout, 0, 1, &BM))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv1x1_bf16: tile too large (H%d W%d)" : "conv1x1_bf16: tensor too large for 32-bit offsets", H, W);
   hipStream_t st = (hipStream_t)stream;
-  static const int dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
-  static const long dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
-  if (!x2 && BM == 256 && (dlds & 2) && (long)B * p.tiles_per_img * nt >= dlds_min) launch_dlds<1>(p, st);
-  else if (x2) {
-    if (BM == 256) launch<0, 4, 64, 4, 1, true>(p, st);
-    else if (BM == 128) launch<0, 4, 64, 2, 1, true>(p, st);
-    else launch<0, 2, 64, 2, 1, true>(p, st);
-  } else if (BM == 256) launch<0, 4, 64, 4, 1>(p, st);
-  else if (BM == 128) launch<0, 4, 64, 2, 1>(p, st);
-  else launch<0, 2, 64, 2, 1>(p, st);
+  if (x2) dispatch1<true, false>(p, BM, st);
+  else dispatch1<false, false>(p, BM, st);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// Pixel tiles per image of the launch the entry points above / below make for this shape = the T of the
+// statistics partials st_out [B][T][Cout][2] they write; -1 when the shape is not covered.
+extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps) {
+  int BM, R;
+  if (taps == 9) {
+    if (!shape3_ok(H, W, Cin, Cout, mode) || !plan3(B, H, W, Cout, mode, &BM, &R)) return -1;
+  } else {
+    if (mode != 0 || !shape1_ok(W, Cin, Cout) || !plan1(B, H, W, Cout, &BM, &R)) return -1;
+  }
+  return H / R;
+}
+
+// y = conv(act(GroupNorm/FiLM(x))) + bias (+ res) in ONE launch (modules.py:264-288, 309-320, 145-150): stride-1 3x3
+// (taps 9) or 1x1 (taps 1) over x [B,H,W,Cin] -- or over the never-materialised concatenation x | x2 (models.py:321).
+// The GroupNorm(32) statistics are not computed here: the launches that produced x (and x2) left per-channel partial
+// sums st1 [B][T1][C1][2] (st2 [B][T2][Cin-C1][2]) behind (st_out of the entry points of this file, or idf_gn_partials);
+// every block folds them with gamma / beta and the FiLM pairs (layout as idf_gn_coef_fwd) into the per-(image, channel)
+// affine and applies  act 1: u = x*sc+sh;  act 2: SiLU(u), then dropout(p_drop) when seed != NULL  while staging its tile.
+// Optional outputs (training; NULL otherwise): a_out = the activated tensor [B,H,W,Cin] (kept for the weight gradient),
+// mean / rstd [B,32] and sc / sh [B,Cin] (for idf_gn_fused_bwd / idf_gn_coef_bwd); st_out as above.
+extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                                const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                                int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
+                                const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                                float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin, int Cout,
+                                int taps, void* stream) {
+  if (!x2) { C1 = Cin; st2 = nullptr; T2 = 0; }
+  const bool ok = taps == 9 ? shape3_ok(H, W, Cin, Cout, 0) : (taps == 1 && shape1_ok(W, Cin, Cout));
+  if (!ok || (Cin % 32) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: B%d H%d W%d Cin%d (C1 %d) Cout%d taps%d not covered", B, H, W, Cin, C1, Cout, taps);
+  if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "conv_gn_bf16: act must be 1 or 2");
+  if (!st1 || T1 < 1 || (x2 && (!st2 || T2 < 1))) IDF_FAIL(IDF_ERR_BADARG, "conv_gn_bf16: input statistics missing");
+  if (st_out && (Cout & 7)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: statistics need Cout %% 8 == 0");
+  if ((sc != nullptr) != (sh != nullptr) || (sc != nullptr) != (mean != nullptr) || (sc != nullptr) != (rstd != nullptr))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_gn_bf16: mean / rstd / sc / sh go together");
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.x2 = (const bf16_t*)x2; p.C1 = C1; p.st_out = st_out;
+  p.st1 = st1; p.T1 = T1; p.st2 = st2; p.T2 = T2;
+  p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * Cin; p.ld_a = ld_a ? ld_a : 2 * Cin; p.eps = eps;
+  p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
+  p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  p.a_out = (bf16_t*)a_out; p.mean_out = mean; p.rstd_out = rstd; p.sc_out = sc; p.sh_out = sh;
+  int BM;
+  if (int e = fill_common(p, B, H, W, Cin, Cout, 0, taps == 9 ? 3 : 1, &BM))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv_gn_bf16: tile too large (H%d W%d)" : "conv_gn_bf16: tensor too large for 32-bit offsets", H, W);
+  if ((long)B * H * W * Cin >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: tensor too large for 32-bit offsets");
+  hipStream_t st = (hipStream_t)stream;
+  if (taps == 9) { if (x2) dispatch3<true, true>(p, 0, BM, st); else dispatch3<false, true>(p, 0, BM, st); }
+  else { if (x2) dispatch1<true, true>(p, BM, st); else dispatch1<false, true>(p, BM, st); }
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

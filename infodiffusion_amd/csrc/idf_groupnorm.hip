@@ -64,6 +64,42 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const T* __restrict__ x,
   }
 }
 
+// grid (nchunk, B): per-CHANNEL partial (sum, sumsq) of `chunk` pixels -> part[b][ck][c].  The statistics a conv
+// launch leaves behind for the GroupNorm that reads its output (idf_conv3x3.hip, st_out), for tensors that did
+// not come out of such a launch.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partials_kernel(const T* __restrict__ x, float2* __restrict__ part,
+                                                          int HW, int C, int chunk) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [lanes][C][2]
+  const int vpp = C / VE, lanes = 256 / vpp, tid = threadIdx.x;
+  const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+  const int v = tid % vpp, pl = tid / vpp;
+  float s[VE], ss[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s[e] = ss[e] = 0.f;
+  const int pend = min(HW, (ck + 1) * chunk);
+  if (pl < lanes) {
+    for (int p = ck * chunk + pl; p < pend; p += lanes) {
+      float xv[VE];
+      Vec16<T>::load(x + ((size_t)b * HW + p) * C + v * VE, xv);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { s[e] += xv[e]; ss[e] += xv[e] * xv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[(pl * C + v * VE + e) * 2] = s[e];
+      red[(pl * C + v * VE + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < lanes; ++l) { a += red[(l * C + c) * 2]; q += red[(l * C + c) * 2 + 1]; }
+    part[((size_t)b * nchunk + ck) * C + c] = make_float2(a, q);
+  }
+}
+
 // grid B.  Merge partials (in double), write mean/rstd, fold coefficients.
 __global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ part, int nchunk, int HW, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -654,6 +690,27 @@ extern "C" int idf_gn_workspace_floats(int B, int HW, int C) {
   int chunk = pick_chunk(B, HW);
   int nchunk = idf_cdiv(HW, chunk);
   return B * nchunk * (C > G ? C : G) * 2;
+}
+
+// Per-channel statistics partials of a tensor: part [B][T][C][2] (sum, sum of squares over T pixel chunks),
+// T = idf_gn_partials_chunks(B, HW).  What the conv launches write as st_out, for tensors produced elsewhere.
+extern "C" int idf_gn_partials_chunks(int B, int HW) { return idf_cdiv(HW, pick_chunk(B, HW)); }
+
+extern "C" int idf_gn_partials(const void* x, float* part, int B, int HW, int C, int dtype, void* stream) {
+  if (B == 0) return IDF_OK;
+  int VE = dtype == IDF_F32 ? 4 : 8;
+  if (C % VE || C / VE > 256) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_partials: C=%d unsupported", C);
+  hipStream_t st = (hipStream_t)stream;
+  int chunk = pick_chunk(B, HW), nchunk = idf_cdiv(HW, chunk);
+  int lanes = 256 / (C / VE);
+  size_t lds = (size_t)lanes * C * 2 * sizeof(float);
+  dim3 g(nchunk, B);
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(gn_partials_kernel<float>, g, dim3(256), lds, st, (const float*)x, (float2*)part, HW, C, chunk);
+  else
+    hipLaunchKernelGGL(gn_partials_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)x, (float2*)part, HW, C, chunk);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
 }
 
 extern "C" int idf_gn_coef_fwd(const void* x, const float* gamma, const float* beta, const float* film_t,

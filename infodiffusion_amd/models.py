@@ -93,7 +93,7 @@ class _UNetSkeleton(nn.Module):
         """block_call(layer, h, **kw).  While gradients are recorded the skip list holds ALIASES of each
         tensor handed out by its down-path consumer (`want_alias`): the skip connection's gradient then
         arrives at that consumer's first op and is added in-kernel instead of by an autograd add pass."""
-        h = ops.fused_conv(x, self.head.weight, self.head.bias, self._cfg_head)
+        h = ops.fused_conv(x, self.head.weight, self.head.bias, self._cfg_head, want_stats=True)
         alias_mode = torch.is_grad_enabled() and h.requires_grad
         skips = []
         for layer in self.downblocks:

@@ -233,8 +233,8 @@ class DownSample(nn.Module):
         """want_alias: also return an alias of x for the skip connection (its gradient joins this conv's
         data-gradient epilogue instead of an autograd add)."""
         if want_alias:
-            return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, passthrough=1)
-        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg)
+            return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, passthrough=1, want_stats=True)
+        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, want_stats=True)
 
 
 class UpSample(nn.Module):
@@ -248,7 +248,7 @@ class UpSample(nn.Module):
         self._cfg = _cfg(_Shadows(self.main), ops.UP2, 9, _ACT_NONE)
 
     def forward(self, x, temb=None, aemb=None):
-        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg)
+        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, want_stats=True)
 
 
 class AttnBlock(nn.Module):
@@ -278,7 +278,7 @@ class AttnBlock(nn.Module):
         qkv, x = ops.fused_conv(x, self._qkv.weight(), self._qkv.bias(), self._cfg_qkv, gn.weight, gn.bias,
                                 passthrough=1)      # the residual branch's gradient joins the GN backward
         o = ops.attention(qkv)
-        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x)
+        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x, want_stats=True)
 
 
 class CrossAttnBlock(nn.Module):
@@ -331,8 +331,10 @@ class _ResBase(nn.Module):
         gn, conv = blk[0], blk[-1]
         seed = self.ctx.seed if (drop_site is not None and self.training) else None
         cfg = _cfg(getattr(self, '_sh_' + name), ops.S1, 9, _ACT_SILU, self.p_drop, self.salt + (drop_site or 0))
+        # every conv of a block feeds a GroupNorm (the next stage, the next block, the AttnBlock or the tail):
+        # its epilogue leaves the statistics of its output behind
         return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
-                              passthrough)
+                              passthrough, want_stats=True)
 
     def _block1(self, x, want_alias=False):
         """(h, residual[, alias of x]) of the block's first stage.  x may be the pair (h_prev, skip) of an

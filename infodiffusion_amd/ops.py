@@ -121,28 +121,108 @@ def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
 _CONV1X1 = os.environ.get('IDF_CONV1X1', '1') != '0'
 
 
-def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None):
-    """x logical [B,Cin,Hs,Ws] NHWC-dense; w_fwd [Cout][taps][Cin] in x.dtype."""
+@functools.lru_cache(maxsize=None)
+def conv_tiles(B, H, W, Cin, Cout, mode, taps):
+    """Pixel tiles per image of the halo-kernel launch for this shape (-1: not covered) = T of its statistics."""
+    return int(_lib.load().idf_conv_tiles(B, H, W, Cin, Cout, {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], taps))
+
+
+def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device):
+    """Buffer for the per-channel GroupNorm statistics partials a conv launch writes for its output, or None."""
+    if Cout % 8:
+        return None
+    T = conv_tiles(B, Ho, Wo, Cin, Cout, mode, taps)
+    return torch.empty((B, T, Cout, 2), dtype=torch.float32, device=device) if T > 0 else None
+
+
+def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None, want_stats=False):
+    """x logical [B,Cin,Hs,Ws] NHWC-dense; w_fwd [Cout][taps][Cin] in x.dtype.  want_stats: returns (y, st) where
+    st = the statistics partials of y (None when the kernel that ran does not produce them)."""
     B, Cin, Hs, Ws = x.shape
     Ho, Wo = out_hw_ if out_hw_ is not None else out_hw(mode, Hs, Ws)
     y = empty_nhwc(B, Cout, Ho, Wo, x.dtype, x.device)
+    st = None
+
+    def done():
+        return (y, st) if want_stats else y
     if (taps == 1 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin % 32 == 0 and Cout % 8 == 0
             and 4 <= Wo <= 128 and not (Wo & (Wo - 1)) and _CONV1X1):
         # 1x1 conv through the halo-conv pipeline without the halo (LDS-swizzled tiles, full-line epilogue)
-        call('idf_conv1x1_bf16', _p(x), None, 0, _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout, _st())
-        return y
+        if want_stats:
+            st = _new_stats(B, Ho, Wo, Cin, Cout, S1, 1, x.device)
+        call('idf_conv1x1_bf16', _p(x), None, 0, _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout, _p(st),
+             _st())
+        return done()
     if taps == 1 and mode == S1 and act == 0 and Cin % 8 == 0 and Cout % 4 == 0:
         # 1x1 conv = [pixels, Cin] x [Cout, Cin]^T (+bias, +residual): the short-K GEMM
         M = B * Ho * Wo
         bgemm_raw(x, 0, w_fwd, 0, y, 0, bias, 1, 0, 0, 0, Cin, Cin, Cout, M, Cout, Cin, 0, 0, res=residual)
-        return y
+        return done()
     if uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
+        if want_stats:
+            st = _new_stats(B, Ho, Wo, Cin, Cout, mode, 9, x.device)
         call('idf_conv3x3_bf16', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), B, Ho, Wo, Cin, Cout,
-             {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], _st())
-        return y
+             {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], _p(st), _st())
+        return done()
     call('idf_conv2d_fwd', _p(x), _p(w_fwd), _p(bias), _p(residual), _p(y), _p(sc), _p(sh), _p(seed),
          salt, float(p_drop), B, Hs, Ws, Cin, Ho, Wo, Cout, mode, taps, act, _dt(x), _st())
-    return y
+    return done()
+
+
+_GN_FUSE = os.environ.get('IDF_GN_FUSE', '1') != '0'
+
+
+def gn_partials_raw(x):
+    """Per-channel statistics partials [B, T, C, 2] of a tensor that did not come out of a conv launch."""
+    B, C, H, W = x.shape
+    T = int(_lib.load().idf_gn_partials_chunks(B, H * W))
+    st = torch.empty((B, T, C, 2), dtype=torch.float32, device=x.device)
+    call('idf_gn_partials', _p(x), _p(st), B, H * W, C, _dt(x), _st())
+    return st
+
+
+def stats_of(x):
+    """The statistics partials riding on x (left by its producer), else one stand-alone pass over it."""
+    st = getattr(x, '_gn', None)
+    if st is not None and st.shape[0] == x.shape[0] and st.shape[2] == x.shape[1]:
+        return st
+    return gn_partials_raw(x)
+
+
+def conv_gn_ok(x, x2, taps, Cout):
+    """The one-launch GroupNorm-prologue conv (idf_conv_gn_bf16) covers this input."""
+    if not (_GN_FUSE and x.is_cuda and x.dtype == torch.bfloat16):
+        return False
+    B, C1, H, W = x.shape
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    if Cin % 32 or (x2 is not None and (C1 % 32 or x2.dtype != torch.bfloat16 or x2.shape[2:] != x.shape[2:])):
+        return False
+    if taps == 1 and not _CONV1X1:
+        return False
+    return conv_tiles(B, H, W, Cin, Cout, S1, taps) > 0
+
+
+def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
+                keep_a=False, keep_coef=False, want_stats=False):
+    """y = conv(act(GN/FiLM(x | x2))) + bias (+ residual) in one launch -> (y, a, mean, rstd, sc, sh, st_out);
+    a / the coefficients are None unless asked for (training)."""
+    B, C1, H, W = x.shape
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    dev = x.device
+    y = empty_nhwc(B, Cout, H, W, x.dtype, dev)
+    a = empty_nhwc(B, Cin, H, W, x.dtype, dev) if keep_a else None
+    mean = rstd = sc = sh = None
+    if keep_coef:
+        mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
+        rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
+        sc = torch.empty((B, Cin), dtype=torch.float32, device=dev)
+        sh = torch.empty((B, Cin), dtype=torch.float32, device=dev)
+    st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev) if want_stats else None
+    call('idf_conv_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
+         _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, act, _p(seed), salt, float(p_drop),
+         _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout,
+         taps, _st())
+    return y, a, mean, rstd, sc, sh, st
 
 
 def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape, residual=None):
@@ -433,41 +513,66 @@ class _FusedConv(torch.autograd.Function):
     """y = conv(act(GN/FiLM(x))) + bias (+ residual);  act per `cfg`.
 
     cfg = dict(mode, taps, act, p_drop, salt, shadows) where shadows() returns the
-    (forward, data-gradient) weight shadows in the activation dtype.  The activated
-    tensor a = dropout(SiLU(GN/FiLM(x))) is materialised once by `idf_gn_apply`
-    (HBM-bound pass) and kept for the weight gradient; the conv itself is a plain
-    implicit GEMM on `a`.
+    (forward, data-gradient) weight shadows in the activation dtype.
+
+    bf16: ONE launch (`idf_conv_gn_bf16`) -- the GroupNorm statistics of x were left behind by the launch
+    that produced x (`xst`; or one stand-alone pass), each block folds them into the per-(sample, channel)
+    affine and applies it, SiLU and dropout while staging its tile; in training that launch also writes
+    the activated tensor `a` (kept for the weight gradient) and the coefficients the GroupNorm backward
+    needs.  fp32 / shapes the halo kernels do not cover: `a` is materialised by the GroupNorm kernels
+    first (one launch, or three for big samples) and the conv is a plain implicit GEMM on it.
+
+    Outputs: y [, statistics partials of y (want_stats; not differentiable)] [, 1-2 aliases of x].
     """
 
     @staticmethod
     def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None,
-                passthrough=False):
+                passthrough=False, xst=None, want_stats=False):
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
         p_drop = cfg['p_drop'] if seed is not None else 0.0
         mean = rstd = sc = sh = None
         a = x
-        if act and gn_small_ok(x):
-            a, mean, rstd, sc, sh = gn_fused_fwd_raw(x, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act)
-        elif act:
-            mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
-            a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
+        st = None
         w_fwd = cfg['shadows'](x.dtype, train)[0]
-        y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, weight.shape[0])
+        Cout = weight.shape[0]
+        need = ctx.needs_input_grad
+        if act and mode == S1 and xst is not None and conv_gn_ok(x, None, taps, Cout):
+            y, a, mean, rstd, sc, sh, st = conv_gn_raw(
+                x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias, residual,
+                Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats)
+        else:
+            if act and gn_small_ok(x):
+                a, mean, rstd, sc, sh = gn_fused_fwd_raw(x, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act)
+            elif act:
+                mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
+                a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
+            y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, Cout, want_stats=want_stats)
+            if want_stats:
+                y, st = y
         ctx.cfg, ctx.p_drop, ctx.slots = cfg, p_drop, slots or (None, None, None, None)
         ctx.has_res = residual is not None
+        ctx.has_st = st is not None
         ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                               seed)
+        outs = (y,)
+        if st is not None:
+            ctx.mark_non_differentiable(st)
+            outs += (st,)
         if passthrough:
             # extra outputs = x itself (1 or 2 aliases): whatever gradient the block's residual / shortcut
             # branch, or a skip connection branching off x, sends back arrives HERE and is added inside the
             # GroupNorm backward kernel / the data-gradient epilogue (no autograd add pass)
-            return (y,) + tuple(x.detach() for _ in range(int(passthrough)))
-        return y
+            outs += tuple(x.detach() for _ in range(int(passthrough)))
+        return outs if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, dy, dxp=None, dxp2=None):
+    def backward(ctx, dy, *extra):
+        if ctx.has_st:
+            extra = extra[1:]
+        dxp = extra[0] if len(extra) > 0 else None
+        dxp2 = extra[1] if len(extra) > 1 else None
         x, a, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed = ctx.saved_tensors
         cfg, p_drop = ctx.cfg, ctx.p_drop
         act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
@@ -507,28 +612,53 @@ class _FusedConv(torch.autograd.Function):
                                                          sc, sh, seed, salt, p_drop, act, gacc)
             else:
                 dx = dA
-                for extra in (dres_in, dres2_in):
-                    if extra is not None:
-                        dx = dx + extra
+                for ex in (dres_in, dres2_in):
+                    if ex is not None:
+                        dx = dx + ex
         elif need[0] and (dxp is not None or dxp2 is not None):
             dx = dxp if dxp2 is None else (dxp2 if dxp is None else dxp + dxp2)
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None, None, None
+
+
+def _tag(t, st):
+    """Attach the statistics partials of t (what the GroupNorm reading t would compute) to it."""
+    if st is not None:
+        t._gn = st
+    return t
 
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None,
-               passthrough=False):
+               passthrough=False, want_stats=False):
     """passthrough = 1 / 2 returns (y, x') / (y, x', x''): the extra outputs alias x, and gradients sent to
     them (the residual / shortcut branch of a ResBlock, a skip connection) are added to dx inside this
-    op's GroupNorm backward kernel (or its data-gradient epilogue)."""
+    op's GroupNorm backward kernel (or its data-gradient epilogue).
+    want_stats: the conv's epilogue leaves the GroupNorm statistics of y behind (y._gn), so the GroupNorm-fused
+    conv that consumes y needs no statistics pass."""
     if passthrough and os.environ.get('IDF_PASSTHROUGH', '1') == '0':
-        return (fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed),) + (x,) * int(passthrough)
+        return (fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed, want_stats=want_stats),) + (x,) * int(passthrough)
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
     slots = None
     if torch.is_grad_enabled():
         slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
-    return _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, int(passthrough))
+    xst = None
+    in_st = getattr(x, '_gn', None)
+    want_stats = bool(want_stats) and x.is_cuda and x.dtype == torch.bfloat16
+    if cfg['act'] and cfg['mode'] == S1 and conv_gn_ok(x, None, cfg['taps'], weight.shape[0]):
+        xst = stats_of(x)
+        in_st = xst
+    out = _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, int(passthrough),
+                           xst, want_stats)
+    if not isinstance(out, tuple):
+        return out
+    y, rest = out[0], list(out[1:])
+    if rest and rest[0].dtype == torch.float32 and rest[0].dim() == 4 and rest[0].shape[-1] == 2 and (
+            len(rest) > int(passthrough)):
+        _tag(y, rest.pop(0))
+    for alias in rest:
+        _tag(alias, in_st)
+    return (y,) + tuple(rest) if rest else y
 
 
 # ------------------------------------------- ResBlock entry on a skip concatenation
@@ -557,21 +687,34 @@ class _BlockEntryCat(torch.autograd.Function):
     (which also adds the shortcut's data gradient), so neither the concat nor its split copies exist."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, b, gn_w, gn_b, sw, sb, cfg, cfg_sc, train, slots):
+    def forward(ctx, x1, x2, w, b, gn_w, gn_b, sw, sb, cfg, cfg_sc, train, slots, st1=None, st2=None):
         x1, x2 = _nhwc(x1), _nhwc(x2)
         B, C1, H, W = x1.shape
         C = C1 + x2.shape[1]
-        a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
-        h = conv_raw(a, cfg['shadows'](x1.dtype, train)[0], b, None, None, None, None, 0, 0.0, S1, 9, 0, w.shape[0])
+        need = ctx.needs_input_grad
+        w_fwd = cfg['shadows'](x1.dtype, train)[0]
+        st = None
+        if st1 is not None and st2 is not None and conv_gn_ok(x1, x2, 9, w.shape[0]):
+            # GroupNorm + SiLU applied while the conv stages the two sources; statistics from their producers
+            h, a, mean, rstd, sc, sh, st = conv_gn_raw(x1, x2, st1, st2, gn_w, gn_b, None, None, None, cfg['salt'], 0.0,
+                                                       cfg['act'], w_fwd, b, None, w.shape[0], 9, keep_a=need[2],
+                                                       keep_coef=any(need[i] for i in (0, 1, 4, 5)), want_stats=True)
+        else:
+            a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
+            h, st = conv_raw(a, w_fwd, b, None, None, None, None, 0, 0.0, S1, 9, 0, w.shape[0], want_stats=True)
         s = empty_nhwc(B, sw.shape[0], H, W, x1.dtype, x1.device)
         call('idf_conv1x1_bf16', _p(x1), _p(x2), C1, _p(cfg_sc['shadows'](x1.dtype, train)[0]), _p(sb), None, _p(s),
-             B, H, W, C, sw.shape[0], _st())
+             B, H, W, C, sw.shape[0], None, _st())
         ctx.cfg, ctx.cfg_sc, ctx.slots = cfg, cfg_sc, slots or (None,) * 6
+        ctx.has_st = st is not None
         ctx.save_for_backward(x1, x2, a, w, b, gn_w, gn_b, sw, sb, mean, rstd, sc, sh)
+        if st is not None:
+            ctx.mark_non_differentiable(st)
+            return h, s, st
         return h, s
 
     @staticmethod
-    def backward(ctx, dh, ds):
+    def backward(ctx, dh, ds, *_):
         x1, x2, a, w, b, gn_w, gn_b, sw, sb, mean, rstd, sc, sh = ctx.saved_tensors
         cfg, cfg_sc = ctx.cfg, ctx.cfg_sc
         ws, bs, gws, gbs, sws, sbs = ctx.slots
@@ -592,7 +735,7 @@ class _BlockEntryCat(torch.autograd.Function):
         dA = conv_dgrad_raw(dh, cfg['shadows'](x1.dtype, True)[1], S1, 9, a.shape)
         (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None,
                                                        cfg['salt'], 0.0, cfg['act'], (gws, gbs), dres=dxs, x2=x2)
-        return dx1, dx2, dW, db, dgw, dgb, dsW, dsb, None, None, None, None
+        return dx1, dx2, dW, db, dgw, dgb, dsW, dsb, None, None, None, None, None, None
 
 
 def block_entry_cat_ok(x1, x2, conv_w, sc_w):
@@ -601,9 +744,14 @@ def block_entry_cat_ok(x1, x2, conv_w, sc_w):
         return False
     B, C1, H, W = x1.shape
     C = C1 + x2.shape[1]
-    return (C1 % 64 == 0 and x2.shape[1] % 32 == 0 and 4 <= W <= 128 and not (W & (W - 1)) and sc_w.shape[0] % 8 == 0
-            and conv_w.shape[1] == C and gn_small_ok(x1, x2) and _CONV1X1
-            and uses_halo_kernel(x1.dtype, 9, 0, S1, B, C, conv_w.shape[0], H, W))
+    if not (C1 % 32 == 0 and x2.shape[1] % 32 == 0 and 4 <= W <= 128 and not (W & (W - 1)) and sc_w.shape[0] % 8 == 0
+            and conv_w.shape[1] == C and _CONV1X1 and uses_halo_kernel(x1.dtype, 9, 0, S1, B, C, conv_w.shape[0], H, W)):
+        return False
+    # the GroupNorm backward (and the forward where the one-launch conv does not apply) runs in the one-launch
+    # two-source GroupNorm kernels; an inference pass needs only the GroupNorm-prologue conv
+    if gn_small_ok(x1, x2) and C1 % 64 == 0:
+        return True
+    return not torch.is_grad_enabled() and conv_gn_ok(x1, x2, 9, conv_w.shape[0])
 
 
 def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
@@ -611,8 +759,14 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
     slots = None
     if torch.is_grad_enabled():
         slots = tuple(slot_of(p) for p in (conv.weight, conv.bias, gn.weight, gn.bias, shortcut.weight, shortcut.bias))
-    return _BlockEntryCat.apply(x1, x2, conv.weight, conv.bias, gn.weight, gn.bias, shortcut.weight, shortcut.bias,
-                                cfg, cfg_sc, train, slots)
+    st1 = st2 = None
+    if conv_gn_ok(x1, x2, 9, conv.weight.shape[0]):
+        st1, st2 = stats_of(x1), stats_of(x2)
+    out = _BlockEntryCat.apply(x1, x2, conv.weight, conv.bias, gn.weight, gn.bias, shortcut.weight, shortcut.bias,
+                               cfg, cfg_sc, train, slots, st1, st2)
+    if len(out) == 3:
+        _tag(out[0], out[2])
+    return out[0], out[1]
 
 
 # ------------------------------------------------------------------ attention

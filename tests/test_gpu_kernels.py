@@ -361,7 +361,7 @@ def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     y1 = ops.conv_raw(xc, wf, bias, None, None, None, None, 0, 0.0, ops.S1, 1, 0, Cout)
     y2 = ops.empty_nhwc(B, Cout, H, H, torch.bfloat16, x1.device)
     ops.call('idf_conv1x1_bf16', x1.data_ptr(), x2.data_ptr(), C1, wf.data_ptr(), bias.data_ptr(), None, y2.data_ptr(),
-             B, H, H, C, Cout, torch.cuda.current_stream().cuda_stream)
+             B, H, H, C, Cout, None, torch.cuda.current_stream().cuda_stream)
     assert torch.equal(y1, y2)
     # weight gradient over the pair (table-driven launch, arena slots)
     dy = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
@@ -390,3 +390,111 @@ def test_prep_u8_matches_torchvision_chain_bitwise():
     assert out.shape == ref.shape and out.is_contiguous(memory_format=CL)
     assert torch.equal(out.cpu(), ref)
     assert torch.equal(ops.prep_u8(img.to(DEV)).cpu(), (img.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5)
+
+
+def _chan_sums(y):
+    """(sum, sum of squares) per (image, channel) of a bf16 NHWC tensor, in double."""
+    yd = y.double()
+    return yd.sum(dim=(2, 3)), (yd * yd).sum(dim=(2, 3))
+
+
+@pytest.mark.parametrize('case', [
+    # (B, Cin, H, W, Cout, taps, mode): every tile shape of the halo family + the direct-to-LDS variant
+    (2, 64, 16, 16, 64, 9, ops.S1), (3, 128, 8, 8, 128, 9, ops.S1), (33, 64, 64, 64, 64, 9, ops.S1),
+    (16, 128, 32, 32, 128, 9, ops.S1), (96, 64, 64, 64, 64, 9, ops.S1), (3, 64, 64, 64, 64, 9, ops.S2),
+    (2, 64, 8, 8, 64, 9, ops.UP2), (33, 128, 32, 32, 128, 9, ops.UP2), (3, 128, 16, 16, 128, 1, ops.S1),
+    (33, 64, 64, 64, 128, 1, ops.S1), (2, 64, 4, 4, 72, 1, ops.S1), (48, 128, 64, 64, 128, 1, ops.S1),
+    (2, 32, 32, 32, 32, 9, ops.S1),
+])
+def test_conv_epilogue_statistics(case):
+    """st_out of the conv entry points == per-(image, channel) sums of the bf16 output, in T partials."""
+    B, Cin, H, W, Cout, taps, mode = case
+    k = 3 if taps == 9 else 1
+    x = rnd(1, B, Cin, H, W).to(DEV).bfloat16().contiguous(memory_format=CL)
+    w = (rnd(2, Cout, Cin, k, k) / (Cin * taps) ** 0.5).to(DEV)
+    bias = rnd(3, Cout).to(DEV)
+    Ho, Wo = ops.out_hw(mode, H, W)
+    res = rnd(4, B, Cout, Ho, Wo).to(DEV).bfloat16().contiguous(memory_format=CL)
+    wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
+    y0 = ops.conv_raw(x, wf, bias, res, None, None, None, 0, 0.0, mode, taps, 0, Cout)
+    y, st = ops.conv_raw(x, wf, bias, res, None, None, None, 0, 0.0, mode, taps, 0, Cout, want_stats=True)
+    assert st is not None and st.shape == (B, ops.conv_tiles(B, Ho, Wo, Cin, Cout, mode, taps), Cout, 2)
+    assert torch.equal(y, y0)
+    s1, s2 = _chan_sums(y)
+    got = st.double().sum(dim=1)
+    assert float((got[..., 0] - s1).abs().max()) < 2e-3 * (1 + float(s1.abs().max()))
+    assert float((got[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+    # the stand-alone pass gives the same sums
+    st2 = ops.gn_partials_raw(y).double().sum(dim=1)
+    assert float((st2[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+    assert float((st2[..., 0] - s1).abs().max()) < 2e-3 * (1 + float(s1.abs().max()))
+
+
+@pytest.mark.parametrize('case', [
+    # (B, C1, C2, H, Cout, taps, act, film, p_drop, keep)
+    (2, 64, 0, 16, 64, 9, 2, True, 0.0, True), (3, 128, 0, 8, 128, 9, 2, True, 0.1, True),
+    (33, 64, 0, 64, 64, 9, 2, True, 0.1, True), (16, 128, 0, 32, 128, 9, 2, False, 0.0, False),
+    (96, 64, 0, 64, 64, 9, 2, True, 0.1, True),      # direct-to-LDS variant, in-LDS prologue
+    (40, 128, 0, 64, 64, 9, 2, False, 0.0, False),
+    (3, 128, 0, 16, 384, 1, 1, False, 0.0, True),    # AttnBlock: affine prologue + q|k|v 1x1
+    (48, 128, 0, 64, 128, 1, 1, False, 0.0, True),
+    (2, 128, 64, 16, 64, 9, 2, False, 0.0, True), (33, 128, 64, 64, 64, 9, 2, False, 0.0, True),   # 192-channel pairs
+    (4, 128, 128, 32, 128, 9, 2, False, 0.0, True), (2, 256, 256, 8, 256, 9, 2, False, 0.0, False),
+    (2, 64, 0, 32, 3, 9, 2, False, 0.0, True), (2, 32, 0, 32, 1, 9, 2, False, 0.0, False),        # tails (ragged couts)
+    (5, 96, 0, 4, 32, 9, 2, True, 0.0, True),
+])
+def test_groupnorm_prologue_conv_one_launch(case):
+    """idf_conv_gn_bf16 (statistics from the producer, GroupNorm / FiLM / SiLU / dropout applied while the conv
+    stages its tile) against fp32 PyTorch, and against the two-launch path's activated tensor / coefficients."""
+    B, C1, C2, H, Cout, taps, act, film, p_drop, keep = case
+    C, k = C1 + C2, 3 if taps == 9 else 1
+    x1 = (0.5 + 1.5 * rnd(1, B, C1, H, H)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    x2 = (rnd(2, B, C2, H, H) - 0.3).to(DEV).bfloat16().contiguous(memory_format=CL) if C2 else None
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL) if C2 else x1
+    gam, bet = (1 + 0.1 * rnd(3, C)).to(DEV), (0.1 * rnd(4, C)).to(DEV)
+    ft = (0.2 * rnd(5, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    w = (rnd(7, Cout, C, k, k) / (C * taps) ** 0.5).to(DEV)
+    bias = rnd(8, Cout).to(DEV)
+    res = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL) if Cout % 8 == 0 else None
+    wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV) if p_drop else None
+    assert ops.conv_gn_ok(x1, x2, taps, Cout)
+    st1, st2 = ops.gn_partials_raw(x1), (ops.gn_partials_raw(x2) if C2 else None)
+    y, a, mean, rstd, sc, sh, st = ops.conv_gn_raw(x1, x2, st1, st2, gam, bet, ft, fa, seed, 7, p_drop, act, wf, bias, res,
+                                                   Cout, taps, keep_a=keep, keep_coef=keep, want_stats=Cout % 8 == 0)
+    # fp32 reference of the same op (dropout mask exported from the product's counter-based generator)
+    u = F.group_norm(xc.float(), 32, gam, bet, eps=1e-5)
+    if film:
+        u = u * (1 + ft[:, :C, None, None]) + ft[:, C:, None, None]
+        u = u * (1 + fa[:, :C, None, None]) + fa[:, C:, None, None]
+    if act == 2:
+        u = F.silu(u)
+        if p_drop:
+            m = ops.dropout_mask(seed, 7, p_drop, xc.numel()).view(B, H, H, C).permute(0, 3, 1, 2)
+            u = u * m
+    ref = F.conv2d(u, w, bias, padding=k // 2) + (res.float() if res is not None else 0)
+    assert rel(y, ref) < 2e-2, rel(y, ref)
+    if keep:
+        assert rel(a, u) < 1e-2
+        mu = xc.float().reshape(B, 32, -1).mean(dim=2)
+        var = xc.float().reshape(B, 32, -1).var(dim=2, unbiased=False)
+        assert rel(mean, mu) < 1e-5 and rel(rstd, (var + 1e-5).rsqrt()) < 1e-5
+        # coefficients / activated tensor of the stand-alone GroupNorm kernels
+        if ops.gn_small_ok(x1, x2):
+            a0, m0, r0, sc0, sh0 = ops.gn_fused_fwd_raw(x1, gam, bet, ft, fa, seed, 7, p_drop, act, x2=x2)
+            assert rel(sc, sc0) < 1e-5 and rel(sh, sh0) < 1e-5
+            assert float((a.float() - a0.float()).abs().max()) <= 2 ** -7 * float(a0.float().abs().max())   # one bf16 ulp
+    if st is not None:
+        s1, s2 = _chan_sums(y)
+        got = st.double().sum(dim=1)
+        assert float((got[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+    # statistics handed over by a producing conv instead of the stand-alone pass: same result
+    if not C2 and C1 % 32 == 0 and taps == 9 and H >= 4:
+        wp = (rnd(10, C1, C1, 3, 3) / (C1 * 9) ** 0.5).to(DEV)
+        wpf, _ = ops.pack_weight(wp, torch.bfloat16, True, False)
+        xp, stp = ops.conv_raw(x1, wpf, None, None, None, None, None, 0, 0.0, ops.S1, 9, 0, C1, want_stats=True)
+        y1 = ops.conv_gn_raw(xp, None, stp, None, gam, bet, ft, fa, seed, 7, p_drop, act, wf, bias, res, Cout, taps)[0]
+        y2 = ops.conv_gn_raw(xp, None, ops.gn_partials_raw(xp), None, gam, bet, ft, fa, seed, 7, p_drop, act, wf, bias, res,
+                             Cout, taps)[0]
+        assert rel(y1, y2) < 1e-2

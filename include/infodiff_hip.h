@@ -71,9 +71,9 @@ int idf_conv3x3_bf16(const void* x, const void* w, const float* bias, const void
  * the GroupNorm one-launch kernels and the weight-gradient table take the same (x2, C1) pair.  st_out: as above. */
 int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* res, void* y,
                      int B, int H, int W, int Cin, int Cout, float* st_out, void* stream);
-/* Pixel tiles per image (= T of st_out) of the launch idf_conv3x3_bf16 / idf_conv1x1_bf16 / idf_conv_gn_bf16 make
- * for this shape (H, W = output dims; taps 9 or 1); -1 when the shape is not covered. */
-int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps);
+/* Pixel tiles per image (= T of st_out) of the launch idf_conv3x3_bf16 / idf_conv1x1_bf16 (pro = 0) or
+ * idf_conv_gn_bf16 (pro = 1) make for this shape (H, W = output dims; taps 9 or 1); -1 when the shape is not covered. */
+int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps, int pro);
 
 /* The conv / GroupNorm-SiLU / AdaGN fused block (modules.py:264-288 block1..3, 309-320 AuxResBlock.forward,
  * 145-150 AttnBlock GroupNorm + q/k/v, models.py:280-284 tail):

@@ -48,6 +48,14 @@ struct C3P {
   float dscale;
   bf16_t* a_out;        // training: the activated tensor [B, H, W, Cin] (dense), kept for the weight gradient
   float* mean_out; float* rstd_out; float* sc_out; float* sh_out;   // training: saved for the GroupNorm backward
+  // ---- persistent wave-specialised form (conv_ps_bf16): a pixel tile = NI images x R rows x W columns = 256 pixels
+  int ps_NI, ps_rwshift;        // images per tile, log2(R * W)
+  int ps_npi;                   // halo pixels per image, (R + 2 halo)(W + 2 halo)
+  unsigned ps_magic_img;        // (pix * magic) >> 16 == pix / ps_npi over the tile's halo pixels
+  int ps_nptiles, ps_work;      // pixel tiles, work items (= pixel tiles x cout tiles)
+  int ps_hbytes;                // bytes of one halo ring slot (whole 1-KB groups)
+  int ps_dbg;                   // timing-only ablations (IDF_CONV_PS_DBG; results are wrong when set): 1 no halo loads
+                                // after a block's first stage, 2 no MFMAs, 4 no epilogue stores, 8 no prologue arithmetic
 };
 
 constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 = 1536;   // (R+2)*(W+2)*4 budget per block size
@@ -403,6 +411,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 // fits 128 VGPRs, TWO 512-thread blocks share a CU, and one block's MFMA phase covers the other's load
 // latency (a block itself does not prefetch: its single LDS image is in use until the chunk's last read).
 __device__ uint4 g_zero16;      // zero page: out-of-image halo pixels and padding rows load from here
+__device__ uint4 g_trash[16];   // where the persistent kernel's epilogue sends the stores of out-of-range elements (branch-free)
 
 // PRO: the GroupNorm prologue as an in-LDS pass -- once the chunk has landed every thread reads its own vectors
 // back, applies act(x * sc + sh) and writes them in place (one more barrier per chunk); with two blocks per CU the
@@ -555,6 +564,516 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
 }
 
+// ---------------------------------------------------------------- persistent, wave-specialised form
+// One 512-thread workgroup per CU walks a contiguous range of (pixel tile, cout tile) work items; a pixel tile is
+// 256 output pixels (NI images x R rows x W columns) x 64 couts.  The (tile, 32-channel chunk) pairs form one
+// stream of STAGES that flows through two LDS rings, and the eight waves split into two roles:
+//   waves 0-3, CONSUMERS (one per SIMD): all MFMAs.  Each owns 64 pixels x 64 couts (16 accumulator tiles) and per
+//     stage runs 9 taps x 16 MFMAs from the stage's halo slot and weight slot (8 ds_read_b128 per 16 MFMAs).
+//   waves 4-7, PRODUCERS (one per SIMD): all data movement and all GroupNorm arithmetic.  Per period each issues
+//     the LDS-DMA loads (global_load_lds_dwordx4) of the halo chunk two stages ahead and of the weight chunk one
+//     stage ahead, then -- PRO -- applies  dropout(SiLU(x * sc + sh))  in place to the halo chunk one stage ahead,
+//     reading back exactly the 16-byte slots its own loads filled (so its own counted vmcnt is the only wait).
+// A SIMD thus runs a matrix stream and a vector stream side by side; the loads of a stage are in flight for a whole
+// period before anyone waits for them, across tile boundaries (the stream does not drain between tiles), and ONE
+// raw s_barrier per period hands slots over:  halo ring 3 deep (being consumed / being transformed / landing),
+// weight ring 2 deep.  The epilogue runs in the consumers' registers (bias, residual, bf16 rounding, statistics of
+// the output for the next GroupNorm) and overlaps the producers' work on the next tile.
+constexpr int PS_HG_MAX = 7;     // halo groups per producer wave (25 groups of 16 pixels -> 7, 6, 6, 6)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt(int n) {     // n wave-uniform, 0..16
+  switch (n) {
+    case 0: wait_vmcnt_n<0>(); break;   case 1: wait_vmcnt_n<1>(); break;   case 2: wait_vmcnt_n<2>(); break;
+    case 3: wait_vmcnt_n<3>(); break;   case 4: wait_vmcnt_n<4>(); break;   case 5: wait_vmcnt_n<5>(); break;
+    case 6: wait_vmcnt_n<6>(); break;   case 7: wait_vmcnt_n<7>(); break;   case 8: wait_vmcnt_n<8>(); break;
+    case 9: wait_vmcnt_n<9>(); break;   case 10: wait_vmcnt_n<10>(); break; case 11: wait_vmcnt_n<11>(); break;
+    case 12: wait_vmcnt_n<12>(); break; case 13: wait_vmcnt_n<13>(); break; case 14: wait_vmcnt_n<14>(); break;
+    case 15: wait_vmcnt_n<15>(); break; default: wait_vmcnt_n<16>(); break;
+  }
+}
+__device__ __forceinline__ void ps_barrier() {
+  // this wave's LDS operations are done; LDS-DMA loads and the epilogue's global stores stay in flight across the
+  // barrier (the builtin barrier would make hipcc drain vmcnt(0) first)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// LDS accesses the compiler must not see: beside LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) in front of every
+// LDS read it knows of (it cannot tell which slot a pending global_load_lds writes), which would drain the producers'
+// load-ahead every period.  The producers wait for exactly the loads that fill the slot they touch (wait_vmcnt) and
+// for their own LDS operations here / in ps_barrier.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+template <int N>
+__device__ __forceinline__ void lds_read16xN(u32x4_t (&v)[N], const unsigned (&addr)[N]) {
+  static_assert(N == 4 || N == PS_HG_MAX, "instantiated sizes");
+  if constexpr (N == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]) : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %8\n\tds_read_b128 %2, %9\n\tds_read_b128 %3, %10\n\t"
+                 "ds_read_b128 %4, %11\n\tds_read_b128 %5, %12\n\tds_read_b128 %6, %13\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]) : "memory");
+}
+__device__ __forceinline__ void lds_write16(unsigned addr, const u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");     // retired by ps_barrier's lgkmcnt(0)
+}
+__device__ __forceinline__ float2 lds_read8(unsigned addr) {
+  float2 v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// per-wave fold of the GroupNorm statistics into cof[c] = (sc, sh) for image b (pro_coefficients without
+// workgroup barriers: every producer wave computes all channels and stores the same values)
+__device__ __forceinline__ void ps_coefficients(const C3P& p, int b, bool writer, float* cof, float* chs, int lane) {
+  const int C = p.Cin, cpg = C >> 5;
+  for (int c = lane; c < C; c += 64) {
+    const float* st = p.st1;
+    int T = p.T1, Cs = p.C1, cl = c;
+    if (c >= p.C1) { st = p.st2; T = p.T2; Cs = C - p.C1; cl = c - p.C1; }
+    const float2* src = reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    int t = 0;
+    for (; t + 2 <= T; t += 2) {
+      float2 v0 = src[(size_t)t * Cs], v1 = src[(size_t)(t + 1) * Cs];
+      s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
+    }
+    if (t < T) { float2 v = src[(size_t)t * Cs]; s0 += v.x; q0 += v.y; }
+    chs[2 * c] = s0 + s1; chs[2 * c + 1] = q0 + q1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its own LDS writes are visible to its lanes
+  const double n = (double)p.H * p.W * cpg;
+  for (int c = lane; c < C; c += 64) {
+    const int g = c / cpg;
+    double a = 0.0, d = 0.0;
+    for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
+    double mu = a / n, var = d / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    float sc = r * ga, sh = be - mf * sc;
+    if (p.film_t) { float f = 1.f + p.film_t[(size_t)b * p.ld_t + c]; sc *= f; sh = sh * f + p.film_t[(size_t)b * p.ld_t + C + c]; }
+    if (p.film_a) { float f = 1.f + p.film_a[(size_t)b * p.ld_a + c]; sc *= f; sh = sh * f + p.film_a[(size_t)b * p.ld_a + C + c]; }
+    cof[2 * c] = sc; cof[2 * c + 1] = sh;
+    if (writer && p.sc_out) {
+      p.sc_out[(size_t)b * C + c] = sc; p.sh_out[(size_t)b * C + c] = sh;
+      if (c == g * cpg) { p.mean_out[b * 32 + g] = mf; p.rstd_out[b * 32 + g] = r; }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// position of a stream in the block's work-item range, decoded incrementally (no divisions in the period loop)
+struct PsPos {
+  int wi, nt, rt, b0, ck;       // work item, cout tile, row tile inside the image, first image, chunk
+  __device__ __forceinline__ void init(const C3P& p, int w) {
+    wi = w; ck = 0;
+    const int pt = w / p.n_tiles;
+    nt = w - pt * p.n_tiles;
+    if (p.ps_NI > 1) { b0 = pt * p.ps_NI; rt = 0; }
+    else { b0 = pt / p.tiles_per_img; rt = pt - b0 * p.tiles_per_img; }
+  }
+  __device__ __forceinline__ void next_item(const C3P& p) {
+    ++wi;
+    if (++nt == p.n_tiles) {
+      nt = 0;
+      if (p.ps_NI > 1) b0 += p.ps_NI;
+      else if (++rt == p.tiles_per_img) { rt = 0; ++b0; }
+    }
+  }
+  __device__ __forceinline__ bool next_chunk(const C3P& p, int nchunks) {     // true when a new work item starts
+    if (++ck == nchunks) { ck = 0; next_item(p); return true; }
+    return false;
+  }
+};
+
+template <int KS, bool DUAL, bool PRO, bool RES>
+__global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
+  constexpr int TAPS = KS * KS, HALO = KS / 2, BN = 64;
+  constexpr int WSZ = TAPS * BN * 64;                     // bytes of a weight ring slot
+  constexpr int WG = TAPS * BN / 16 / 4;                  // weight groups per producer wave (9 / 1)
+  constexpr int SROW = 144;                               // epilogue staging: bytes per pixel row (128 + pad, 16-byte aligned)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int HSZ = p.ps_hbytes;
+  unsigned char* const Hring = smem;                      // [3][HSZ]
+  unsigned char* const Wring = smem + 3 * HSZ;            // [2][WSZ]
+  float* const aux = reinterpret_cast<float*>(smem + p.aux_off);   // PRO: cof [Cin][2] | chs [Cin][2]
+  float* const stw = aux + (PRO ? 4 * p.Cin : 0);         // statistics [4 waves][64 couts][2]; then staging [4][16][SROW]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = p.W, R = p.R, WH = W + 2 * HALO;
+  const int npix_h = p.ps_NI * p.ps_npi, hgroups = (npix_h + 15) >> 4;
+  const int nchunks = p.Cin / CK;
+  // this block's contiguous range of work items (pixel tile major, cout tile minor).
+  // Blocks b and b + 8 share an XCD (observed round-robin placement; speed only): give each XCD one contiguous
+  // stretch of the work so neighbouring tiles' halo rows and a pixel tile's cout tiles meet in one L2
+  const int G = gridDim.x;
+  const int bid = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+  const int w0 = (int)(((long)bid * p.ps_work) / G), w1 = (int)(((long)(bid + 1) * p.ps_work) / G);
+  const int S = (w1 - w0) * nchunks;                      // stages of this block
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+
+  if (wave < 4) {
+    // =============================================================== consumers
+    const int fr = lane & 15, fq = lane >> 4;
+    int wbase[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int n = a * 16 + fr;
+      wbase[a] = n * 64 + swz(n, fq) * 16;
+    }
+    int hbase[4];                   // halo row of tap (0,0) of this lane's pixel in each 16-pixel slice
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pl = wave * 64 + i * 16 + fr;
+      const int img = pl >> p.ps_rwshift, rem = pl & ((1 << p.ps_rwshift) - 1);
+      hbase[i] = img * p.ps_npi + (rem >> p.wshift) * WH + (rem & (W - 1));
+    }
+    // row view of a 16-pixel slice (epilogue): lane -> pixel row (lane >> 2), 32 bytes = couts (lane & 3) * 16 .. + 15
+    const int rrow = lane >> 2, rcol = (lane & 3) * 16;
+    int rpix[4], rimg[4];           // that pixel's offset inside the tile's first image, and its image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pl = wave * 64 + i * 16 + rrow;
+      const int rem = pl & ((1 << p.ps_rwshift) - 1);
+      rimg[i] = pl >> p.ps_rwshift;
+      rpix[i] = (rimg[i] * p.H + (rem >> p.wshift)) * W + (rem & (W - 1));
+    }
+    unsigned char* const stg = reinterpret_cast<unsigned char*>(stw + 512) + wave * (16 * SROW);
+    float* const swv = stw + wave * 128;                    // this wave's statistics [64 couts][2]
+    const bool wants = p.st_out != nullptr && !(p.ps_dbg & 16);
+
+    PsPos pos;
+    pos.init(p, w0);
+    // the accumulators start from the bias: no add in the epilogue
+    auto bias4 = [&](int n0, int a) {
+      const int n = n0 + a * 16 + fq * 4;                   // Cout % 8 == 0: the 4 couts are inside or outside together
+      const float4 v = *reinterpret_cast<const float4*>((p.bias && n < p.Cout) ? p.bias + n : reinterpret_cast<const float*>(&g_zero16));
+      return f32x4_t{v.x, v.y, v.z, v.w};
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const f32x4_t bv = bias4(pos.nt * BN, a);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[a][i] = bv;
+    }
+
+    ps_barrier();                                          // period -2
+    ps_barrier();                                          // period -1
+    int hs = 0;                                            // halo ring slot of the current stage (s % 3)
+    for (int s = 0; s < S; ++s) {
+      const unsigned char* Xs = Hring + hs * HSZ;
+      const unsigned char* Ws = Wring + (s & 1) * WSZ;
+      hs = hs == 2 ? 0 : hs + 1;
+      if (!(p.ps_dbg & 2))
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int toff = (tap / KS) * WH + (tap % KS);
+        bf16x8_t wf[4], xf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Ws + tap * BN * 64 + wbase[a]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int h = hbase[i] + toff;
+          xf[i] = *reinterpret_cast<const bf16x8_t*>(Xs + h * 64 + swz(h, fq) * 16);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
+      }
+      if (pos.ck + 1 == nchunks && !(p.ps_dbg & 32)) {
+        // ------------------------------------------------ epilogue of work item pos.wi
+        // A lane holds 4 couts of a pixel (8 bytes): stored as they stand, 32-byte pieces land in 16 different
+        // lines per instruction and the memory side crawls (5.7 us per tile measured).  Each wave therefore passes
+        // its 16-pixel x 64-cout slices through a private 16 x 144-byte LDS image and stores whole 128-byte pixel
+        // rows, 16 bytes per lane; a residual takes the same road in the other direction first.  Wave-private:
+        // no barrier, and plain LDS operations (the consumers have no LDS-DMA in flight).
+        const int n0 = pos.nt * BN, oy0 = p.ps_NI > 1 ? 0 : pos.rt * R, b0 = pos.b0;
+        const bool colok = n0 + rcol < p.Cout;
+        size_t erow[4];
+        bool rowok[4];
+        u32x4_t rres0[4], rres1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rowok[i] = (b0 + rimg[i]) < p.B && colok && !(p.ps_dbg & 4);
+          erow[i] = ((size_t)(b0 * p.H + oy0) * W + rpix[i]) * p.Cout + n0 + rcol;
+          if constexpr (RES) {                              // residual rows of all four slices first: one round trip
+            const bf16_t* rp = rowok[i] ? p.res + erow[i] : zero;
+            rres0[i] = *reinterpret_cast<const u32x4_t*>(rp);
+            rres1[i] = *reinterpret_cast<const u32x4_t*>(rowok[i] ? rp + 8 : zero);
+          }
+        }
+        f32x4_t ssum[4], ssq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ssum[a] = ssq[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint2 rr[4];
+          if constexpr (RES) {                              // residual rows -> MFMA layout
+            *reinterpret_cast<u32x4_t*>(stg + rrow * SROW + rcol * 2) = rres0[i];
+            *reinterpret_cast<u32x4_t*>(stg + rrow * SROW + rcol * 2 + 16) = rres1[i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) rr[a] = *reinterpret_cast<const uint2*>(stg + fr * SROW + (a * 16 + fq * 4) * 2);
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            f32x4_t o = acc[a][i];
+            if constexpr (RES) {
+              o[0] += __uint_as_float(rr[a].x << 16); o[1] += __uint_as_float(rr[a].x & 0xffff0000u);
+              o[2] += __uint_as_float(rr[a].y << 16); o[3] += __uint_as_float(rr[a].y & 0xffff0000u);
+            }
+            const uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+            const uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(stg + fr * SROW + (a * 16 + fq * 4) * 2) = make_uint2(lo, hi);
+            if (wants) {                                    // wave-uniform: statistics of the rounded values
+              const f32x4_t rv = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
+                                  __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+              ssum[a] += rv;
+              ssq[a] += rv * rv;
+            }
+          }
+          const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(stg + rrow * SROW + rcol * 2);
+          const u32x4_t v1 = *reinterpret_cast<const u32x4_t*>(stg + rrow * SROW + rcol * 2 + 16);
+          // hidden from hipcc's vmcnt bookkeeping (a counted store makes it drain vmcnt(0) before the next tile's
+          // first LDS read); out-of-range rows go to a trash line
+          const void* dst = rowok[i] ? (const void*)(p.y + erow[i]) : (const void*)&g_trash[(lane & 3) * 4];
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1"
+                       ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+        }
+        if (wants) {
+          // per-cout sums over this wave's 64 pixels (16 lanes of a DPP row hold the same couts) -> swv[cout][2];
+          // a producer wave folds the four waves (fixed order) and stores the tile's partial one period later.
+          // (LDS float adds from the 16 lanes instead: 14 us per tile -- same-address LDS atomics serialise badly.
+          // Out-of-range pixels carry the bias: the host asks for statistics only when B is a multiple of the
+          // images per tile.)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sv = row16_sum(ssum[a][r]), qv = row16_sum(ssq[a][r]);
+              if (fr == 0) {
+                swv[(a * 16 + fq * 4 + r) * 2] = sv;
+                swv[(a * 16 + fq * 4 + r) * 2 + 1] = qv;
+              }
+            }
+        }
+        PsPos nx = pos;
+        nx.next_item(p);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const f32x4_t bv = bias4(nx.nt * BN, a);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[a][i] = bv;
+        }
+      }
+      pos.next_chunk(p, nchunks);
+      ps_barrier();
+    }
+    ps_barrier();                                          // drain period (statistics of the last tile)
+    return;
+  }
+
+  // ================================================================= producers
+  const int pw = wave - 4;                                 // producer wave 0..3: halo groups pw, pw+4, ..; weight groups likewise
+  const int prow = lane >> 2;
+  const int chs_ = (lane & 3) ^ (((lane >> 4) & 1) << 1);  // logical 8-channel slot this lane's 16 bytes hold (swz inverse)
+  const int nhg = (hgroups - pw + 3) >> 2;                 // halo groups of this wave (wave-uniform)
+  int woff[WG];                                            // weight element offsets relative to cout tile 0, chunk 0
+  bool wnok[WG];
+#pragma unroll
+  for (int k = 0; k < WG; ++k) {
+    const int r = (pw + 4 * k) * 16 + prow, tap = r / BN, n = r - tap * BN;
+    woff[k] = (n * TAPS + tap) * p.Cin + chs_ * 8;
+    wnok[k] = true;
+  }
+  int poffL[PS_HG_MAX], poffT[PS_HG_MAX];                  // global pixel index of this lane's halo pixel per group (-1: zero page)
+  unsigned amL = 0, amT = 0;                               // groups whose pixel belongs to the tile itself (a_out)
+#pragma unroll
+  for (int k = 0; k < PS_HG_MAX; ++k) poffL[k] = poffT[k] = -1;
+  int bT = -1;                                             // image the coefficients in LDS belong to
+  float scv[8], shv[8];
+  uint64_t seedv = 0;
+  bool drop = false;
+  if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
+
+  auto plan = [&](const PsPos& q) {    // poffL / amL for the work item at q
+    const int oy0 = p.ps_NI > 1 ? 0 : q.rt * R;
+    amL = 0;
+#pragma unroll
+    for (int k = 0; k < PS_HG_MAX; ++k) {
+      poffL[k] = -1;
+      const int pix = (pw + 4 * k) * 16 + prow;
+      if (k < nhg && pix < npix_h) {
+        const int img = (int)(((unsigned)pix * p.ps_magic_img) >> 16), qq = pix - img * p.ps_npi;
+        const int hy = (int)(((unsigned)qq * p.wh_magic) >> 16), hx = qq - hy * WH;
+        const int iy = oy0 + hy - HALO, ix = hx - HALO, b = q.b0 + img;
+        if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {
+          poffL[k] = (b * p.H + iy) * W + ix;
+          if (PRO && p.a_out && q.nt == 0 && (unsigned)(hy - HALO) < (unsigned)R && (unsigned)(hx - HALO) < (unsigned)W) amL |= 1u << k;
+        }
+      }
+    }
+  };
+  auto issue_halo = [&](int slot_i, int c0) {
+    const bf16_t* src = p.x;
+    int pitch = p.Cin, cc = c0;
+    if (DUAL) { if (c0 < p.C1) pitch = p.C1; else { src = p.x2; pitch = p.Cin - p.C1; cc = c0 - p.C1; } }
+    unsigned char* slot = Hring + slot_i * HSZ;
+#pragma unroll
+    for (int k = 0; k < PS_HG_MAX; ++k)
+      if (k < nhg) {
+        const bf16_t* g = poffL[k] >= 0 ? src + (size_t)((unsigned)poffL[k] * (unsigned)pitch + (unsigned)(cc + chs_ * 8)) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(slot + (pw + 4 * k) * 1024), 16, 0, 0);
+      }
+  };
+  auto issue_weights = [&](int slot_i, int n0, int c0) {
+    unsigned char* slot = Wring + slot_i * WSZ;
+#pragma unroll
+    for (int k = 0; k < WG; ++k) {
+      const int n = ((pw + 4 * k) * 16 + prow) % BN;
+      const bf16_t* g = (n0 + n < p.Cout) ? p.w + (size_t)((unsigned)woff[k] + (unsigned)(n0 * TAPS * p.Cin + c0)) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(slot + (pw + 4 * k) * 1024), 16, 0, 0);
+    }
+  };
+  auto transform = [&](int slot_i, int c0) {               // PRO: in-place activation of a halo chunk
+    const unsigned slot = lds_addr(Hring + slot_i * HSZ) + (unsigned)(pw * 1024 + lane * 16);
+    const int cb = c0 + chs_ * 8;
+    {
+      u32x4_t cv[4];
+      const unsigned ca = lds_addr(aux + 2 * cb);
+      const unsigned cad[4] = {ca, ca + 16, ca + 32, ca + 48};
+      lds_read16xN<4>(cv, cad);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        scv[2 * q] = __uint_as_float(cv[q][0]); shv[2 * q] = __uint_as_float(cv[q][1]);
+        scv[2 * q + 1] = __uint_as_float(cv[q][2]); shv[2 * q + 1] = __uint_as_float(cv[q][3]);
+      }
+    }
+    u32x4_t hv[PS_HG_MAX];
+    unsigned had[PS_HG_MAX];
+#pragma unroll
+    for (int k = 0; k < PS_HG_MAX; ++k) had[k] = slot + (unsigned)(k < nhg ? 4 * k * 1024 : 0);   // idle groups re-read group 0
+    lds_read16xN<PS_HG_MAX>(hv, had);
+#pragma unroll
+    for (int k = 0; k < PS_HG_MAX; ++k)
+      if (k < nhg && poffT[k] >= 0) {                      // padding pixels stay zero
+        const unsigned e0 = (unsigned)poffT[k] * (unsigned)p.Cin + (unsigned)cb;
+        const uint4 o = pro_vec(make_uint4(hv[k][0], hv[k][1], hv[k][2], hv[k][3]), scv, shv, p.act, drop, seedv, p.salt,
+                                p.thr, p.dscale, e0 >> 3);
+        lds_write16(had[k], u32x4_t{o.x, o.y, o.z, o.w});
+        if ((amT >> k) & 1u) *reinterpret_cast<uint4*>(p.a_out + e0) = o;
+      }
+  };
+  auto flush_stats = [&](const PsPos& q) {                 // the four consumer waves' sums of the work item at q -> st_out
+    if (pw != 0) return;
+    const int c = lane, n0 = q.nt * BN;
+    const unsigned sb = lds_addr(stw) + (unsigned)c * 8;
+    float2 v[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v[w] = lds_read8(sb + (unsigned)w * 512);
+    if (n0 + c >= p.Cout) return;
+    if (p.ps_NI == 1) {                                    // one tile of one image: fold the waves in a fixed order
+      const float a = ((v[0].x + v[1].x) + v[2].x) + v[3].x, qq = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
+      reinterpret_cast<float2*>(p.st_out)[((size_t)q.b0 * p.tiles_per_img + q.rt) * p.Cout + n0 + c] = make_float2(a, qq);
+    } else {                                               // four 64-pixel images per tile: wave w = image b0 + w
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (q.b0 + w < p.B) reinterpret_cast<float2*>(p.st_out)[(size_t)(q.b0 + w) * p.Cout + n0 + c] = v[w];
+    }
+  };
+
+  // stage s of the stream: work item w0 + s / nchunks, chunk s % nchunks
+  // period -2: halo(0).   period -1: weights(0), halo(1); transform halo(0).
+  // period t >= 0: weights(t+1), halo(t+2); transform halo(t+1); [statistics of the tile that ended at stage t-1]
+  PsPos pL, pT, pW, pC;             // load / transform / weight stream positions; pC follows the consumers
+  pL.init(p, w0); pT = pL; pW = pL; pC = pL;
+  int sL = 0, sT = 0, sW = 0;
+  int hL = 0, hT = 0;               // halo ring slots of the next load / transform stage
+  bool stat_pending = false;
+  PsPos stat_pos = pL;
+  int wkey[2] = {-1, -1};           // what each weight ring slot holds
+  for (int t = -2; t < S + 1; ++t) {
+    int nissued = 0;
+    // the transform stream enters a tile one period after the load stream planned it: take the plan over BEFORE the
+    // load stream moves on (with one chunk per tile it plans the next tile in this very period)
+    if (t >= -1 && sT < S && pT.ck == 0) {
+#pragma unroll
+      for (int k = 0; k < PS_HG_MAX; ++k) poffT[k] = poffL[k];
+      amT = amL;
+    }
+    // ---- weights one stage ahead (oldest of this period's loads: the end-of-period wait retires them first).
+    // With at most two chunks the ring holds the whole cout tile's weights: they are fetched once per cout tile
+    // and stay for every pixel tile the block walks.
+    if (t >= -1 && sW < S) {
+      const int key = pW.nt * 64 + pW.ck;                  // (cout tile, chunk) the slot would hold
+      if (wkey[sW & 1] != key) {
+        issue_weights(sW & 1, pW.nt * BN, pW.ck * CK);
+        nissued += WG;
+        wkey[sW & 1] = key;
+      }
+      ++sW;
+      pW.next_chunk(p, nchunks);
+    }
+    // ---- halo two stages ahead
+    int nh_now = 0;
+    if (sL < S) {
+      if (pL.ck == 0) plan(pL);
+      if (!(p.ps_dbg & 1) || sL == 0) {
+        issue_halo(hL, pL.ck * CK);
+        nh_now = nhg;
+        nissued += nhg;
+      }
+      hL = hL == 2 ? 0 : hL + 1;
+      ++sL;
+      pL.next_chunk(p, nchunks);
+    }
+    // ---- statistics of the tile whose last stage the consumers finished in the previous period
+    if (stat_pending) { if (p.st_out) flush_stats(stat_pos); stat_pending = false; }
+    // ---- transform the stage that is consumed next period
+    if (t >= -1 && sT < S) {
+      if (PRO) {
+        if (pT.ck == 0 && pT.b0 != bT) {
+          ps_coefficients(p, pT.b0, pw == 0 && pT.rt == 0 && pT.nt == 0, aux, aux + 2 * p.Cin, lane);
+          bT = pT.b0;
+        }
+        wait_vmcnt(nissued);                               // everything older than this period's loads has landed
+        if (!(p.ps_dbg & 8)) transform(hT, pT.ck * CK);
+      }
+      hT = hT == 2 ? 0 : hT + 1;
+      ++sT;
+      pT.next_chunk(p, nchunks);
+    }
+    // the consumers finish stage t in this period: if it closes a tile, its statistics are ready next period
+    if (t >= 0 && t < S) {
+      if (pC.ck + 1 == nchunks) { stat_pending = true; stat_pos = pC; }
+      pC.next_chunk(p, nchunks);
+    }
+    // ---- the weights of stage t+1 (and, without PRO, its halo chunk issued last period) must have landed
+    wait_vmcnt(nh_now);
+    ps_barrier();
+  }
+}
+
+
 // magic multiplier for the division by the halo-row width; 0 when not exact over [0, npix)
 inline unsigned wh_magic(int WH, int npix) {
   unsigned m = 65536u / (unsigned)WH + 1u;
@@ -601,6 +1120,72 @@ void clear_pro(C3P& p) {
   p.gamma = p.beta = p.film_t = p.film_a = nullptr; p.ld_t = p.ld_a = 0; p.eps = 0.f;
   p.act = 0; p.seed = nullptr; p.salt = 0; p.thr = 0; p.dscale = 1.f;
   p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr;
+  p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
+  static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
+  p.ps_dbg = dbg;
+}
+
+// ---- persistent form: geometry and the decision to use it
+const int g_ps = getenv("IDF_CONV_PS") ? atoi(getenv("IDF_CONV_PS")) : 1;
+const int g_ps_min = getenv("IDF_CONV_PS_MIN") ? atoi(getenv("IDF_CONV_PS_MIN")) : 256;   // work items (one per CU) below which the small-tile kernels spread better
+// The GroupNorm prologue in this form runs on the four producer waves alone -- one wave per SIMD issues a vector
+// instruction every 4 cycles at best, beside a consumer wave whose MFMAs hold half the issue slots -- and is
+// 2.5-3.6 us per stage against 1 us of MFMAs: measured equal to or slower than the two-blocks-per-CU kernels
+// (64->64 @64^2: 38.7 vs 30.4 us at B = 32, 190 vs 196 us at B = 256).  Off unless asked for.
+const int g_ps_pro = getenv("IDF_CONV_PS_PRO") ? atoi(getenv("IDF_CONV_PS_PRO")) : 0;
+
+struct PsPlan { int R, NI, rwshift, npi, hgroups, nptiles, work, T; unsigned magic_img, magic_row; size_t lds; int aux_off; };
+
+// stride-1 3x3 / 1x1 (mode 0) only.  pro: GroupNorm prologue; want_st: statistics epilogue
+bool ps_plan(int B, int H, int W, int Cin, int Cout, int KS, bool pro, bool want_st, PsPlan* o) {
+  if (!g_ps || (Cout & 7) || (Cin % CK) || W < 8 || W > 64 || (W & (W - 1)) || (H & (H - 1)) || H < 1) return false;
+  if ((KS == 3 && !(g_ps & 1)) || (KS == 1 && !(g_ps & 2)) || (pro && !g_ps_pro)) return false;
+  const int HW = H * W, halo = KS / 2;
+  int R, NI;
+  if (HW >= 256) { R = 256 / W; NI = 1; if (R < 1 || H % R) return false; }
+  else { if (256 % HW) return false; NI = 256 / HW; R = H; }
+  if (NI > 1 && (pro || (want_st && !(NI == 4 && HW == 64)))) return false;
+  int rw = 0;
+  while ((1 << rw) < R * W) ++rw;
+  const int WH = W + 2 * halo, npi = (R + 2 * halo) * WH, npix = NI * npi, hg = (npix + 15) / 16;
+  if (hg > 4 * PS_HG_MAX) return false;
+  const size_t aux = (pro ? (size_t)Cin * 16 : 0) + 2048 + 4 * 16 * 144;      // coefficients, statistics, epilogue staging
+  if (want_st && Cin == CK) return false;                  // one chunk per tile: the single statistics buffer would be rewritten too early
+  const size_t main_ = (size_t)3 * hg * 1024 + (size_t)2 * KS * KS * 64 * 64;
+  if (main_ + aux > 160 * 1024) return false;
+  const int n_tiles = idf_cdiv(Cout, 64);
+  const int nptiles = NI > 1 ? idf_cdiv(B, NI) : B * (HW / 256);
+  if ((long)nptiles * n_tiles < g_ps_min) return false;
+  const unsigned mi = NI > 1 ? wh_magic(npi, npix) : 1u, mr = wh_magic(WH, npi);     // one image: (pix * 1) >> 16 == 0
+  if (!mi || !mr) return false;
+  o->R = R; o->NI = NI; o->rwshift = rw; o->npi = npi; o->hgroups = hg; o->nptiles = nptiles; o->work = nptiles * n_tiles;
+  o->T = NI > 1 ? 1 : HW / 256; o->magic_img = mi; o->magic_row = mr; o->lds = main_ + aux; o->aux_off = (int)main_;
+  return true;
+}
+
+template <int KS, bool DUAL, bool PRO, bool RES>
+void launch_ps_r(C3P& p, const PsPlan& pl, int G, hipStream_t st) {
+  auto kern = conv_ps_bf16<KS, DUAL, PRO, RES>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), pl.lds, st, p);
+}
+
+template <int KS, bool DUAL, bool PRO>
+void launch_ps(C3P& p, const PsPlan& pl, hipStream_t st) {
+  p.R = pl.R; p.tiles_per_img = pl.T; p.n_tiles = idf_cdiv(p.Cout, 64); p.wh_magic = pl.magic_row;
+  p.ps_NI = pl.NI; p.ps_rwshift = pl.rwshift; p.ps_npi = pl.npi; p.ps_magic_img = pl.magic_img;
+  p.ps_nptiles = pl.nptiles; p.ps_work = pl.work; p.ps_hbytes = pl.hgroups * 1024; p.aux_off = pl.aux_off;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ncu = 256;
+    else ncu = prop.multiProcessorCount;
+  }
+  const int per = idf_cdiv(pl.work, ncu);                  // work items per block, then an even spread
+  const int G = idf_cdiv(pl.work, per);
+  if (p.res) launch_ps_r<KS, DUAL, PRO, true>(p, pl, G, st);
+  else launch_ps_r<KS, DUAL, PRO, false>(p, pl, G, st);
 }
 
 // pixel tile of a 3x3 launch: BM pixels = R rows x W columns; false when the halo tile does not fit
@@ -651,11 +1236,13 @@ bool shape1_ok(int W, int Cin, int Cout) {
 
 const int g_dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
 const long g_dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
-const long g_dlds_min_pro = getenv("IDF_CONV_DLDS_MIN_PRO") ? atol(getenv("IDF_CONV_DLDS_MIN_PRO")) : 1536;
+const long g_dlds_min_pro = getenv("IDF_CONV_DLDS_MIN_PRO") ? atol(getenv("IDF_CONV_DLDS_MIN_PRO")) : 512;
 
 // dispatch of a 3x3 launch whose C3P is filled in (PRO / DUAL only for mode 0)
 template <bool DUAL, bool PRO>
 void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
+  PsPlan pl;
+  if (mode == 0 && ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 3, PRO, p.st_out != nullptr, &pl)) { launch_ps<3, DUAL, PRO>(p, pl, st); return; }
   const bool bn32 = p.Cout <= 32;
   p.n_tiles = idf_cdiv(p.Cout, bn32 ? 32 : 64);
 #define IDF_C3_LAUNCH(MODE)                                              \
@@ -678,6 +1265,8 @@ void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
 
 template <bool DUAL, bool PRO>
 void dispatch1(C3P& p, int BM, hipStream_t st) {
+  PsPlan pl;
+  if (ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 1, PRO, p.st_out != nullptr, &pl)) { launch_ps<1, DUAL, PRO>(p, pl, st); return; }
   p.n_tiles = idf_cdiv(p.Cout, 64);
   const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
   if (!DUAL && BM == 256 && (g_dlds & 2) && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min)) launch_dlds<1, PRO>(p, st);
@@ -755,13 +1344,19 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
 }
 
 // Pixel tiles per image of the launch the entry points above / below make for this shape = the T of the
-// statistics partials st_out [B][T][Cout][2] they write; -1 when the shape is not covered.
-extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps) {
+// statistics partials st_out [B][T][Cout][2] they write; -1 when the shape is not covered.  pro != 0: the launch is
+// idf_conv_gn_bf16 (the choice of kernel, hence T, can depend on it).
+extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps, int pro) {
   int BM, R;
+  PsPlan pl;
   if (taps == 9) {
-    if (!shape3_ok(H, W, Cin, Cout, mode) || !plan3(B, H, W, Cout, mode, &BM, &R)) return -1;
+    if (!shape3_ok(H, W, Cin, Cout, mode)) return -1;
+    if (mode == 0 && ps_plan(B, H, W, Cin, Cout, 3, pro != 0, true, &pl)) return pl.T;
+    if (!plan3(B, H, W, Cout, mode, &BM, &R)) return -1;
   } else {
-    if (mode != 0 || !shape1_ok(W, Cin, Cout) || !plan1(B, H, W, Cout, &BM, &R)) return -1;
+    if (mode != 0 || !shape1_ok(W, Cin, Cout)) return -1;
+    if (ps_plan(B, H, W, Cin, Cout, 1, pro != 0, true, &pl)) return pl.T;
+    if (!plan1(B, H, W, Cout, &BM, &R)) return -1;
   }
   return H / R;
 }

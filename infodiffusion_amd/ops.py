@@ -122,16 +122,17 @@ _CONV1X1 = os.environ.get('IDF_CONV1X1', '1') != '0'
 
 
 @functools.lru_cache(maxsize=None)
-def conv_tiles(B, H, W, Cin, Cout, mode, taps):
-    """Pixel tiles per image of the halo-kernel launch for this shape (-1: not covered) = T of its statistics."""
-    return int(_lib.load().idf_conv_tiles(B, H, W, Cin, Cout, {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], taps))
+def conv_tiles(B, H, W, Cin, Cout, mode, taps, pro=0):
+    """Pixel tiles per image of the conv launch for this shape (-1: not covered) = T of its statistics; pro: the
+    launch is the GroupNorm-prologue conv."""
+    return int(_lib.load().idf_conv_tiles(B, H, W, Cin, Cout, {S1: 0, S2: 1, UP2: 2, T2: 3}[mode], taps, int(pro)))
 
 
-def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device):
+def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device, pro=0):
     """Buffer for the per-channel GroupNorm statistics partials a conv launch writes for its output, or None."""
     if Cout % 8:
         return None
-    T = conv_tiles(B, Ho, Wo, Cin, Cout, mode, taps)
+    T = conv_tiles(B, Ho, Wo, Cin, Cout, mode, taps, pro)
     return torch.empty((B, T, Cout, 2), dtype=torch.float32, device=device) if T > 0 else None
 
 
@@ -199,7 +200,7 @@ def conv_gn_ok(x, x2, taps, Cout):
         return False
     if taps == 1 and not _CONV1X1:
         return False
-    return conv_tiles(B, H, W, Cin, Cout, S1, taps) > 0
+    return conv_tiles(B, H, W, Cin, Cout, S1, taps, 1) > 0
 
 
 def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
@@ -217,7 +218,7 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
         rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
         sc = torch.empty((B, Cin), dtype=torch.float32, device=dev)
         sh = torch.empty((B, Cin), dtype=torch.float32, device=dev)
-    st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev) if want_stats else None
+    st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev, 1) if want_stats else None
     call('idf_conv_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
          _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, act, _p(seed), salt, float(p_drop),
          _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout,
@@ -528,6 +529,7 @@ class _FusedConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None,
                 passthrough=False, xst=None, want_stats=False):
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the statistics output / unused aliases
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
         act, mode, taps = cfg['act'], cfg['mode'], cfg['taps']
@@ -578,6 +580,9 @@ class _FusedConv(torch.autograd.Function):
         act, mode, taps, salt = cfg['act'], cfg['mode'], cfg['taps'], cfg['salt']
         if a is None:
             a = x
+        if dy is None:        # y itself unused: only what arrived over the aliases flows on
+            dy = torch.zeros((x.shape[0], weight.shape[0]) + out_hw(mode, x.shape[2], x.shape[3]), dtype=x.dtype,
+                             device=x.device).contiguous(memory_format=CL)
         dy = _nhwc(dy.to(x.dtype))
         need = ctx.needs_input_grad
         dW = db = dx = dgw = dgb = dft = dfa = dres = None
@@ -688,6 +693,7 @@ class _BlockEntryCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, w, b, gn_w, gn_b, sw, sb, cfg, cfg_sc, train, slots, st1=None, st2=None):
+        ctx.set_materialize_grads(False)
         x1, x2 = _nhwc(x1), _nhwc(x2)
         B, C1, H, W = x1.shape
         C = C1 + x2.shape[1]
@@ -720,6 +726,10 @@ class _BlockEntryCat(torch.autograd.Function):
         ws, bs, gws, gbs, sws, sbs = ctx.slots
         B, C1, H, W = x1.shape
         C = C1 + x2.shape[1]
+        if dh is None:
+            dh = torch.zeros((B, w.shape[0], H, W), dtype=x1.dtype, device=x1.device).contiguous(memory_format=CL)
+        if ds is None:
+            ds = torch.zeros((B, sw.shape[0], H, W), dtype=x1.dtype, device=x1.device).contiguous(memory_format=CL)
         dh, ds = _nhwc(dh.to(x1.dtype)), _nhwc(ds.to(x1.dtype))
         # shortcut: weight gradient over the two-source input, data gradient dense (joins in the GN backward)
         got = _defer_or_launch_wgrad(x1, ds, sws, sbs, 1, a2=x2)

@@ -416,7 +416,9 @@ __device__ uint4 g_trash[16];   // where the persistent kernel's epilogue sends 
 // PRO: the GroupNorm prologue as an in-LDS pass -- once the chunk has landed every thread reads its own vectors
 // back, applies act(x * sc + sh) and writes them in place (one more barrier per chunk); with two blocks per CU the
 // other block's MFMA phase runs beside this VALU phase.
-template <int KS, bool PRO = false>
+// DUAL: the input is the never-materialised concatenation x | x2 -- a chunk's per-lane source addresses point into
+// the tensor the chunk lies in.
+template <int KS, bool PRO = false, bool DUAL = false>
 __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   constexpr int TM = 4, BN = 64, NWM = 4, NT = 512, TN = 2;
   constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 256;
@@ -456,32 +458,25 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // group plan: wave w fetches groups w, w + 8, ...; per group this lane's global element offset
-  // (relative to the chunk's first channel) or -1 for the zero page
-  constexpr int MAXG = 9;                            // ceil((hgroups + WGROUPS) / 8) for every supported tile
-  const int ngroups = hgroups + WGROUPS;
-  int goff[MAXG];
+  // group plan: wave w fetches halo groups w, w + 8, ... and weight groups w, w + 8, ...; per halo group this
+  // lane's global element offset (relative to the chunk's first channel) or -1 for the zero page is kept; the
+  // weight offsets are recomputed per chunk (a handful of integer operations: registers matter more here)
+  constexpr int HGM = 5, WGM = (WGROUPS + 7) / 8;    // halo groups per wave (<= 36 groups per tile), weight groups per wave
+  const int prow = lane >> 2;
+  const int chl = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // logical 8-channel slot of this lane's 16 bytes: swz() inverted;
+                                                           // (row >> 2) & 1 == (lane >> 4) & 1 for rows 16 g + (lane >> 2)
+  int goff[HGM];
 #pragma unroll
-  for (int k = 0; k < MAXG; ++k) {
+  for (int k = 0; k < HGM; ++k) {
     const int gi = wave + k * 8;
     goff[k] = -1;
-    if (gi < ngroups) {
-      const int prow = lane >> 2, pslot = lane & 3;
-      if (gi < hgroups) {
-        const int pix = gi * 16 + prow;
-        const int ch = pslot ^ (((pix >> 2) & 1) << 1);          // inverse of swz(): XOR is an involution
-        if (pix < npix_h) {
-          int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
-          int iy = oy0 + hy - HALO, ix = hx - HALO;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
-            goff[k] = ((b * p.H + iy) * W + ix) * p.Cin + ch * 8;
-        }
-      } else {
-        const int r = (gi - hgroups) * 16 + prow;
-        const int tap = r / BN, n = r - tap * BN;
-        const int ch = pslot ^ (((n >> 2) & 1) << 1);
-        if (n0 + n < p.Cout) goff[k] = ((n0 + n) * TAPS + tap) * p.Cin + ch * 8;
-      }
+    const int pix = gi * 16 + prow;
+    if (gi < hgroups && pix < npix_h) {
+      int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
+      int iy = oy0 + hy - HALO, ix = hx - HALO;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+        goff[k] = DUAL ? (((b * p.H + iy) * W + ix) * 4 + chl)            // pixel index, vector slot
+                       : ((b * p.H + iy) * W + ix) * p.Cin + chl * 8;
     }
   }
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
@@ -501,13 +496,33 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   const int nchunks = p.Cin / CK;
   for (int ck = 0; ck < nchunks; ++ck) {
     const int c0 = ck * CK;
+    const bf16_t* dbase = p.x;      // DUAL: the tensor this chunk lies in, advanced to the chunk's first channel
+    int dpitch = p.Cin;
+    if (DUAL) {
+      if (c0 < p.C1) { dbase = p.x + c0; dpitch = p.C1; }
+      else { dbase = p.x2 + (c0 - p.C1); dpitch = p.Cin - p.C1; }
+    }
 #pragma unroll
-    for (int k = 0; k < MAXG; ++k) {
+    for (int k = 0; k < HGM; ++k) {
       const int gi = wave + k * 8;
-      if (gi < ngroups) {
-        const bf16_t* src = goff[k] >= 0 ? (gi < hgroups ? p.x : p.w) + goff[k] + c0 : zero;
+      if (gi < hgroups) {
+        const bf16_t* src;
+        if (DUAL)
+          src = goff[k] >= 0 ? dbase + ((unsigned)(goff[k] >> 2) * (unsigned)dpitch + (unsigned)(goff[k] & 3) * 8u) : zero;
+        else
+          src = goff[k] >= 0 ? p.x + goff[k] + c0 : zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + (size_t)gi * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WGM; ++k) {
+      const int gw = wave + k * 8;
+      if (gw < WGROUPS) {
+        const int r = gw * 16 + prow, tap = r / BN, n = r - tap * BN;
+        const bf16_t* src = (n0 + n < p.Cout) ? p.w + (((n0 + n) * TAPS + tap) * p.Cin + chl * 8 + c0) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Ws + (size_t)gw * 1024), 16, 0, 0);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);                   // the direct loads are counted by vmcnt
@@ -1087,7 +1102,7 @@ inline size_t aux_bytes(const C3P& p, bool pro, int nwaves, int BN) {
   return a > s ? a : s;
 }
 
-template <int KS, bool PRO = false>
+template <int KS, bool PRO = false, bool DUAL = false>
 void launch_dlds(C3P& p, hipStream_t st) {
   const int HALO = KS / 2;
   const int npix_h = (p.R + 2 * HALO) * (p.W + 2 * HALO);
@@ -1096,7 +1111,7 @@ void launch_dlds(C3P& p, hipStream_t st) {
   if (olds > lds) lds = olds;
   p.aux_off = (int)lds;
   lds += aux_bytes(p, PRO, 8, 64);
-  auto kern = conv_dlds_bf16<KS, PRO>;
+  auto kern = conv_dlds_bf16<KS, PRO, DUAL>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
 }
@@ -1252,8 +1267,8 @@ void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
   } while (0)
   // direct-to-LDS variant: pays once two of its blocks share every CU (it does not prefetch within a block)
   const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
-  if (!DUAL && mode == 0 && BM == 256 && !bn32 && (g_dlds & 1) && (p.Cout & 7) == 0 && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min) &&
-      ((p.R + 2) * (p.W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3, PRO>(p, st);
+  if (mode == 0 && BM == 256 && !bn32 && (g_dlds & 1) && (p.Cout & 7) == 0 && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min) &&
+      ((p.R + 2) * (p.W + 2) + 15) / 16 + 36 <= 72) launch_dlds<3, PRO, DUAL>(p, st);
   else if (mode == 0) IDF_C3_LAUNCH(0);
   else if constexpr (!DUAL && !PRO) {
     if (mode == 1) launch<1, 2, 64>(p, st);
@@ -1269,7 +1284,7 @@ void dispatch1(C3P& p, int BM, hipStream_t st) {
   if (ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 1, PRO, p.st_out != nullptr, &pl)) { launch_ps<1, DUAL, PRO>(p, pl, st); return; }
   p.n_tiles = idf_cdiv(p.Cout, 64);
   const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
-  if (!DUAL && BM == 256 && (g_dlds & 2) && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min)) launch_dlds<1, PRO>(p, st);
+  if (BM == 256 && (g_dlds & 2) && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min)) launch_dlds<1, PRO, DUAL>(p, st);
   else if (BM == 256) launch<0, 4, 64, 4, 1, DUAL, PRO>(p, st);
   else if (BM == 128) launch<0, 4, 64, 2, 1, DUAL, PRO>(p, st);
   else launch<0, 2, 64, 2, 1, DUAL, PRO>(p, st);

@@ -74,6 +74,9 @@ int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const void* w, const
 /* Pixel tiles per image (= T of st_out) of the launch idf_conv3x3_bf16 / idf_conv1x1_bf16 (pro = 0) or
  * idf_conv_gn_bf16 (pro = 1) make for this shape (H, W = output dims; taps 9 or 1); -1 when the shape is not covered. */
 int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps, int pro);
+/* 1 when idf_conv_gn_bf16 is expected to beat idf_gn_fused_fwd (or idf_gn_coef_fwd + idf_gn_apply) followed by the plain
+ * conv for this shape, 0 when the two-launch form wins (measured rules, see idf_conv3x3.hip); the host picks with it. */
+int idf_conv_gn_advice(int B, int H, int W, int Cin, int Cout, int taps);
 
 /* The conv / GroupNorm-SiLU / AdaGN fused block (modules.py:264-288 block1..3, 309-320 AuxResBlock.forward,
  * 145-150 AttnBlock GroupNorm + q/k/v, models.py:280-284 tail):
@@ -87,13 +90,15 @@ int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, int taps, i
  * seed != NULL (keyed by (*seed, salt, element index), as idf_conv2d_fwd)  once per staged element.
  * Optional outputs (training; NULL otherwise): a_out [B,H,W,Cin] bf16 = the activated tensor (input of the
  * weight gradient), mean / rstd [B,32] and sc / sh [B,Cin] (all four or none; inputs of idf_gn_fused_bwd /
- * idf_gn_coef_bwd), st_out as above.  IDF_ERR_UNSUPPORTED for shapes outside idf_conv3x3_bf16 / idf_conv1x1_bf16. */
+ * idf_gn_coef_bwd), st_out as above.  coef_ws (optional): B * Cin * 2 floats of scratch; with it, launches that cut an
+ * image into many tiles fold the coefficients once per image in a small launch of their own instead of once per block.
+ * IDF_ERR_UNSUPPORTED for shapes outside idf_conv3x3_bf16 / idf_conv1x1_bf16. */
 int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
                      const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
                      int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
                      const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
-                     float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin, int Cout,
-                     int taps, void* stream);
+                     float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
+                     int Cout, int taps, void* stream);
 
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */

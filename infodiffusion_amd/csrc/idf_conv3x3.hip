@@ -46,6 +46,7 @@ struct C3P {
   const uint64_t* seed;
   uint32_t salt, thr;
   float dscale;
+  const float* cof_in;  // [B][Cin][2] (sc, sh) folded by pro_coef_kernel beforehand (big launches: many blocks per image)
   bf16_t* a_out;        // training: the activated tensor [B, H, W, Cin] (dense), kept for the weight gradient
   float* mean_out; float* rstd_out; float* sc_out; float* sh_out;   // training: saved for the GroupNorm backward
   // ---- persistent wave-specialised form (conv_ps_bf16): a pixel tile = NI images x R rows x W columns = 256 pixels
@@ -69,6 +70,11 @@ __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1
 template <int NT>
 __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool writer, float* cof, float* chs, int tid) {
   const int C = p.Cin, cpg = C >> 5;
+  if (p.cof_in) {                 // folded once per image by pro_coef_kernel: just fetch
+    for (int c = tid; c < 2 * C; c += NT) cof[c] = p.cof_in[(size_t)b * 2 * C + c];
+    __syncthreads();
+    return;
+  }
   for (int c = tid; c < C; c += NT) {
     const float* st = p.st1;
     int T = p.T1, Cs = p.C1, cl = c;
@@ -103,6 +109,17 @@ __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool write
     }
   }
   __syncthreads();
+}
+
+// grid B: the fold once per image, for launches whose images are cut into many tiles (every block of the conv would
+// otherwise repeat it: two dependent memory round trips and a double-precision rsqrt in front of its first MFMA)
+__global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __restrict__ cof_out) {
+  extern __shared__ __attribute__((aligned(16))) float cs[];        // cof [Cin][2] | chs [Cin][2]
+  C3P q = p;
+  q.cof_in = nullptr;
+  const int b = blockIdx.x;
+  pro_coefficients<256>(q, b, true, cs, cs + 2 * p.Cin, threadIdx.x);
+  for (int c = threadIdx.x; c < 2 * p.Cin; c += 256) cof_out[(size_t)b * 2 * p.Cin + c] = cs[c];
 }
 
 // a = act(x * sc + sh) on one 16-byte vector (8 bf16 channels); vec = index of the vector in the dense activated
@@ -655,6 +672,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 // workgroup barriers: every producer wave computes all channels and stores the same values)
 __device__ __forceinline__ void ps_coefficients(const C3P& p, int b, bool writer, float* cof, float* chs, int lane) {
   const int C = p.Cin, cpg = C >> 5;
+  if (p.cof_in) {
+    for (int c = lane; c < 2 * C; c += 64) cof[c] = p.cof_in[(size_t)b * 2 * C + c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+  }
   for (int c = lane; c < C; c += 64) {
     const float* st = p.st1;
     int T = p.T1, Cs = p.C1, cl = c;
@@ -1134,7 +1156,7 @@ void clear_pro(C3P& p) {
   p.st1 = p.st2 = nullptr; p.T1 = p.T2 = 0;
   p.gamma = p.beta = p.film_t = p.film_a = nullptr; p.ld_t = p.ld_a = 0; p.eps = 0.f;
   p.act = 0; p.seed = nullptr; p.salt = 0; p.thr = 0; p.dscale = 1.f;
-  p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr;
+  p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr; p.cof_in = nullptr;
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
   static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
   p.ps_dbg = dbg;
@@ -1376,6 +1398,23 @@ extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, 
   return H / R;
 }
 
+// 1 when the one-launch GroupNorm-prologue conv is expected to beat the GroupNorm kernel + plain conv pair for this
+// shape, 0 when the pair wins (measured on MI355X, tools/bench_gnconv.py: the prologue's vector work is done once per
+// staged element -- halo rows and every 64-cout tile repeat it -- so it loses where that repetition is large and the
+// stand-alone GroupNorm pass runs near its bandwidth):
+//   two or more cout tiles on >= 1536 pixel-tile blocks (128->128 @32^2 at B = 256: 130 vs 112 us),
+//   ragged cout counts (epsilon / latent heads: 32-cout tiles of 128 pixels) on >= 2^19 pixels (263 vs 167 us).
+extern "C" int idf_conv_gn_advice(int B, int H, int W, int Cin, int Cout, int taps) {
+  static const int force = getenv("IDF_GN_FUSE_FORCE") ? atoi(getenv("IDF_GN_FUSE_FORCE")) : -1;
+  if (force >= 0) return force;
+  const long M = (long)B * H * W;
+  if (taps == 9) {
+    if ((Cout & 7) && M >= (1L << 19)) return 0;
+    if (idf_cdiv(Cout, 64) >= 2 && (M / 256) * idf_cdiv(Cout, 64) >= 1536) return 0;
+  }
+  return 1;
+}
+
 // y = conv(act(GroupNorm/FiLM(x))) + bias (+ res) in ONE launch (modules.py:264-288, 309-320, 145-150): stride-1 3x3
 // (taps 9) or 1x1 (taps 1) over x [B,H,W,Cin] -- or over the never-materialised concatenation x | x2 (models.py:321).
 // The GroupNorm(32) statistics are not computed here: the launches that produced x (and x2) left per-channel partial
@@ -1384,12 +1423,14 @@ extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, 
 // affine and applies  act 1: u = x*sc+sh;  act 2: SiLU(u), then dropout(p_drop) when seed != NULL  while staging its tile.
 // Optional outputs (training; NULL otherwise): a_out = the activated tensor [B,H,W,Cin] (kept for the weight gradient),
 // mean / rstd [B,32] and sc / sh [B,Cin] (for idf_gn_fused_bwd / idf_gn_coef_bwd); st_out as above.
+// coef_ws (optional): B * Cin * 2 floats of scratch -- launches that cut an image into many tiles fold the coefficients
+// once per image into it with a small launch of their own instead of once per block.
 extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
                                 const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
                                 int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
                                 const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
-                                float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin, int Cout,
-                                int taps, void* stream) {
+                                float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
+                                int Cout, int taps, void* stream) {
   if (!x2) { C1 = Cin; st2 = nullptr; T2 = 0; }
   const bool ok = taps == 9 ? shape3_ok(H, W, Cin, Cout, 0) : (taps == 1 && shape1_ok(W, Cin, Cout));
   if (!ok || (Cin % 32) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
@@ -1416,6 +1457,14 @@ extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const flo
     IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv_gn_bf16: tile too large (H%d W%d)" : "conv_gn_bf16: tensor too large for 32-bit offsets", H, W);
   if ((long)B * H * W * Cin >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
+  // many tiles per image: fold the coefficients once per image in a launch of their own
+  static const long coef_min = getenv("IDF_GN_COEF_MIN") ? atol(getenv("IDF_GN_COEF_MIN")) : 1024;
+  if (coef_ws && (long)B * p.tiles_per_img * idf_cdiv(Cout, 64) >= coef_min && p.tiles_per_img >= 4) {
+    hipLaunchKernelGGL(pro_coef_kernel, dim3(B), dim3(256), (size_t)Cin * 16, st, p, coef_ws);
+    IDF_CHECK_LAUNCH();
+    p.cof_in = coef_ws;
+    p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr;      // written by the coefficient launch
+  }
   if (taps == 9) { if (x2) dispatch3<true, true>(p, 0, BM, st); else dispatch3<false, true>(p, 0, BM, st); }
   else { if (x2) dispatch1<true, true>(p, BM, st); else dispatch1<false, true>(p, BM, st); }
   IDF_CHECK_LAUNCH();

@@ -200,7 +200,12 @@ def conv_gn_ok(x, x2, taps, Cout):
         return False
     if taps == 1 and not _CONV1X1:
         return False
-    return conv_tiles(B, H, W, Cin, Cout, S1, taps, 1) > 0
+    return conv_tiles(B, H, W, Cin, Cout, S1, taps, 1) > 0 and _gn_advice(B, H, W, Cin, Cout, taps)
+
+
+@functools.lru_cache(maxsize=None)
+def _gn_advice(B, H, W, Cin, Cout, taps):
+    return bool(_lib.load().idf_conv_gn_advice(B, H, W, Cin, Cout, taps))
 
 
 def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
@@ -219,10 +224,11 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
         sc = torch.empty((B, Cin), dtype=torch.float32, device=dev)
         sh = torch.empty((B, Cin), dtype=torch.float32, device=dev)
     st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev, 1) if want_stats else None
+    ws = torch.empty((B, Cin, 2), dtype=torch.float32, device=dev) if B * H * W >= (1 << 18) else None
     call('idf_conv_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
          _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, act, _p(seed), salt, float(p_drop),
-         _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout,
-         taps, _st())
+         _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), _p(ws), B, H, W, Cin,
+         Cout, taps, _st())
     return y, a, mean, rstd, sc, sh, st
 
 

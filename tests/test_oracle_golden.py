@@ -156,6 +156,28 @@ def test_vanilla(gold, manifest):
     assert rel(y, g['y2']) < 2e-5
 
 
+def test_config5_cifar(gold, manifest):
+    """BASELINE configs[4] at its own shape (CIFAR-10 3x32x32, ch 64): vanilla [1,2,4,8] UNet, the latent denoiser at
+    a_dim = 256 and its DDIM trace, against the reference fixture (tools/gen_golden.py config5)."""
+    g = gold('config5_cifar')
+    cfg = O.dataset_cfg('cifar10', a_dim=256, diffusion_steps=4)
+    sd = O.synth_state_dict(manifest('manifest_vanilla_cifar'))
+    with torch.no_grad():
+        y = O.vanilla_unet(sd, 'backbone', g['x'], torch.full((2,), 2, dtype=torch.long),
+                           cfg.unets_channels, O.ch_mult_for(cfg, vanilla=True))
+    assert rel(y, g['y2']) < 2e-5
+    sdl = O.synth_state_dict(manifest('manifest_latent256'))
+    with torch.no_grad():
+        yl = O.latent_unet(sdl, 'backbone', g['lat.x'], torch.full((3,), 3, dtype=torch.long), 256)
+        sched = O.noise_schedule(1e-5, 1e-2, 4)
+        nz = {3: g['lat.noise'][0], 2: g['lat.noise'][1], 1: g['lat.noise'][2]}
+        tr = O.sample_loop(sched, lambda xx, i: O.latent_unet(sdl, 'backbone', xx, torch.full((3,), i, dtype=torch.long), 256),
+                           g['lat.xT'], True, nz)
+    assert rel(yl, g['lat.y3']) < 2e-5
+    for k in range(4):
+        assert rel(tr[k], g['lat.trace'][k]) < 5e-5, k
+
+
 def test_priors_and_kl_capacity(gold, manifest):
     """'10mix' / 'roll' prior samplers (utils.py:11-40; host numpy RNG => bit-identical under the same seed) and the
     --use_C KL-capacity branch of the loss (models.py:662-671) at epoch 3, against the reference fixture."""

@@ -573,8 +573,75 @@ def gen_vanilla_twophase():
         R_models.ResBlock.__init__ = orig
 
 
+# ------------------------------ BASELINE configs[4]: CIFAR-10 shape, two-phase + latent-DDIM
+def gen_config5():
+    """The CIFAR-10 32x32 pipeline of eval_fid.sh:11 at its own shape: vanilla [1,2,4,8] UNet (512-channel 4x4
+    maps), latent denoiser at a_dim = 256 (hidden 1024) with a DDIM trace, and the two-phase sampler's result."""
+    orig = R_modules.ResBlock.__init__
+
+    def patched(self, in_ch, out_ch, tdim, dropout, attn=False, crossattn=False):
+        orig(self, in_ch, out_ch, tdim, dropout, attn=attn)
+    R_modules.ResBlock.__init__ = patched
+    R_models.ResBlock.__init__ = patched
+    try:
+        cfg = O.dataset_cfg('cifar10', a_dim=256, diffusion_steps=4, deterministic=True, model='diff',
+                            is_latent=False, mode='eval_fid', split_step=1)
+        a = args_for(cfg)
+        torch.manual_seed(0)
+        m2 = R_models.Diff(a, 'cpu', cfg.shape)
+        man2, syn2 = load_synth(m2)
+        with open(os.path.join(GOLD, 'manifest_vanilla_cifar.json'), 'w') as f:
+            json.dump([(k, list(s)) for k, s in man2], f)
+        m2.eval()
+        x = rnd(51, 2, *cfg.shape)
+        with torch.no_grad():
+            y = m2(x, 2)
+        yo = O.vanilla_unet(syn2, 'backbone', x, torch.full((2,), 2, dtype=torch.long),
+                            cfg.unets_channels, O.ch_mult_for(cfg, vanilla=True))
+        check('vanilla unet (cifar)', yo, y)
+        m1 = R_models.InfoDiff(a, 'cpu', cfg.shape)
+        load_synth(m1)
+        m1.eval()
+        proc = R_sampling.TwoPhaseDiffusionProcess(a, m1, m2, 'cpu', cfg.shape)
+        xT = rnd(52, 2, *cfg.shape)
+        a2 = rnd(53, 2, cfg.a_dim)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            fin = proc.sampling(2, xT=xT, a=a2)
+        torch.manual_seed(5)
+        noises = {i: torch.randn_like(xT) for i in reversed(range(4)) if i != 0}
+        out = dict(x=x, y2=y, xT=xT, a=a2, final=fin, noise=torch.stack([noises[3], noises[2], noises[1]]))
+    finally:
+        R_modules.ResBlock.__init__ = orig
+        R_models.ResBlock.__init__ = orig
+    # latent denoiser at a_dim 256
+    cfgl = O.Cfg(a_dim=256, is_latent=True, diffusion_steps=4, input_size=32, deterministic=True)
+    al = args_for(cfgl)
+    torch.manual_seed(0)
+    ml = R_models.Diff(al, 'cpu', (1, 256, 256))
+    manl, synl = load_synth(ml)
+    with open(os.path.join(GOLD, 'manifest_latent256.json'), 'w') as f:
+        json.dump([(k, list(s)) for k, s in manl], f)
+    ml.eval()
+    xl = rnd(54, 3, 256)
+    with torch.no_grad():
+        yl = ml(xl, 3)
+    yo = O.latent_unet(synl, 'backbone', xl, torch.full((3,), 3, dtype=torch.long), 256)
+    check('latent unet a_dim 256', yo, yl, 1e-5)
+    procl = R_sampling.LatentDiffusionProcess(al, ml, 'cpu')
+    xTl = rnd(55, 3, 256)
+    torch.manual_seed(78)
+    with torch.no_grad():
+        trl = list(procl._one_diffusion_step(xTl, True))
+    torch.manual_seed(78)
+    nzl = {i: torch.randn_like(xTl) for i in reversed(range(4)) if i != 0}
+    out.update({'lat.x': xl, 'lat.y3': yl, 'lat.xT': xTl, 'lat.noise': torch.stack([nzl[3], nzl[2], nzl[1]]),
+                'lat.trace': torch.stack(trl)})
+    save('config5_cifar', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'celeba']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'celeba', 'config5']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -601,4 +668,6 @@ if __name__ == '__main__':
         gen_branches()
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
+    if 'config5' in which:
+        gen_config5()
     print('ALL ORACLE-vs-REFERENCE CHECKS PASSED')

@@ -57,17 +57,17 @@ def make_args(a):
                            is_latent=False, act_dtype=a.dtype, dataset='celeba')
 
 
-CPU_THREADS = 16      # the oracle's convs stop scaling (and oversubscribe badly) far below the box's 256 cores
-CPU_BATCH = 8
+CPU_THREADS = 32      # the oracle's convs stop scaling (and oversubscribe badly) far below the box's 256 cores
+CPU_BATCH = 32        # the benchmarked batch, 1 warm-up + 3 timed steps; then 3 backbone evaluations
 
 
 def cpu_baseline_worker(a_dim, out_path):
     """Child process: the CPU oracle (restatement of the reference's stock-ATen path, fp32 NCHW) doing
-    the same training step on host cores; appends each step's seconds to `out_path` as it goes."""
+    the same training step on host cores, then the sampler's network evaluation; appends one line per
+    measurement to `out_path` as it goes ('train <s>' / 'eval <s>')."""
     from oracle import infodiff_oracle as O
     torch.set_num_threads(CPU_THREADS)
     cfg = O.dataset_cfg('celeba', a_dim=a_dim, mmd_weight=0.1)
-    down, mid, up, _ = O.unet_layout(64, [1, 2, 2, 2])
     from types import SimpleNamespace
     from infodiffusion_amd.models import InfoDiff
     margs = SimpleNamespace(**{**cfg.__dict__})
@@ -84,7 +84,7 @@ def cpu_baseline_worker(a_dim, out_path):
     g = torch.Generator(device='cpu')
     g.manual_seed(64)
     B = CPU_BATCH
-    for it in range(3):
+    for it in range(4):
         x = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
         t0 = time.time()
         idx = torch.randint(0, 1000, (B,))
@@ -95,10 +95,20 @@ def cpu_baseline_worker(a_dim, out_path):
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
         opt.step()
         with open(out_path, 'a') as f:
-            f.write('%.4f\n' % (time.time() - t0))
+            f.write('train %.4f\n' % (time.time() - t0))
+    # sampling (sampling.py:41-60 calls the backbone once per step; models.py:705-723): 1 warm-up + 3 evaluations
+    sdd = {k: v.detach() for k, v in sd.items()}
+    xs = torch.randn(B, 3, 64, 64, generator=g)
+    av = torch.randn(B, cfg.a_dim, generator=g)
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.time()
+            O.infodiff_eps(sdd, cfg, xs, 50, av)
+            with open(out_path, 'a') as f:
+                f.write('eval %.4f\n' % (time.time() - t0))
 
 
-def cpu_baseline(margs, budget_s=150):
+def cpu_baseline(margs, budget_s=240):
     """Run the worker as a child process (bounded: killed by PID after `budget_s`) and report
     images/s from the timed steps it completed (first step = warm-up, excluded when more exist)."""
     import subprocess
@@ -113,23 +123,32 @@ def cpu_baseline(margs, budget_s=150):
     except subprocess.TimeoutExpired:
         proc.kill()
         proc.wait()
+    train, evals = [], []
     try:
-        times = [float(l) for l in open(out).read().split()]
-    except OSError:
-        times = []
+        for line in open(out).read().splitlines():
+            kind, v = line.split()
+            (train if kind == 'train' else evals).append(float(v))
+    except (OSError, ValueError):
+        pass
     finally:
         if os.path.exists(out):
             os.unlink(out)
-    if not times:
+    if not train:
         return {'value': None, 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
                 'sample': 'CPU oracle did not finish one B=%d step within %d s' % (CPU_BATCH, budget_s)}
-    timed = times[1:] if len(times) > 1 else times
+    timed = train[1:] if len(train) > 1 else train
     t = sum(timed) / len(timed)
-    return {'value': round(CPU_BATCH / t, 3), 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
-            'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
-                      '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores): %d timed '
-                      'step(s) after 1 warm-up, %.1f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0,
-                                                                 len(timed), t)}
+    res = {'value': round(CPU_BATCH / t, 3), 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
+           'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
+                     '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores): %d timed '
+                     'step(s) after 1 warm-up, %.2f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0,
+                                                                len(timed), t)}
+    if len(evals) > 1:
+        te = sum(evals[1:]) / len(evals[1:])
+        res['sampling'] = {'value': round(CPU_BATCH / (100 * te), 4), 'unit': 'images/s',
+                           'sample': 'DDIM-100 = 100 backbone evaluations per image batch: %d timed evaluations at B=%d '
+                                     'after 1 warm-up, %.2f s each, x100' % (len(evals) - 1, CPU_BATCH, te)}
+    return res
 
 
 def pmc_traffic(prefix):
@@ -145,51 +164,129 @@ def pmc_traffic(prefix):
         return None
 
 
-class ConvTimer:
-    """HIP-event timing of the dominant kernel (the halo 3x3 conv: forward + data-gradient launches).
-    One eager step records every launch's arguments; each distinct launch configuration is then replayed
-    n times back to back from a captured hipGraph -- exactly how the timed region issues it -- between one
-    HIP event pair on that stream, and the per-launch durations are weighted by the step's launch counts.
-    (An event pair around every single eager launch measures the events: +10 us per launch.)"""
+def pmc_traffic_r02(names):
+    """Average HBM bytes per launch over the kernels whose name contains one of `names`, from the committed rocprofv3
+    PMC passes of this round (profiles/r02_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+            d = json.load(f)
+        ks = [v for k, v in d.items() if any(n in k for n in names)]
+        n = sum(v['launches'] for v in ks)
+        return round(sum(v['launches'] * v['hbm_bytes_avg'] for v in ks) / n) if n else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+class LaunchRecorder:
+    """Cold HIP-event timing of the step's hot kernels.  One eager step records every C-ABI call of the kernel
+    families below; each distinct launch configuration is then replayed from a captured hipGraph between one HIP event
+    pair -- every replayed call on its OWN set of activation buffers, >= 4 sets and > 256 MB (the Infinity Cache)
+    together, so no call finds its operands in L2 / MALL because the previous call left them there.  (An event pair
+    around every single eager launch measures the events: +10 us per launch; replaying one launch on the same buffers
+    measures the caches.)  The per-launch times are weighted by the step's launch counts."""
 
     def __init__(self):
-        self.calls = {}      # key -> [count, args]
+        self.calls = {}      # (name, signature) -> [count, args]
+        self.order = []
+
+    # ---- per entry point: (family, [(arg index, bytes)] of the activation-sized buffers, work)
+    @staticmethod
+    def _spec(name, a):
+        if name == 'idf_conv3x3_bf16':
+            B, H, W, Cin, Cout, mode = a[5:11]
+            Hs, Ws = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode >= 2 else (H, W))
+            yb = B * H * W * Cout * 2
+            bufs = [(0, B * Hs * Ws * Cin * 2), (4, yb)] + ([(3, yb)] if a[3] else [])
+            return 'conv3x3', bufs, 2.0 * B * H * W * Cout * 9 * Cin / (4 if mode == 3 else 1)
+        if name == 'idf_conv_gn_bf16':
+            C1 = a[2]
+            B, H, W, Cin, Cout, taps = a[29:35]
+            if taps != 9:
+                return None
+            px = B * H * W
+            bufs = [(0, px * (C1 if a[1] else Cin) * 2), (21, px * Cout * 2)]
+            if a[1]:
+                bufs.append((1, px * (Cin - C1) * 2))
+            if a[20]:
+                bufs.append((20, px * Cout * 2))
+            if a[22]:
+                bufs.append((22, px * Cin * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_gn_fused_bwd':
+            C1 = a[3]
+            B, HW, C, dt = a[27:31]
+            esz = 2 if dt == 1 else 4
+            c1 = C1 if a[2] else C
+            bufs = [(0, B * HW * C * esz), (1, B * HW * c1 * esz), (6, B * HW * c1 * esz)]
+            if a[2]:
+                bufs += [(2, B * HW * (C - c1) * esz), (7, B * HW * (C - c1) * esz)]
+            if a[4]:
+                bufs.append((4, B * HW * C * esz))
+            if a[5]:
+                bufs.append((5, B * HW * C * esz))
+            return 'gn_bwd', bufs, float(sum(n for _, n in bufs))
+        if name == 'idf_attn_fwd':
+            B, N, C = a[3:6]
+            return 'attn', [(0, B * N * 3 * C * 2), (1, B * N * C * 2)], 4.0 * B * N * N * C
+        return None
 
     def install(self):
         from infodiffusion_amd import ops
         self.ops = ops
-        self.orig = ops.conv_raw
-        timer = self
+        self.orig = ops.call
+        rec = self
 
-        def recorded(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None, **kw):
-            B, Cin, Hs, Ws = x.shape
-            Ho, Wo = out_hw_ if out_hw_ is not None else ops.out_hw(mode, Hs, Ws)
-            if ops.uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
-                key = (B, Cin, Hs, Ws, Cout, mode, residual is not None, bias is not None)
-                if key in timer.calls:
-                    timer.calls[key][0] += 1
+        def recorded(name, *args):
+            sp = rec._spec(name, args)
+            if sp is not None:
+                ptr = {i for i, _ in sp[1]}
+                key = (name,) + tuple((v is not None) if (i in ptr or isinstance(v, int) and v > (1 << 32)) else v
+                                      for i, v in enumerate(args[:-1]))
+                if key in rec.calls:
+                    rec.calls[key][0] += 1
                 else:
-                    timer.calls[key] = [1, (x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout,
-                                            out_hw_)]
-            return timer.orig(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_, **kw)
-        ops.conv_raw = recorded
+                    rec.calls[key] = [1, (name, args)]
+            return rec.orig(name, *args)
+        ops.call = recorded
 
     def remove(self):
-        self.ops.conv_raw = self.orig
+        self.ops.call = self.orig
 
-    def summary(self, reps=10):
-        """(launches per step, total ms per step, FLOPs per step, algorithmic bytes per step)"""
-        n = tot_ms = fl = by = 0
+    def measure(self, dev, reps_min=8):
+        """family -> (launches per step, ms per step, work per step, bytes per step)"""
+        fam = {}
         side = torch.cuda.Stream()
-        for key, (count, args) in self.calls.items():
-            x, w_fwd, _, residual = args[0], args[1], args[2], args[3]
-            for _ in range(2):
-                y = self.orig(*args)
+        for key, (count, (name, args)) in self.calls.items():
+            family, bufs, work = self._spec(name, args)
+            per_set = sum(n for _, n in bufs)
+            K = max(4, min(16, -(-(320 << 20) // per_set)))
+            sets = []
+            for k in range(K):
+                al = list(args)
+                keep = []
+                for i, n in bufs:
+                    t = torch.randn(n // 2, device=dev, dtype=torch.bfloat16)
+                    keep.append(t)
+                    al[i] = t.data_ptr()
+                if name == 'idf_gn_fused_bwd':      # not into the live gradient arena: per-sample sums to scratch
+                    B_, C_ = al[27], al[29]
+                    t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
+                    keep.append(t)
+                    al[20], al[21], al[22] = t.data_ptr(), None, None
+                al[-1] = None
+                sets.append((al, keep))
+            reps = max(1, -(-reps_min // K))
+
+            def run_all(stream_ptr):
+                for _ in range(reps):
+                    for al, _k in sets:
+                        al[-1] = stream_ptr
+                        self.orig(name, *al)
+            run_all(torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side), torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                for _ in range(reps):
-                    y = self.orig(*args)
+                run_all(side.cuda_stream)
             g.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -198,14 +295,14 @@ class ConvTimer:
                 g.replay()
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / (3 * reps)
-            M = y.shape[0] * y.shape[2] * y.shape[3]
-            n += count
-            tot_ms += count * ms
-            fl += count * 2.0 * M * args[12] * args[10] * x.shape[1]
-            by += count * (x.numel() + y.numel() + (residual.numel() if residual is not None else 0)
-                           + w_fwd.numel()) * x.element_size()
-        return n, tot_ms, fl, by
+            ms = e0.elapsed_time(e1) / (3 * reps * K)
+            f = fam.setdefault(family, [0, 0.0, 0.0, 0.0])
+            f[0] += count
+            f[1] += count * ms
+            f[2] += count * work
+            f[3] += count * per_set
+            del sets, g
+        return fam
 
 
 def large_batch_rate(a, margs, dev, batch=128, steps=10):
@@ -348,13 +445,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.time()
+    marks[0].record()
     for i in range(a.steps):
         step(i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -367,7 +469,8 @@ def main():
     out = {
         'metric': 'training images/sec, CelebA 64x64 (InfoDiff loss_fn fwd+bwd+clip+AdamW)',
         'value': round(imgs / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(dt / a.steps * 1e3, 3), 'ms_per_step_median': round(median_ms, 3),
+        'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: CelebA 3x64x64 a_dim=%d mmd_weight=0.1 T=1000 dropout=0.1 '
                                'train step, random-pixel batches, random-init weights' % a.a_dim,
@@ -378,23 +481,45 @@ def main():
     }
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel: the halo 3x3 conv (forward + data-gradient launches)
-        tm = ConvTimer()
-        tm.install()
-        fwd_bwd()       # every conv launch of a step; no exchange / optimizer: the other ranks are not in this block
-        tm.remove()
+        # dominant kernel family: the 3x3 convs (forward incl. the GroupNorm-prologue form, and data gradients)
+        rec = LaunchRecorder()
+        rec.install()
+        fwd_bwd()       # every launch of a step; no exchange / optimizer: the other ranks are not in this block
+        rec.remove()
         torch.cuda.synchronize()
-        nrep = 1
-        n, tot_ms, fl, by = tm.summary()
-        ach = fl / (tot_ms * 1e-3) / 1e12
+        fam = rec.measure(dev)
         peak = 2500.0 if a.dtype == 'bf16' else 157.3
-        out['roofline'] = {'kernel': 'conv3x3_halo_bf16 (3x3 conv forward + data-gradient launches)', 'bound': 'mfma',
-                           'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           'traffic': pmc_traffic('conv3x3_halo_bf16'), 'launches_per_step': n // nrep,
-                           'avg_launch_us': round(tot_ms * 1e3 / n, 2),
-                           'algorithmic_gflop_per_step': round(fl / nrep / 1e9, 1),
-                           'algorithmic_bytes_per_launch': round(by / n),
-                           'algorithmic_gbs': round(by / (tot_ms * 1e-3) / 1e9, 1)}
+        if 'conv3x3' in fam:
+            n, ms, fl, by = fam['conv3x3']
+            ach = fl / (ms * 1e-3) / 1e12
+            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16: forward incl. '
+                                         'GroupNorm-prologue launches + data-gradient launches)',
+                               'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': round(ach / peak, 4),
+                               'traffic': pmc_traffic_r02(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16']),
+                               'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+                               'timing': 'cold: each replayed launch on its own buffer set, sets > 256 MB together',
+                               'algorithmic_gflop_per_step': round(fl / 1e9, 1),
+                               'algorithmic_bytes_per_launch': round(by / n),
+                               'algorithmic_gbs': round(by / (ms * 1e-3) / 1e9, 1)}
+        if 'gn_bwd' in fam:
+            n, ms, _, by = fam['gn_bwd']
+            gbs = by / (ms * 1e-3) / 1e9
+            out['roofline_hbm'] = {'kernel': 'gn_small_bwd (GroupNorm + FiLM + SiLU + dropout backward, the ResBlock '
+                                             'elementwise pass that remains stand-alone)', 'bound': 'hbm',
+                                   'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                                   'traffic': pmc_traffic_r02(['gn_small_bwd']), 'launches_per_step': n,
+                                   'avg_launch_us': round(ms * 1e3 / n, 2),
+                                   'algorithmic_bytes_per_launch': round(by / n),
+                                   'note': 'bytes = dA + x (+ branch gradients) read, dx written, once each'}
+        if 'attn' in fam:
+            n, ms, fl, by = fam['attn']
+            ach = fl / (ms * 1e-3) / 1e12
+            out['roofline_attn'] = {'kernel': 'attn_fwd_kernel (N = 256 tokens, d = 128: QK^T, softmax, PV in one launch)',
+                                    'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic_r02(['attn_fwd_kernel']),
+                                    'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+                                    'note': '4 N^2 d FLOP per image; launch-bound at B = 32 (32 x 4 workgroups)'}
     if world > 1:
         dist.barrier()
 
@@ -430,6 +555,14 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_large_batch:
         out['large_batch'] = large_batch_rate(a, margs, dev)
+        if a.dtype == 'bf16':
+            # the same step in the reference's own arithmetic (fp32 activations, exact-f32 MFMA): supplementary
+            import copy
+            fa = copy.copy(margs)
+            fa.act_dtype = 'fp32'
+            r = large_batch_rate(a, fa, dev, batch=a.batch, steps=5)
+            out['fp32_value'] = {'value': r['value'], 'unit': 'images/s', 'ms_per_step': r['ms_per_step'],
+                                 'note': 'fp32 activations / weights (1e-4 parity path), B=%d, graph replay' % a.batch}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(margs)
     if rank == 0:

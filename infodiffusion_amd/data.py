@@ -36,18 +36,29 @@ class _Batches:
             self.array = arr
             self.n = len(arr) // (self.bs * world)
         self.seed = getattr(args, 'r_seed', 0)
+        self.epoch = 0
+        # the reference shuffles every loader but CelebA's (data.py:184 vs 197-243)
+        self.shuffle = args.dataset != 'celeba' and getattr(args, 'mode', 'train') == 'train'
         self.augment = args.dataset in ('celeba', 'ffhq') and getattr(args, 'mode', 'train') == 'train'   # data.py:165-166
 
     def __len__(self):
         return self.n
 
     def __iter__(self):
+        # fresh draws every epoch (flip masks, random pixels), different per rank; ONE permutation per epoch shared by
+        # all ranks for the datasets the reference shuffles
+        epoch, self.epoch = self.epoch, self.epoch + 1
         g = torch.Generator(device='cpu')
-        g.manual_seed(self.seed + self.rank)
+        g.manual_seed((self.seed * 1000003 + epoch) * 64 + self.rank)
         on_gpu = torch.device(self.device).type == 'cuda'
         if on_gpu and self.array is None:
             gd = torch.Generator(device=self.device)          # random pixels are drawn where they are consumed:
-            gd.manual_seed(self.seed + self.rank)             # a host draw + H2D copy costs more than a training step
+            gd.manual_seed((self.seed * 1000003 + epoch) * 64 + self.rank)   # a host draw + H2D copy costs more than a step
+        perm = None
+        if self.array is not None and self.shuffle:
+            gp = torch.Generator(device='cpu')
+            gp.manual_seed(self.seed * 1000003 + epoch)
+            perm = torch.randperm(len(self.array), generator=gp).numpy()
         for i in range(self.n):
             if self.array is None and on_gpu:
                 x = torch.rand(self.bs, *self.shape, generator=gd, device=self.device) * 2 - 1
@@ -55,7 +66,8 @@ class _Batches:
                 x = torch.rand(self.bs, *self.shape, generator=g) * 2 - 1
             else:
                 lo = (i * self.world + self.rank) * self.bs
-                a = torch.from_numpy(np.ascontiguousarray(self.array[lo:lo + self.bs]))
+                rows = self.array[lo:lo + self.bs] if perm is None else self.array[np.sort(perm[lo:lo + self.bs])]
+                a = torch.from_numpy(np.ascontiguousarray(rows))
                 if a.dtype == torch.uint8 and torch.device(self.device).type == 'cuda':
                     # bytes cross PCIe; ToTensor / RandomHorizontalFlip / Normalize run on the GPU (idf_prep_u8)
                     from . import ops

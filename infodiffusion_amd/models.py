@@ -283,6 +283,23 @@ def _schedule(args, device):
     return alpha_bars, betas, alphas, alpha_prev_bars
 
 
+def _draw_idx(model, n):
+    """models.py:701 / 754 draw the timesteps on the CPU and copy them over; under stream capture the draw must stay
+    on the device (a blocking pageable H2D copy is not capturable)."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return torch.randint(0, len(model.alpha_bars), (n,), device=model.device)
+    return torch.randint(0, len(model.alpha_bars), (n,)).to(device=model.device)
+
+
+def _kl_capacity(model, args, curr_epoch):
+    """clamp(C_max / epochs * curr_epoch, 0, C_max) as a device scalar (models.py:662-671): the persistent scalar
+    `set_epoch` maintains; set here too when the caller did not (eager use, not under capture)."""
+    if getattr(model, '_C_dev', None) is None or (getattr(model, '_C_epoch', None) != curr_epoch
+                                                  and not torch.cuda.is_current_stream_capturing()):
+        model.set_epoch(args, curr_epoch)
+    return model._C_dev
+
+
 class InfoDiff(nn.Module):
     """models.py:605-723."""
 
@@ -312,10 +329,17 @@ class InfoDiff(nn.Module):
         self.encoder.ctx.act_dtype = dtype
 
     def _draw_idx(self, n):
-        # models.py:701 draws on the CPU; under stream capture the draw must stay on the device
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            return torch.randint(0, len(self.alpha_bars), (n,), device=self.device)
-        return torch.randint(0, len(self.alpha_bars), (n,)).to(device=self.device)
+        return _draw_idx(self, n)
+
+    def set_epoch(self, args, curr_epoch):
+        """KL capacity C of this epoch (models.py:662-671, --use_C) into the device scalar the loss reads: a replayed
+        hipGraph picks up the new value without a re-capture.  Call outside stream capture (the trainer does)."""
+        if getattr(args, 'use_C', False):
+            c = min(max(float(args.C_max) / args.epochs * curr_epoch, 0.0), float(args.C_max))
+            if getattr(self, '_C_dev', None) is None:
+                self._C_dev = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._C_dev.fill_(c)
+            self._C_epoch = curr_epoch
 
     def loss_fn(self, args, x, idx=None, curr_epoch=0):
         output, epsilon, a, mu, log_var = self.forward(x, idx=idx, get_target=True)
@@ -335,10 +359,7 @@ class InfoDiff(nn.Module):
         def kl_term():
             kld_loss = torch.sum(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
             if args.use_C:
-                self.C_max = torch.FloatTensor([args.C_max]).to(device=self.device)
-                C = torch.clamp(self.C_max / args.epochs * curr_epoch,
-                                torch.FloatTensor([0]).to(device=self.device), self.C_max)
-                return args.kld_weight * (kld_loss - C.squeeze(dim=0)).abs()
+                return args.kld_weight * (kld_loss - _kl_capacity(self, args, curr_epoch)).abs()
             return args.kld_weight * kld_loss
 
         if self.mmd_weight != 0 and self.kld_weight != 0:
@@ -393,7 +414,7 @@ class Diff(nn.Module):
 
     def forward(self, x, idx=None, get_target=False):
         if idx is None:
-            idx = torch.randint(0, len(self.alpha_bars), (x.size(0),)).to(device=self.device)
+            idx = _draw_idx(self, x.size(0))
             epsilon = torch.randn_like(x)
             if self.is_latent:
                 x_tilde = ops.q_sample(x[:, :, None, None], epsilon[:, :, None, None], idx, self._qs_tables,
@@ -428,6 +449,8 @@ class VAE(nn.Module):
         self.encoder.ctx.act_dtype = dtype
         self.decoder.ctx.act_dtype = dtype
 
+    set_epoch = InfoDiff.set_epoch
+
     def loss_fn(self, args, x, curr_epoch=0):
         reconstruction, a_q, mu, log_var = self.forward(x, get_target=True)
         loss = ops.diff_loss(reconstruction, x, x, 1.0, 0.0, 0.0)[0]        # mean((rec - x)^2), models.py:796
@@ -440,10 +463,7 @@ class VAE(nn.Module):
             # a batch MEAN here (models.py:807), unlike InfoDiff's sum
             kld_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
             if args.use_C:
-                self.C_max = torch.FloatTensor([args.C_max]).to(device=self.device)
-                C = torch.clamp(self.C_max / args.epochs * curr_epoch,
-                                torch.FloatTensor([0]).to(device=self.device), self.C_max)
-                loss = loss + args.kld_weight * (kld_loss - C.squeeze(dim=0)).abs()
+                loss = loss + args.kld_weight * (kld_loss - _kl_capacity(self, args, curr_epoch)).abs()
             else:
                 loss = loss + args.kld_weight * kld_loss
         return loss

@@ -454,6 +454,8 @@ class WgradBatch:
                 cls._graph_bufs.append(cls._bufs.pop((taps, mode)))
                 buf[2] = None
             if buf[2] != key:
+                if len(buf) > 5 and buf[5] is not None:
+                    buf[5].synchronize()        # the previous step's copy out of this pinned table has been issued AND done
                 host = buf[0].data_ptr()
                 blk, lds = 0, 0
                 nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
@@ -464,6 +466,13 @@ class WgradBatch:
                     lds = max(lds, nlds.value)
                 buf[1][:n * nb].copy_(buf[0][:n * nb], non_blocking=True)
                 buf[2], buf[3], buf[4] = key, blk, lds
+                if not capturing:               # eager runs can be a step ahead of the GPU: guard the table's next rewrite
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    if len(buf) > 5:
+                        buf[5] = ev
+                    else:
+                        buf.append(ev)
             call('idf_conv_wgrad_bf16_batched', _p(buf[1]), n, buf[3], buf[4], taps, mode, _st())
 
 

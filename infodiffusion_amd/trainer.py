@@ -5,7 +5,10 @@ Eagerly a CelebA step issues ~800 kernel launches from Python and is host-bound 
 graph it runs at the GPU's pace (~12 ms).  The step is captured after two eager warm-up steps (they build
 the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) only
 forward + backward are captured; the all-reduce and the optimizer then run eagerly, as RCCL wants.
-A batch whose shape differs from the captured one (the last, short batch of an epoch) runs eagerly."""
+A batch whose shape differs from the captured one (the last, short batch of an epoch) runs eagerly, after which the
+step is captured afresh (the eager pass re-homes gradients the graph's kernels write).  Objectives whose draws are
+made on the host every step (--prior 10mix / roll: numpy samplers, models.py:654-657) are never captured; the KL
+capacity of --use_C lives in a device scalar refreshed per call, so its schedule needs no re-capture."""
 import sys
 
 import torch
@@ -18,8 +21,10 @@ class GraphedTrainStep:
         self.graph = None
         self.xbuf = None
         self.loss = None          # device scalar of the last step
-        self.epoch = None
         self.seen = 0
+        host_prior = getattr(args, 'prior', 'regular') != 'regular' and getattr(args, 'mmd_weight', 0) != 0
+        if host_prior:
+            self.use_graph = False
 
     def _fwd_bwd(self, x, epoch):
         loss = self.model.loss_fn(args=self.args, x=x, curr_epoch=epoch)
@@ -37,9 +42,11 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), dtype=torch.float32, device=x.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        self._warm_done = False
         with torch.cuda.stream(side):               # one step on a side stream: private-pool warm-up
             self.loss.copy_(self._fwd_bwd(self.xbuf, epoch))
             self._tail()
+        self._warm_done = True
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -49,33 +56,57 @@ class GraphedTrainStep:
             self.loss.copy_(self._fwd_bwd(self.xbuf, epoch))
             if self.sync is None:
                 self._tail()
-        self.graph, self.epoch = g, epoch
+        self.graph = g
+
+    def _all_ranks_agree(self, ok):
+        """Under data parallelism every rank must take the same path (a rank that replays and a rank that steps
+        eagerly issue different numbers of collectives): capture counts only if it worked everywhere."""
+        if self.sync is None or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.loss.device if self.loss is not None else 'cuda')
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
 
     def __call__(self, x, epoch=0):
         """One optimisation step on batch x; returns the loss as a device scalar (no host sync)."""
         self.seen += 1
-        # the KL capacity schedule (models.py:662-671, --use_C) bakes the epoch into the graph: re-capture
-        epoch_baked = getattr(self.args, 'use_C', False) and getattr(self.args, 'kld_weight', 0) != 0
-        if self.graph is not None and epoch_baked and epoch != self.epoch:
-            self.graph = None
+        if hasattr(self.model, 'set_epoch'):
+            self.model.set_epoch(self.args, epoch)        # --use_C: the KL capacity's device scalar (no re-capture)
         if (self.use_graph and self.graph is None and self.seen > self.warmup
                 and (self.xbuf is None or x.shape == self.xbuf.shape)):
+            stepped = False
             try:
                 self._capture(x, epoch)
-                # the capture's warm-up pass WAS this batch's optimisation step (capturing itself executes nothing):
-                # replaying now would train on the batch a second time
-                return self.loss
+                stepped, ok = True, True
             except Exception as e:  # noqa: BLE001
+                # _capture's warm-up pass is a full optimisation step: if the failure came after it, this batch has
+                # been trained on already
+                stepped = self.loss is not None and self.xbuf is not None and self.xbuf.shape == x.shape and \
+                    getattr(self, '_warm_done', False)
+                ok = False
                 print('graph capture failed (%s: %s); training eagerly' % (type(e).__name__, str(e)[:200]),
                       file=sys.stderr)
-                self.use_graph, self.graph = False, None
                 torch.cuda.synchronize()
+            if not self._all_ranks_agree(ok):
+                self.use_graph, self.graph = False, None
+            if stepped:
+                # the capture's warm-up pass WAS this batch's optimisation step (capturing itself executes nothing):
+                # replaying / stepping now would train on the batch a second time
+                return self.loss
         if self.graph is not None and x.shape == self.xbuf.shape:
             self.xbuf.copy_(x)
             self.graph.replay()
             if self.sync is not None:
                 self._tail()
             return self.loss
+        had_graph = self.graph is not None
         loss = self._fwd_bwd(x, epoch)
         self._tail()
+        if had_graph:
+            # this eager step dropped the `.grad` tensors that live in the graph's private pool and installed its own
+            # (gradients outside the arena), and re-keyed the optimizer's chunk table: the graph would now write
+            # buffers nobody reads.  Capture afresh at the next full batch.
+            self.graph = None
+            if hasattr(self.opt, '_key'):
+                self.opt._key = None
         return loss

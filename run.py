@@ -264,13 +264,17 @@ def evaluate(args):
             np.save(os.path.join(out_root, sub, 'sample-%06d.npy' % n), img.cpu().numpy())
         print('DONE')
     elif args.mode == 'save_latent':
-        all_a = []
-        for data in get_dataset(args, shape, dev, rank, world):
-            with torch.no_grad():
-                a, _, mu, _ = model.encoder(data[0].to(dev))
-            all_a.append((mu if args.kld_weight != 0 else a).cpu().numpy())
-        np.savez('%s_%s_latent' % (args.model, generate_exp_string(args).replace('.', '_')),
-                 all_a=np.concatenate(all_a), all_attr=np.zeros(len(all_a)))
+        # one file for the whole dataset (reference run.py:415-443): rank 0 encodes all of it, unsharded
+        if rank == 0:
+            all_a, all_attr = [], []
+            for data in get_dataset(args, shape, dev, 0, 1):
+                with torch.no_grad():
+                    a, _, mu, _ = model.encoder(data[0].to(dev))
+                all_a.append((mu if args.kld_weight != 0 else a).cpu().numpy())
+                all_attr.append(np.asarray(data[1]))
+            all_a = np.concatenate(all_a)
+            np.savez('%s_%s_latent' % (args.model, generate_exp_string(args).replace('.', '_')),
+                     all_a=all_a, all_attr=np.concatenate(all_attr).reshape(len(all_a), -1).squeeze(-1))
     elif args.mode in ('interpolate', 'disentangle', 'latent_quality'):
         _latent_edit(args, model, dev, shape, out_root, rank, world)
     elif args.mode == 'plot_latent':
@@ -278,8 +282,10 @@ def evaluate(args):
         import matplotlib
         matplotlib.use('Agg')
         import matplotlib.pyplot as plt
+        if rank != 0:
+            return
         all_a, all_attr = [], []
-        for data in get_dataset(args, shape, dev, rank, world):
+        for data in get_dataset(args, shape, dev, 0, 1):
             with torch.no_grad():
                 a, _, mu, _ = model.encoder(data[0].to(dev))
             use_mu = args.kld_weight != 0 and args.mmd_weight == 0

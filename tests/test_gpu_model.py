@@ -735,6 +735,68 @@ def test_graphed_train_step_replays_and_follows_lr_changes():
     assert np.isfinite(float(step(short, 0)))
 
 
+def test_graphed_train_step_other_objectives_and_short_batches():
+    """The capture paths the InfoDiff/regular-prior tests do not reach: (1) the latent Diff model (its timestep draw
+    used to be a CPU draw + blocking copy: not capturable); (2) --use_C: the KL capacity follows the epoch through
+    a replayed graph (device scalar, no re-capture) exactly as the eager loss does; (3) a short batch after capture
+    runs eagerly and the step is captured afresh afterwards, still training; (4) a host-drawn prior is never captured."""
+    import numpy as np
+    import oracle.infodiff_oracle as O
+    from infodiffusion_amd.models import Diff
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    # (1) latent denoiser
+    cfgl = O.Cfg(a_dim=32, is_latent=True, diffusion_steps=1000, input_size=32, mode='train_latent_ddim')
+    ml = Diff(args_of(cfgl), DEV, (1, 32, 32)).train()
+    optl = FusedClipAdamW(ml.parameters(), lr=1e-3, weight_decay=0.0)
+    stepl = GraphedTrainStep(ml, args_of(cfgl), optl)
+    xl = torch.randn(16, 32, device=DEV)
+    ll = [float(stepl(xl, 0)) for _ in range(6)]
+    assert stepl.graph is not None and all(np.isfinite(ll)) and len(set(ll)) == len(ll)
+    # (2) KL capacity schedule through a replayed graph == eager
+    cfg = O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.0, kld_weight=0.01, use_C=True, C_max=25.0, epochs=20)
+
+    def run(graph):
+        model, args, sd = make_infodiff(cfg, DEV, 'fp32', 'manifest_fmnist_kld')
+        model.eval()
+        opt = FusedClipAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
+        step = GraphedTrainStep(model, args_of(cfg), opt, use_graph=graph)
+        x = gold('model_fmnist_kld')['x'].to(DEV)
+        out = []
+        for k, epoch in enumerate([0, 0, 0, 0, 5, 5, 12, 19]):
+            torch.manual_seed(100)                      # same host draws; the graph's device draws differ -> compare trend
+            out.append(float(step(x, epoch)))
+        return out, step
+    eager, _ = run(False)
+    graphed, st = run(True)
+    assert st.graph is not None
+    # |KL - C| changes with the epoch: the replayed graph must follow (losses at epochs 0 / 5 / 12 / 19 differ markedly)
+    for seq in (eager, graphed):
+        assert abs(seq[4] - seq[3]) > 1e-3 and abs(seq[6] - seq[5]) > 1e-3 and abs(seq[7] - seq[6]) > 1e-3, seq
+    # (3) short batch -> eager -> re-capture, (4) host prior never captured
+    cfg3 = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    model, args, sd = make_infodiff(cfg3, DEV, torch.bfloat16, 'manifest_fmnist')
+    model.train()
+    opt = FusedClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    step = GraphedTrainStep(model, args, opt)
+    x = gold('model_fmnist')['x'].to(DEV)
+    w = model.backbone.head.weight
+    for _ in range(4):
+        step(x, 0)
+    assert step.graph is not None
+    assert np.isfinite(float(step(x[:2], 0))) and step.graph is None      # eager, graph dropped
+    n0 = float(w.detach().float().norm())
+    l = [float(step(x, 0)) for _ in range(3)]
+    assert step.graph is not None and all(np.isfinite(l))                  # captured afresh
+    assert float(w.detach().float().norm()) != n0                          # and still training
+    model.zero_grad(set_to_none=True)
+    a10 = args_of(cfg3, act_dtype='bf16', prior='10mix', batch_size=x.shape[0])
+    step10 = GraphedTrainStep(model, a10, opt)
+    for _ in range(4):
+        assert np.isfinite(float(step10(x, 0)))
+    assert step10.graph is None and not step10.use_graph
+
+
 @pytest.mark.parametrize('tag,kw', [('fmnist_vae', dict(a_dim=32, mmd_weight=0.1)),
                                     ('fmnist_vae_kld', dict(a_dim=32, mmd_weight=0.0, kld_weight=0.01))])
 def test_vae_baseline_vs_reference(tag, kw):

@@ -377,6 +377,7 @@ def main():
         else None
     if sync is not None:
         sync.broadcast_parameters()
+        model.attach_grad_sync(sync)      # backbone slice of the exchange overlaps the encoder's backward pass
 
     g = torch.Generator(device='cpu')
     g.manual_seed(64 + rank)
@@ -405,6 +406,7 @@ def main():
 
     graph = None
     used_graph = False
+    sync_in_graph = sync is not None    # the exchange (side stream, RCCL) and the optimizer are captured too
     # warm-up (eager) -- also builds allocator pools and weight shadows
     for i in range(max(2, a.warmup if not a.graph else 3)):
         step_eager(i)
@@ -420,10 +422,22 @@ def main():
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
             # thread_local: RCCL's watchdog thread keeps querying events while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                fwd_bwd()
-                if sync is None:
+            try:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    fwd_bwd()
                     tail()
+            except Exception as e:  # noqa: BLE001
+                if sync is None:
+                    raise
+                if rank == 0:
+                    print('capture with the gradient exchange failed (%s: %s); capturing forward + backward only'
+                          % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+                torch.cuda.synchronize()
+                sync_in_graph = False
+                graph = torch.cuda.CUDAGraph()
+                opt.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    fwd_bwd()
             used_graph = True
         except Exception as e:  # noqa: BLE001
             if rank == 0:
@@ -435,7 +449,7 @@ def main():
         if graph is not None:
             xbuf.copy_(pool[i % 8])
             graph.replay()
-            if sync is not None:
+            if sync is not None and not sync_in_graph:
                 tail()
         else:
             step_eager(i)
@@ -476,6 +490,8 @@ def main():
                                'train step, random-pixel batches, random-init weights' % a.a_dim,
                    'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                    'parallelism': 'dp%d' % world, 'hipgraph': used_graph,
+                   'exchange': None if sync is None else ('in graph, backbone slice overlapped with the encoder backward'
+                                                          if (used_graph and sync_in_graph) else 'eager after backward'),
                    'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW',
                    'last_grad_norm': None if gnorm is None else round(gnorm, 4)},
     }

@@ -15,6 +15,13 @@ conv / GroupNorm gradient the kernels accumulated in place) need no packing at a
 buffer is all-reduced in place as one collective.  Parameters that never receive a gradient (the dead `crossattn.*`
 weights, `encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are
 skipped.
+
+Overlap with backward (`attach`): the backbone's backward ends before the encoder's begins (the encoder ran first
+in the forward pass), so the arena is cut at the backbone / encoder boundary and the backbone slice is all-reduced on
+the side stream from a hook on the latent `a` -- the moment its gradient is complete -- while the encoder's backward
+pass still runs; the encoder slice and the few stand-alone gradients follow at the end of backward.  The collectives
+sit on a side stream and are capturable (RCCL all-reduce inside a hipGraph replays correctly on this stack), so the
+whole data-parallel step -- exchange and optimizer included -- is one graph.
 """
 import torch
 import torch.distributed as dist
@@ -41,6 +48,50 @@ class GradSync:
         self._side = None
         self._plan_key = None
         self._plan = None       # [(flat buffer, [views shaped/strided like the grads], [grad indices])]
+        self._cut = None        # arena offset (floats) where the early slice ends; None: no early slice
+        self._early_done = False
+
+    # ---------------------------------------------------------------- overlap with backward
+    def attach(self, early_module):
+        """Cut the arena after `early_module`'s parameters (the sub-network whose backward pass ends first) and let
+        `early_module`'s owner trigger `reduce_early()` when that backward has ended.  Returns True when the arena
+        layout allows it (the early parameters occupy a prefix of the arena)."""
+        from .grad_arena import slot_of
+        if self.arena is None or self.arena.flat is None:
+            return False
+        early = {id(p) for p in early_module.parameters()}
+        hi_early, lo_rest = 0, self.arena.flat.numel()
+        for p in self.params:
+            sl = slot_of(p)
+            if sl is None or sl.arena is not self.arena:
+                continue
+            off = sl.view.storage_offset()
+            if id(p) in early:
+                hi_early = max(hi_early, off + p.numel())
+            else:
+                lo_rest = min(lo_rest, off)
+        if hi_early == 0 or hi_early > lo_rest:
+            return False
+        self._cut = lo_rest
+        return True
+
+    @torch.no_grad()
+    def reduce_early(self):
+        """All-reduce the early slice of the arena on the side stream (everything enqueued so far on the current
+        stream has produced it); the rest of backward keeps running on the current stream."""
+        if self._cut is None or self._early_done or (self.world == 1 and not self.force):
+            return
+        flat = self.arena.flat
+        if not flat.is_cuda:
+            self._reduce_mean(flat[:self._cut])
+        else:
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._reduce_mean(flat[:self._cut])
+        self._early_done = True
 
     @torch.no_grad()
     def broadcast_parameters(self, src=0):
@@ -107,6 +158,9 @@ class GradSync:
             # ONE collective over the whole arena: nothing is left to overlap with once backward has ended, and a
             # ring over point-to-point xGMI links is per-link bound -- fewer, larger messages
             flat = self.arena.flat
+            if self._early_done:                 # the early slice is already on the wire (reduce_early)
+                flat = flat[self._cut:]
+                self._early_done = False
             if use_side:
                 self._side.wait_stream(cur)
                 with torch.cuda.stream(self._side):

@@ -328,6 +328,12 @@ class InfoDiff(nn.Module):
         self.backbone.ctx.act_dtype = dtype
         self.encoder.ctx.act_dtype = dtype
 
+    def attach_grad_sync(self, sync):
+        """Data parallel: overlap the backbone's share of the gradient exchange with the encoder's backward pass
+        (dist.GradSync.attach).  Returns whether the overlap is active."""
+        self._dp_sync = sync if (sync is not None and sync.attach(self.backbone)) else None
+        return self._dp_sync is not None
+
     def _draw_idx(self, n):
         return _draw_idx(self, n)
 
@@ -384,7 +390,19 @@ class InfoDiff(nn.Module):
         else:
             a_q = a
         use_q = self.kld_weight != 0     # models.py:714-721
-        output = self.backbone(x_tilde, idx, a_q if use_q else a)
+        lat = a_q if use_q else a
+        sync = getattr(self, '_dp_sync', None)
+        if sync is not None and torch.is_grad_enabled() and lat.requires_grad:
+            # data parallel: the gradient of the latent is complete exactly when the backbone's backward pass has
+            # ended -- launch the backbone's deferred weight gradients and put its slice of the gradient arena on
+            # the wire while the encoder's backward pass runs (dist.GradSync.attach)
+            def _early(grad, sync=sync):
+                ops.WgradBatch.flush()
+                sync.reduce_early()
+                return None
+            lat = lat.view_as(lat)
+            lat.register_hook(_early)
+        output = self.backbone(x_tilde, idx, lat)
         return (output, epsilon, a, mu, log_var) if get_target else output
 
 

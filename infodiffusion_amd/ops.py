@@ -454,8 +454,10 @@ class WgradBatch:
                 cls._graph_bufs.append(cls._bufs.pop((taps, mode)))
                 buf[2] = None
             if buf[2] != key:
-                if len(buf) > 5 and buf[5] is not None:
+                if not capturing and len(buf) > 5 and buf[5] is not None:
                     buf[5].synchronize()        # the previous step's copy out of this pinned table has been issued AND done
+                    # (under capture nothing may be synchronised -- and nothing needs to be: the capture follows a
+                    # device-wide synchronisation, and the pair is retired to the graph)
                 host = buf[0].data_ptr()
                 blk, lds = 0, 0
                 nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)

@@ -25,6 +25,9 @@ class GraphedTrainStep:
         host_prior = getattr(args, 'prior', 'regular') != 'regular' and getattr(args, 'mmd_weight', 0) != 0
         if host_prior:
             self.use_graph = False
+        self.sync_in_graph = sync is not None      # RCCL collectives on a side stream are capturable on this stack
+        if sync is not None and hasattr(model, 'attach_grad_sync'):
+            model.attach_grad_sync(sync)
 
     def _fwd_bwd(self, x, epoch):
         loss = self.model.loss_fn(args=self.args, x=x, curr_epoch=epoch)
@@ -54,7 +57,7 @@ class GraphedTrainStep:
         # thread_local: RCCL's watchdog thread keeps querying events while this thread captures
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             self.loss.copy_(self._fwd_bwd(self.xbuf, epoch))
-            if self.sync is None:
+            if self.sync is None or self.sync_in_graph:
                 self._tail()
         self.graph = g
 
@@ -84,6 +87,16 @@ class GraphedTrainStep:
                 stepped = self.loss is not None and self.xbuf is not None and self.xbuf.shape == x.shape and \
                     getattr(self, '_warm_done', False)
                 ok = False
+                if self.sync is not None and self.sync_in_graph:
+                    # retry once with the exchange and the optimizer outside the graph
+                    self.sync_in_graph = False
+                    print('graph capture with the gradient exchange failed (%s: %s); retrying with forward + '
+                          'backward only' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+                    torch.cuda.synchronize()
+                    self.seen -= 1
+                    if stepped:
+                        return self.loss
+                    return self.__call__(x, epoch)
                 print('graph capture failed (%s: %s); training eagerly' % (type(e).__name__, str(e)[:200]),
                       file=sys.stderr)
                 torch.cuda.synchronize()
@@ -96,7 +109,7 @@ class GraphedTrainStep:
         if self.graph is not None and x.shape == self.xbuf.shape:
             self.xbuf.copy_(x)
             self.graph.replay()
-            if self.sync is not None:
+            if self.sync is not None and not self.sync_in_graph:
                 self._tail()
             return self.loss
         had_graph = self.graph is not None

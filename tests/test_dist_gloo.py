@@ -49,7 +49,25 @@ def _worker(rank, world, port, q):
             v.copy_(g)
             p.grad = v
     sync2.all_reduce_grads()
-    res = {'params': [p.detach().tolist() for p in net.parameters()],
+    # third exchange: the arena cut in two slices (early module = net[0]); the early slice goes first, as the
+    # hook in InfoDiff.forward triggers it, the rest at the end
+    for p, g in zip(plist, local):
+        p.grad = None
+    arena.zero()
+    sync3 = GradSync(model, world, bucket_bytes=256, arena=arena)
+    cut_ok = sync3.attach(net[0])
+    for p, g in zip(plist, local):
+        if p is plist[1]:
+            p.grad = g.clone()
+        else:
+            v = slot_of(p).take()
+            v.copy_(g)
+            p.grad = v
+    sync3.reduce_early()
+    early_first = [p.grad.tolist() for p in plist]      # after the early slice only
+    sync3.all_reduce_grads()
+    res = {'cut_ok': cut_ok, 'early_first': early_first, 'avg_sliced': [p.grad.tolist() for p in plist],
+           'params': [p.detach().tolist() for p in net.parameters()],
            'local': [t.tolist() for t in local], 'avg': avg1,
            'avg_arena': [p.grad.tolist() for p in plist],
            'in_arena': [arena.holds(p.grad) for p in plist],
@@ -83,5 +101,13 @@ def test_grad_allreduce_world2():
         la, lb, ga, gb = T(la), T(lb), T(ga), T(gb)
         assert torch.allclose(ga, (la + lb) / 2, atol=1e-7) and torch.equal(ga, gb)
     assert a['in_arena'] == [True, False, True, True]
+    # sliced exchange: same averages; after the early slice alone only net[0].weight (its bias is the stand-alone
+    # gradient in this set-up) has been averaged
+    assert a['cut_ok'] and b['cut_ok']
+    for la, lb, ga, gb in zip(a['local'], b['local'], a['avg_sliced'], b['avg_sliced']):
+        la, lb, ga, gb = T(la), T(lb), T(ga), T(gb)
+        assert torch.allclose(ga, (la + lb) / 2, atol=1e-7) and torch.equal(ga, gb)
+    assert torch.allclose(T(a['early_first'][0]), (T(a['local'][0]) + T(b['local'][0])) / 2, atol=1e-7)
+    assert torch.equal(T(a['early_first'][2]), T(a['local'][2]))          # late slice untouched so far
     assert a['dead_none'] and b['dead_none']
     assert a['shard'] == (0, 5) and b['shard'] == (5, 10)

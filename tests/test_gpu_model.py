@@ -773,10 +773,10 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange():
         assert st.graph is not None and st.sync_in_graph
         # the first step must agree closely; later steps drift apart like two runs of the SAME configuration do (fp32
         # atomic order in the weight gradients feeding bf16 training: 0.3 % on the loss, a few % on the norm by step 5)
-        assert abs(ref[0][0] - got[0][0]) <= 1e-4 * abs(ref[0][0]) and abs(ref[0][1] - got[0][1]) <= 1e-3 * ref[0][1]
-        for (l0, n0), (l1, n1) in zip(ref, got):
-            assert abs(l0 - l1) <= 1.5e-2 * abs(l0) and abs(n0 - n1) <= 0.12 * abs(n0), (ref, got)
-        assert ref[-1][0] < ref[0][0]           # it trains
+        for k, (tl, tn) in enumerate([(1e-4, 1e-3), (5e-3, 3e-2), (2e-2, 0.15), (3e-2, 0.25), (4e-2, 0.4)]):
+            (l0, n0), (l1, n1) = ref[k], got[k]
+            assert abs(l0 - l1) <= tl * abs(l0) and abs(n0 - n1) <= tn * abs(n0), (k, ref, got)
+        assert ref[-1][0] < ref[0][0] and got[-1][0] < got[0][0]           # both train
     finally:
         if own_group:
             dist.destroy_process_group()

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
                                                      float* __restrict__ dfilm_a, float* __restrict__ dgb,
                                                      float* __restrict__ dgam_acc, float* __restrict__ dbet_acc, int HW, int C,
                                                      int CS, int vs, int act, const uint64_t* seed, uint32_t salt, uint32_t thr,
-                                                     float dscale) {
+                                                     float dscale, int pre) {
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NT = blockDim.x, nw = NT >> 6, cpg = C / G, GS = CS / cpg;
@@ -534,6 +534,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   constexpr int NV = KEEP > 0 ? KEEP : (KEEP < 0 ? SNV_MAX : SNV);
   uint4 xr[KEEP < 0 ? 1 : NV];  // packed x stays in registers (KEEP < 0: nothing kept, x and dA are re-read)
   float duk[KEEP > 0 ? KEEP : 1][VE];
+  uint4 rr[KEEP > 0 ? KEEP : 1];  // KEEP > 0: the residual-branch gradient is fetched with x and dA (one HBM latency, not two)
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     int p = pl + k * lanes;
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       size_t e0 = ((size_t)b * HW + p) * C + c0 + v * VE;
       const uint4 xraw = *reinterpret_cast<const uint4*>(src + ((size_t)b * HW + p) * spitch + sc0);
       if (KEEP >= 0) xr[k] = xraw;
+      if (KEEP > 0 && dres && pre) rr[k] = *reinterpret_cast<const uint4*>(dres + e0);
       float xv[VE], dav[VE], du[VE];
       unpack16<T>(xraw, xv);
       Vec16<T>::load(dA + e0, dav);
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
       for (int e = 0; e < VE; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
       if (dres) {                 // gradient arriving over the block's residual / shortcut branch
         float rv[VE];
-        Vec16<T>::load(dres + e0, rv);
+        if (KEEP > 0 && pre) unpack16<T>(rr[k], rv);
+        else Vec16<T>::load(dres + e0, rv);
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] += rv[e];
       }
@@ -860,10 +863,11 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   static const int keep_env = getenv("IDF_GN_KEEP") ? atoi(getenv("IDF_GN_KEEP")) : 1;
   const int nvt = idf_cdiv((long)HW * sp.VS, sp.NT);             // vectors per thread
   const bool keep = keep_env && nvt <= 4;
+  static const int pre = getenv("IDF_GN_PREFETCH_RES") ? atoi(getenv("IDF_GN_PREFETCH_RES")) : 1;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
                      (const T*)x2, C1, (const T*)dres, (const T*)dres2, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
-                     dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale)
+                     dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale, pre)
   if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else if (nvt > SNV) IDF_GN_BWD(float, -1); else IDF_GN_BWD(float, 0); }
   else { if (keep) IDF_GN_BWD(bf16_t, 4); else if (nvt > SNV) IDF_GN_BWD(bf16_t, -1); else IDF_GN_BWD(bf16_t, 0); }
 #undef IDF_GN_BWD

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
 
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
-            int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0) {
+            int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
+            int tiles_per_block = 0, int min_blocks = 0) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -292,6 +293,13 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
     if (forced > 0) target_blocks = forced;
   }
   int split = idf_cdiv(target_blocks, gx);
+  if (tiles_per_block > 0) {
+    // batched launch: every problem shares the chip, so blocks are sized by WORK (pixel tiles per block) instead of a
+    // per-problem block count -- the fp32-atomic bytes of a problem are split * |dW|, and only the large-image problems
+    // (small dW, many pixels) need many splits
+    split = (p.tiles + tiles_per_block / 2) / tiles_per_block;
+    if (gx * split < min_blocks) split = idf_cdiv(min_blocks, gx);
+  }
   if (split > p.tiles) split = p.tiles;
   if (split < 1) split = 1;
   p.tiles_per_blk = idf_cdiv(p.tiles > 0 ? p.tiles : 1, split);
@@ -349,8 +357,10 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   size_t lds;
   static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
   if (forced > 0) target_blocks = forced;
-  int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 128,
-                   a2, C1);
+  static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 48;
+  static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 48;
+  int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
+                   a2, C1, target_blocks > 0 ? 0 : tpb, minb);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;

@@ -190,8 +190,9 @@ def stats_of(x):
     return gn_partials_raw(x)
 
 
-def conv_gn_ok(x, x2, taps, Cout):
-    """The one-launch GroupNorm-prologue conv (idf_conv_gn_bf16) covers this input."""
+def conv_gn_ok(x, x2, taps, Cout, advice=True):
+    """The one-launch GroupNorm-prologue conv (idf_conv_gn_bf16) covers this input -- and, with `advice`, the library's
+    measured policy (idf_conv_gn_advice) prefers it over the two-launch path at this shape."""
     if not (_GN_FUSE and x.is_cuda and x.dtype == torch.bfloat16):
         return False
     B, C1, H, W = x.shape
@@ -200,7 +201,7 @@ def conv_gn_ok(x, x2, taps, Cout):
         return False
     if taps == 1 and not _CONV1X1:
         return False
-    return conv_tiles(B, H, W, Cin, Cout, S1, taps, 1) > 0 and _gn_advice(B, H, W, Cin, Cout, taps)
+    return conv_tiles(B, H, W, Cin, Cout, S1, taps, 1) > 0 and (not advice or _gn_advice(B, H, W, Cin, Cout, taps))
 
 
 @functools.lru_cache(maxsize=None)

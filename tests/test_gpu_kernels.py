@@ -459,7 +459,7 @@ def test_groupnorm_prologue_conv_one_launch(case):
     res = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL) if Cout % 8 == 0 else None
     wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
     seed = torch.tensor([123456789], dtype=torch.int64, device=DEV) if p_drop else None
-    assert ops.conv_gn_ok(x1, x2, taps, Cout)
+    assert ops.conv_gn_ok(x1, x2, taps, Cout, advice=False)      # coverage, not the policy
     st1, st2 = ops.gn_partials_raw(x1), (ops.gn_partials_raw(x2) if C2 else None)
     y, a, mean, rstd, sc, sh, st = ops.conv_gn_raw(x1, x2, st1, st2, gam, bet, ft, fa, seed, 7, p_drop, act, wf, bias, res,
                                                    Cout, taps, keep_a=keep, keep_coef=keep, want_stats=Cout % 8 == 0)

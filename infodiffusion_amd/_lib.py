@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch ships, not load a second one
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libinfodiff_hip.so')
+# IDF_LIB: another build of the same library (A/B of compile-time variants, tools/build_variant.sh); same no-fallback rule
+LIB_PATH = os.environ.get('IDF_LIB') or os.path.join(HERE, 'libinfodiff_hip.so')
 
 F32, BF16 = 0, 1
 ERR_UNSUPPORTED, ERR_BADARG = 1001, 1002

@@ -118,6 +118,63 @@ __device__ __forceinline__ bool idf_keep_h(uint32_t h, int lane, uint32_t thresh
 __device__ __forceinline__ bool idf_keep(uint64_t seed, uint32_t salt, uint64_t idx, uint32_t thresh16) {
   return idf_keep_h(idf_vec_hash(seed, salt, idx >> 3), (int)(idx & 7), thresh16);
 }
+// act(x * sc + sh) (+ dropout) over one vector of N elements, straight-line.  The conditions are uniform (kernel
+// arguments): resolving them once per VECTOR instead of once per element lets the N exp / rcp chains interleave --
+// with a scalar branch around every element the compiler emits them strictly one after the other.
+// Same operations per element as silu_f / idf_keep_h: results are bit-identical to the element-wise form.
+template <int N, bool SILU, bool DROP>
+__device__ __forceinline__ void idf_act_vec_t(float* v, const float* scv, const float* shv, uint32_t h, int l0,
+                                              uint32_t thr, float dscale) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] = v[e] * scv[e] + shv[e];
+  if (SILU) {
+    float t[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) t[e] = __expf(-v[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) t[e] = __builtin_amdgcn_rcpf(1.0f + t[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = v[e] * t[e];
+    if (DROP) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = idf_keep_h(h, l0 + e, thr) ? v[e] * dscale : 0.f;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void idf_act_vec(float* v, const float* scv, const float* shv, int act, bool drop, uint32_t h,
+                                            int l0, uint32_t thr, float dscale) {
+  if (act == 2) {
+    if (drop) idf_act_vec_t<N, true, true>(v, scv, shv, h, l0, thr, dscale);
+    else idf_act_vec_t<N, true, false>(v, scv, shv, h, l0, thr, dscale);
+  } else {
+    idf_act_vec_t<N, false, false>(v, scv, shv, h, l0, thr, dscale);
+  }
+}
+// backward companion: du = dA * act'(x * sc + sh) (* dropout mask / keep probability)
+template <int N, bool SILU, bool DROP>
+__device__ __forceinline__ void idf_dact_vec_t(const float* dav, const float* xv, const float* scv, const float* shv,
+                                               uint32_t h, int l0, uint32_t thr, float dscale, float* du) {
+  if (SILU) {
+    float u[N], s[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) u[e] = xv[e] * scv[e] + shv[e];
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = __expf(-u[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = __builtin_amdgcn_rcpf(1.0f + s[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) du[e] = dav[e] * (s[e] * (1.0f + u[e] * (1.0f - s[e])));
+    if (DROP) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) du[e] = idf_keep_h(h, l0 + e, thr) ? du[e] * dscale : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) du[e] = dav[e];
+  }
+}
+
 __host__ __device__ __forceinline__ uint32_t idf_drop_thresh(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);
 }

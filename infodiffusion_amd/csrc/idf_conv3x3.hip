@@ -124,6 +124,14 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
 
 // a = act(x * sc + sh) on one 16-byte vector (8 bf16 channels); vec = index of the vector in the dense activated
 // tensor (the dropout key, as idf_groupnorm.hip's gn_apply_kernel / du_vec use it)
+// G = elements activated together (their exp / rcp chains interleave; 8 costs ~10 more live registers than 4)
+#ifndef IDF_DLDS_PRO_G
+#define IDF_DLDS_PRO_G 1
+#endif
+#ifndef IDF_HALO_PRO_G
+#define IDF_HALO_PRO_G 8
+#endif
+template <int G = 8>
 __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8], const float (&shv)[8], int act, bool drop,
                                          uint64_t seedv, uint32_t salt, uint32_t thr, float dscale, uint32_t vec) {
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -132,14 +140,7 @@ __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8],
   for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
   const uint32_t h = drop ? idf_vec_hash(seedv, salt, vec) : 0u;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float u = v[e] * scv[e] + shv[e];
-    if (act == 2) {
-      u = silu_f(u);
-      if (drop) u = idf_keep_h(h, e, thr) ? u * dscale : 0.f;
-    }
-    v[e] = u;
-  }
+  for (int g0 = 0; g0 < 8; g0 += G) idf_act_vec<G>(v + g0, scv + g0, shv + g0, act, drop, h, g0, thr, dscale);
   uint32_t o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
         if (hoff[k] >= 0) {
           const unsigned e0 = DUAL ? (unsigned)(hoff[k] >> 2) * (unsigned)p.Cin + (unsigned)cb
                                    : (unsigned)(hoff[k] + ck * CK);
-          hreg[k] = pro_vec(hreg[k], scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+          hreg[k] = pro_vec<IDF_HALO_PRO_G>(hreg[k], scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
           if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.a_out + e0) = hreg[k];
         }
     }
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
           if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {      // padding pixels stay zero
             uint4* slot = reinterpret_cast<uint4*>(Xs + pix * 64 + swz(pix, tid & 3) * 16);
             const unsigned e0 = (unsigned)(((b * p.H + iy) * W + ix) * p.Cin + cb);
-            const uint4 v = pro_vec(*slot, scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+            const uint4 v = pro_vec<IDF_DLDS_PRO_G>(*slot, scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
             *slot = v;
             if (keep_a && (unsigned)(hy - HALO) < (unsigned)R && (unsigned)(hx - HALO) < (unsigned)W)
               *reinterpret_cast<uint4*>(p.a_out + e0) = v;

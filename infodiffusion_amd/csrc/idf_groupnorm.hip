@@ -155,15 +155,11 @@ __device__ __forceinline__ void du_vec(const float* dav, const float* xv, const 
   constexpr int VE = Elem<T>::VE;
   const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;   // one hash per vector
   const int l0 = (int)(e0 & 7);
-#pragma unroll
-  for (int e = 0; e < VE; ++e) {
-    float d = dav[e];
-    if (act == 2) {
-      float u = xv[e] * scv[e] + shv[e];
-      d *= dsilu_f(u);
-      if (seed) d = idf_keep_h(h, l0 + e, thr) ? d * dscale : 0.f;
-    }
-    du[e] = d;
+  if (act == 2) {
+    if (seed) idf_dact_vec_t<VE, true, true>(dav, xv, scv, shv, h, l0, thr, dscale, du);
+    else idf_dact_vec_t<VE, true, false>(dav, xv, scv, shv, h, l0, thr, dscale, du);
+  } else {
+    idf_dact_vec_t<VE, false, false>(dav, xv, scv, shv, h, l0, thr, dscale, du);
   }
 }
 
@@ -339,15 +335,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     Vec16<T>::load(x + e0, xv);
     const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
     const int l0 = (int)(e0 & 7);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float u = xv[e] * scv[e] + shv[e];
-      if (act == 2) {
-        u = silu_f(u);
-        if (seed) u = idf_keep_h(h, l0 + e, thr) ? u * dscale : 0.f;
-      }
-      xv[e] = u;
-    }
+    idf_act_vec<VE>(xv, scv, shv, act, seed != nullptr, h, l0, thr, dscale);
     Vec16<T>::store(out + e0, xv);
   }
 }
@@ -477,15 +465,7 @@ __global__ __launch_bounds__(1024) void gn_small_fwd(const T* __restrict__ x, co
       const int l0 = (int)(e0 & 7);
       float xv[VE];
       unpack16<T>(xr[k], xv);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        float u = xv[e] * scv[e] + shv[e];
-        if (act == 2) {
-          u = silu_f(u);
-          if (seed) u = idf_keep_h(h, l0 + e, thr) ? u * dscale : 0.f;
-        }
-        xv[e] = u;
-      }
+      idf_act_vec<VE>(xv, scv, shv, act, seed != nullptr, h, l0, thr, dscale);
       Vec16<T>::store(out + e0, xv);
     }
   }

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence on the GPU box into gpurun_out/<tag>_*; copy what should be judged into profiles/.
+# usage: tools/collect_profiles.sh <tag>     (e.g. r02k)
+tag=$1
+export TMPDIR=/tmp
+out=gpurun_out
+rocprofv3 --kernel-trace --stats -d $out/${tag}_p1 -o train -- python3 bench.py --no-cpu-baseline --no-large-batch > $out/${tag}_p1.log 2>&1
+db=$(find $out/${tag}_p1 -name '*results.db' | head -1)
+python tools/step_inventory.py $db 80 > $out/${tag}_step_inventory.txt
+python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv
+tail -1 $out/${tag}_p1.log > $out/${tag}_bench_under_rocprof.json
+rocprofv3 --kernel-trace -d $out/${tag}_p2 -o samp -- python3 tools/run_sampling.py 256 100 2 > $out/${tag}_p2.log 2>&1
+db2=$(find $out/${tag}_p2 -name '*results.db' | head -1)
+python tools/eval_inventory.py $db2 45 > $out/${tag}_sampling_eval_inventory_b256.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_$c -- python3 bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-sampling --no-large-batch > $out/${tag}_$c.log 2>&1
+done
+python tools/pmc_traffic.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_traffic.json
+rm -rf $out/${tag}_p1 $out/${tag}_p2      # the databases are large; the summaries above are what is kept
+ls -la $out | grep ${tag}_

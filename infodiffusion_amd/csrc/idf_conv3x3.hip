@@ -1403,16 +1403,16 @@ extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, 
 // shape, 0 when the pair wins (measured on MI355X, tools/bench_gnconv.py: the prologue's vector work is done once per
 // staged element -- halo rows and every 64-cout tile repeat it -- so it loses where that repetition is large and the
 // stand-alone GroupNorm pass runs near its bandwidth):
-//   maps below 512 pixels at batches below 32768 pixels in all (16^2 / 8^2 levels at B = 32),
+//   (small maps at small batches -- 16^2 / 8^2 at B = 32 -- measure the same either way in the train step: 10.98 vs
+//   10.99 ms over repeated runs on one box; the one-launch form is kept there: 72 fewer launches.  IDF_GN_FUSE_MINPIX=512
+//   restores the pair for them)
 //   two or more cout tiles on >= 1536 pixel-tile blocks (128->128 @32^2 at B = 256: 130 vs 112 us),
 //   ragged cout counts (epsilon / latent heads: 32-cout tiles of 128 pixels) on >= 2^19 pixels (263 vs 167 us).
 extern "C" int idf_conv_gn_advice(int B, int H, int W, int Cin, int Cout, int taps) {
   static const int force = getenv("IDF_GN_FUSE_FORCE") ? atoi(getenv("IDF_GN_FUSE_FORCE")) : -1;
   if (force >= 0) return force;
-  static const int minpix = getenv("IDF_GN_FUSE_MINPIX") ? atoi(getenv("IDF_GN_FUSE_MINPIX")) : 512;
+  static const int minpix = getenv("IDF_GN_FUSE_MINPIX") ? atoi(getenv("IDF_GN_FUSE_MINPIX")) : 0;
   const long M = (long)B * H * W;
-  // small maps at small batches: one 64-pixel tile per block repeats the prologue 1.7x (halo) x the cout tiles on four
-  // waves, against a 5-us one-launch GroupNorm that finds its input in L2 (in-step at B = 32: 17.7 vs 9.9 + 5.7 us)
   if (H * W < minpix && M < 32768) return 0;
   if (taps == 9) {
     if ((Cout & 7) && M >= (1L << 19)) return 0;

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the hot kernels at the CelebA training shapes (B = 32, bf16):
-per-shape time, algorithmic TFLOP/s and GB/s.  Usage: python tools/bench_kernels.py [conv|wgrad|gn|all]"""
+per-shape time, algorithmic TFLOP/s and GB/s.  Usage: python tools/bench_kernels.py [conv|wgrad|gn|all]
+
+HOT numbers: every call of a shape works on the same buffers, which stay L2 / Infinity-Cache resident between calls
+(the largest tensor here is 34 MB against 256 MB of Infinity Cache), so the GB/s columns are cache rates, not HBM
+rates.  The cold counterparts, which bench.py's rooflines are built from: tools/bench_gnbwd.py (GroupNorm backward),
+tools/bench_gnconv.py (GroupNorm + conv, both forms), bench.py's LaunchRecorder (the step's own launches).
+GB/s counts the algorithmic passes: GroupNorm forward = x read + a written (2 passes), backward = x, dA read + dx
+written (3 passes)."""
 import os
 import sys
 
@@ -63,7 +70,7 @@ def main(which):
                 m, r, sc, sh = ops.gn_coef_fwd_raw(x, g, b_, None, None)
                 return ops.gn_apply_raw(x, sc, sh, None, 0, 0.0, 2)
             t = timeit(gn)
-            line += ' gn-fwd %6.1f us %5.0f GB/s' % (t, 3 * x.numel() * 2 / t / 1e3)
+            line += ' gn-fwd %6.1f us %5.0f GB/s' % (t, 2 * x.numel() * 2 / t / 1e3)
             dA = torch.randn_like(x)
             if ops.gn_small_ok(x):
                 _, m, r, sc, sh = ops.gn_fused_fwd_raw(x, g, b_, None, None, None, 0, 0.0, 2)

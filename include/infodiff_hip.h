@@ -199,7 +199,8 @@ int idf_softmax_fwd(void* s, long R, int N, int dtype, void* stream);           
 int idf_softmax_bwd(const void* P, void* dP, long R, int N, int dtype, void* stream);
 
 /* Fused single-head attention of the AttnBlock (modules.py:129-164: bmm, softmax, bmm and their
- * backward) for the shapes idf_attn_fused_ok() accepts (N = 256 tokens, D = C in {64, 128}, bf16):
+ * backward) for the shapes idf_attn_fused_ok() accepts (N = 256 or 64 tokens -- the 16x16 levels and the 8x8 middle
+ * block --, D = C in {64, 128}, bf16):
  * qkv [B, N, 3D] (q | k | v along channels), o [B, N, D], lse [B, N] row logsumexp kept for the
  * backward, dsum [B, N] scratch (row sums of P dP), dqkv [B, N, 3D].  scale = C^-1/2.
  * Scores / probabilities stay in registers; other shapes use idf_bgemm + idf_softmax_*. */

@@ -1,9 +1,10 @@
 // Fused single-head spatial self-attention (modules.py:129-164 of the reference AttnBlock) for the
-// N = 256-token level (16x16), head dim D = C in {64, 128}, bf16 activations:
+// N = 256-token level (16x16) and the N = 64-token middle block (8x8), head dim D = C in {64, 128}, bf16 activations:
 //   forward   O = softmax(Q K^T * scale) V            one launch  (was bmm, softmax, bmm)
 //   backward  dQ, dK, dV                              two launches (was 4 bmm + softmax backward)
 // qkv is the [B, N, 3D] output of the fused q/k/v 1x1 conv (token-major, q | k | v along channels).
 //
+// (below for N = 256; N = 64 is the same kernel with a quarter of the score tiles and one block per image)
 // One block = 64 "row" tokens (16 per wave) against ALL 256 "column" tokens, whose two [256][D]
 // operands sit in LDS for the whole kernel.  The score products take the LDS operand K-contiguous
 // (ds_read_b128) and the row operand from registers; the MFMA result leaves each lane holding, for
@@ -21,13 +22,14 @@
 
 namespace {
 
-constexpr int AN = 256;      // tokens
 constexpr int ANT = 256;     // threads: 4 waves x 16 rows
 
-template <int D> struct ACfg {
+template <int D, int AN = 256> struct ACfg {
   static constexpr int PITCH = D + 16;          // elements; (2D + 32) bytes: tr reads conflict-free
   static constexpr int KS = D / 32;             // k-steps of a score product
   static constexpr int CT = D / 16;             // channel tiles of an output product
+  static constexpr int NT16 = AN / 16;           // 16-column score tiles per row
+  static constexpr int NS32 = AN / 32;           // 32-row k-steps of an output product
   static constexpr size_t LDS = (size_t)2 * AN * PITCH * sizeof(bf16_t) + 2 * AN * sizeof(float);
 };
 
@@ -41,7 +43,7 @@ __device__ __forceinline__ bf16x8_t amk(s16x4_t lo, s16x4_t hi) {
 }
 
 // [256][D] rows of `src` (row pitch ld elements) -> LDS, pitch ACfg<D>::PITCH
-template <int D>
+template <int D, int AN>
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int ld, bf16_t* lds, int tid) {
   constexpr int VPR = D / 8, NV = AN * VPR / ANT;
   uint4 r[NV];
@@ -66,11 +68,11 @@ __device__ __forceinline__ void load_rowfrag(const bf16_t* __restrict__ rows, in
 }
 
 // acc[t][r] = <X[16 t + 4 (lane >> 4) + r], row (lane & 15)>
-template <int D>
-__device__ __forceinline__ void scores(f32x4_t (&acc)[16], const bf16_t* X, const bf16x8_t (&f)[ACfg<D>::KS], int lane) {
+template <int D, int AN>
+__device__ __forceinline__ void scores(f32x4_t (&acc)[AN / 16], const bf16_t* X, const bf16x8_t (&f)[ACfg<D>::KS], int lane) {
   const bf16_t* xb = X + (lane & 15) * ACfg<D>::PITCH + (lane >> 4) * 8;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
+  for (int t = 0; t < AN / 16; ++t) {
     acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < ACfg<D>::KS; ++s) {
@@ -81,9 +83,10 @@ __device__ __forceinline__ void scores(f32x4_t (&acc)[16], const bf16_t* X, cons
 }
 
 // 64 fp32 weights per lane (as `scores` lays them out) -> the 8 B-operand fragments of `outprod`
-__device__ __forceinline__ void pack_w(const f32x4_t (&w)[16], bf16x8_t (&pk)[8]) {
+template <int AN>
+__device__ __forceinline__ void pack_w(const f32x4_t (&w)[AN / 16], bf16x8_t (&pk)[AN / 32]) {
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < AN / 32; ++s) {
     bf16x8_t v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] = (__bf16)w[2 * s][r]; v[4 + r] = (__bf16)w[2 * s + 1][r]; }
@@ -92,13 +95,13 @@ __device__ __forceinline__ void pack_w(const f32x4_t (&w)[16], bf16x8_t (&pk)[8]
 }
 
 // out[c][r] = sum over the 256 LDS rows j of w[j] * X[j][16 c + 4 (lane >> 4) + r]   (for row lane & 15)
-template <int D>
-__device__ __forceinline__ void outprod(f32x4_t (&out)[ACfg<D>::CT], const bf16_t* X, const bf16x8_t (&pk)[8], int lane) {
+template <int D, int AN>
+__device__ __forceinline__ void outprod(f32x4_t (&out)[ACfg<D>::CT], const bf16_t* X, const bf16x8_t (&pk)[AN / 32], int lane) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
   for (int c = 0; c < ACfg<D>::CT; ++c) out[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < AN / 32; ++s) {
     const bf16_t* x0 = X + (32 * s + 4 * g + q) * ACfg<D>::PITCH + 4 * pp;
     const bf16_t* x1 = x0 + 16 * ACfg<D>::PITCH;
 #pragma unroll
@@ -132,7 +135,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // ------------------------------------------------------------------ forward
-template <int D>
+template <int D, int AN>
 __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,40 +144,40 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
   const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
-  stage_rows<D>(base + D, 3 * D, Ks, tid);
-  stage_rows<D>(base + 2 * D, 3 * D, Vs, tid);
+  stage_rows<D, AN>(base + D, 3 * D, Ks, tid);
+  stage_rows<D, AN>(base + 2 * D, 3 * D, Vs, tid);
   bf16x8_t qf[ACfg<D>::KS];
   load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
   __syncthreads();
-  f32x4_t s[16];
-  scores<D>(s, Ks, qf, lane);
+  f32x4_t s[AN / 16];
+  scores<D, AN>(s, Ks, qf, lane);
   float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[t][r] *= scale; mx = fmaxf(mx, s[t][r]); }
   mx = quad_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); sum += s[t][r]; }
   sum = quad_sum(sum);
   const float inv = 1.0f / sum;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[t][r] *= inv;
-  bf16x8_t pk[8];
-  pack_w(s, pk);
+  bf16x8_t pk[AN / 32];
+  pack_w<AN>(s, pk);
   f32x4_t out[ACfg<D>::CT];
-  outprod<D>(out, Vs, pk, lane);
+  outprod<D, AN>(out, Vs, pk, lane);
   store_out<D>(o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
   if (lse && lane < 16) lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
 }
 
 // ------------------------------------------------- backward A: dQ and the row sums  sum_j P dP
-template <int D>
+template <int D, int AN>
 __global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ dsum, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,48 +186,48 @@ __global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
   const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
-  stage_rows<D>(base + D, 3 * D, Ks, tid);
-  stage_rows<D>(base + 2 * D, 3 * D, Vs, tid);
+  stage_rows<D, AN>(base + D, 3 * D, Ks, tid);
+  stage_rows<D, AN>(base + 2 * D, 3 * D, Vs, tid);
   bf16x8_t qf[ACfg<D>::KS], gf[ACfg<D>::KS];
   load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
   load_rowfrag<D>(dO + ((size_t)b * AN + r0) * D, D, lane, gf);
   __syncthreads();
-  f32x4_t p[16], dp[16];
-  scores<D>(p, Ks, qf, lane);
+  f32x4_t p[AN / 16], dp[AN / 16];
+  scores<D, AN>(p, Ks, qf, lane);
   float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[t][r] *= scale; mx = fmaxf(mx, p[t][r]); }
   mx = quad_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[t][r] = __expf(p[t][r] - mx); sum += p[t][r]; }
   sum = quad_sum(sum);
   const float inv = 1.0f / sum;
-  scores<D>(dp, Vs, gf, lane);
+  scores<D, AN>(dp, Vs, gf, lane);
   float dot = 0.f;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[t][r] *= inv; dot += p[t][r] * dp[t][r]; }
   dot = quad_sum(dot);
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[t][r] = p[t][r] * (dp[t][r] - dot);
-  bf16x8_t pk[8];
-  pack_w(p, pk);
+  bf16x8_t pk[AN / 32];
+  pack_w<AN>(p, pk);
   f32x4_t out[ACfg<D>::CT];
-  outprod<D>(out, Ks, pk, lane);
+  outprod<D, AN>(out, Ks, pk, lane);
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D, 3 * D, out, lane, scale);
   if (lane < 16) dsum[(size_t)b * AN + r0 + lane] = dot;
 }
 
 // ------------------------------------------------- backward B: dK and dV (rows = keys)
-template <int D>
+template <int D, int AN>
 __global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
                                                           bf16_t* __restrict__ dqkv, float scale) {
@@ -236,58 +239,83 @@ __global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
   const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
-  stage_rows<D>(base, 3 * D, Qs, tid);
-  stage_rows<D>(dO + (size_t)b * AN * D, D, Gs, tid);
-  Ls[tid] = lse[(size_t)b * AN + tid];
-  Ds[tid] = dsum[(size_t)b * AN + tid];
+  stage_rows<D, AN>(base, 3 * D, Qs, tid);
+  stage_rows<D, AN>(dO + (size_t)b * AN * D, D, Gs, tid);
+  if (tid < AN) {
+    Ls[tid] = lse[(size_t)b * AN + tid];
+    Ds[tid] = dsum[(size_t)b * AN + tid];
+  }
   bf16x8_t kf[ACfg<D>::KS], vf[ACfg<D>::KS];
   load_rowfrag<D>(base + (size_t)r0 * 3 * D + D, 3 * D, lane, kf);
   load_rowfrag<D>(base + (size_t)r0 * 3 * D + 2 * D, 3 * D, lane, vf);
   __syncthreads();
   const int g4 = (lane >> 4) * 4;
-  f32x4_t p[16], dp[16];
-  scores<D>(p, Qs, kf, lane);            // p[t][r]: query 16 t + g4 + r  x  key (lane & 15)
+  f32x4_t p[AN / 16], dp[AN / 16];
+  scores<D, AN>(p, Qs, kf, lane);            // p[t][r]: query 16 t + g4 + r  x  key (lane & 15)
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[t][r] = __expf(p[t][r] * scale - Ls[16 * t + g4 + r]);
-  bf16x8_t pk[8];
+  bf16x8_t pk[AN / 32];
   f32x4_t out[ACfg<D>::CT];
-  pack_w(p, pk);
-  outprod<D>(out, Gs, pk, lane);         // dV = P^T dO
+  pack_w<AN>(p, pk);
+  outprod<D, AN>(out, Gs, pk, lane);         // dV = P^T dO
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + 2 * D, 3 * D, out, lane, 1.0f);
-  scores<D>(dp, Gs, vf, lane);           // dP^T
+  scores<D, AN>(dp, Gs, vf, lane);           // dP^T
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < AN / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[t][r] = p[t][r] * (dp[t][r] - Ds[16 * t + g4 + r]);
-  pack_w(p, pk);
-  outprod<D>(out, Qs, pk, lane);         // dK = dS^T Q
+  pack_w<AN>(p, pk);
+  outprod<D, AN>(out, Qs, pk, lane);         // dK = dS^T Q
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + D, 3 * D, out, lane, scale);
 }
 
-template <int D>
-int set_lds(const void* k) {
-  return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ACfg<D>::LDS);
+template <int D, int AN>
+void raise_lds_once() {       // hipFuncAttributeMaxDynamicSharedMemorySize: once per kernel, not per launch
+  static const int done = [] {
+    const int lds = (int)ACfg<D, AN>::LDS;
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return 1;
+  }();
+  (void)done;
+}
+
+template <int D, int AN>
+void launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, hipStream_t st) {
+  raise_lds_once<D, AN>();
+  const size_t lds = ACfg<D, AN>::LDS;
+  hipLaunchKernelGGL((attn_fwd_kernel<D, AN>), dim3(AN / 64, B), dim3(ANT), lds, st, (const bf16_t*)qkv,
+                     (bf16_t*)o, lse, scale);
+}
+
+template <int D, int AN>
+void launch_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, float scale,
+                hipStream_t st) {
+  raise_lds_once<D, AN>();
+  const dim3 g(AN / 64, B);
+  const size_t lds = ACfg<D, AN>::LDS;
+  hipLaunchKernelGGL((attn_bwd_q_kernel<D, AN>), g, dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                     (bf16_t*)dqkv, dsum, scale);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<D, AN>), g, dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                     lse, dsum, (bf16_t*)dqkv, scale);
 }
 
 }  // namespace
 
-extern "C" int idf_attn_fused_ok(int N, int D, int dtype) { return (N == AN && (D == 64 || D == 128) && dtype == IDF_BF16) ? 1 : 0; }
+extern "C" int idf_attn_fused_ok(int N, int D, int dtype) {
+  return ((N == 256 || N == 64) && (D == 64 || D == 128) && dtype == IDF_BF16) ? 1 : 0;
+}
 
 extern "C" int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int D, float scale, int dtype,
                             void* stream) {
   if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
   if (B == 0) return IDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(AN / 64, B);
-  if (D == 128) {
-    set_lds<128>((const void*)attn_fwd_kernel<128>);
-    hipLaunchKernelGGL(attn_fwd_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (bf16_t*)o, lse, scale);
-  } else {
-    set_lds<64>((const void*)attn_fwd_kernel<64>);
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (bf16_t*)o, lse, scale);
-  }
+  if (N == 256) { if (D == 128) launch_fwd<128, 256>(qkv, o, lse, B, scale, st); else launch_fwd<64, 256>(qkv, o, lse, B, scale, st); }
+  else { if (D == 128) launch_fwd<128, 64>(qkv, o, lse, B, scale, st); else launch_fwd<64, 64>(qkv, o, lse, B, scale, st); }
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -297,23 +325,12 @@ extern "C" int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, f
   if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_bwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
   if (B == 0) return IDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(AN / 64, B);
-  if (D == 128) {
-    set_lds<128>((const void*)attn_bwd_q_kernel<128>);
-    set_lds<128>((const void*)attn_bwd_kv_kernel<128>);
-    hipLaunchKernelGGL(attn_bwd_q_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       (bf16_t*)dqkv, dsum, scale);
-    IDF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<128>, g, dim3(ANT), ACfg<128>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       lse, dsum, (bf16_t*)dqkv, scale);
+  if (N == 256) {
+    if (D == 128) launch_bwd<128, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
+    else launch_bwd<64, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
   } else {
-    set_lds<64>((const void*)attn_bwd_q_kernel<64>);
-    set_lds<64>((const void*)attn_bwd_kv_kernel<64>);
-    hipLaunchKernelGGL(attn_bwd_q_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       (bf16_t*)dqkv, dsum, scale);
-    IDF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, g, dim3(ANT), ACfg<64>::LDS, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       lse, dsum, (bf16_t*)dqkv, scale);
+    if (D == 128) launch_bwd<128, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
+    else launch_bwd<64, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
   }
   IDF_CHECK_LAUNCH();
   return IDF_OK;

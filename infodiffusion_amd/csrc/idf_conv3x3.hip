@@ -16,6 +16,7 @@
 // LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-ed with
 // 2*((row>>2)&1), which makes ds_read_b128 of any 16 consecutive rows conflict-free.
 #include "idf_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -1125,6 +1126,17 @@ inline size_t aux_bytes(const C3P& p, bool pro, int nwaves, int BN) {
   return a > s ? a : s;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is raised once per kernel (per larger request), not on every launch:
+// `have` is a static of the calling launch<...> instantiation, i.e. one per kernel.  (A racing duplicate call is harmless.)
+#define IDF_ENSURE_LDS(kern, bytes)                                                                            \
+  do {                                                                                                         \
+    static std::atomic<size_t> have{64 * 1024};                                                                \
+    if ((size_t)(bytes) > have.load(std::memory_order_relaxed)) {                                             \
+      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      have.store((size_t)(bytes), std::memory_order_relaxed);                                                  \
+    }                                                                                                          \
+  } while (0)
+
 template <int KS, bool PRO = false, bool DUAL = false>
 void launch_dlds(C3P& p, hipStream_t st) {
   const int HALO = KS / 2;
@@ -1135,7 +1147,7 @@ void launch_dlds(C3P& p, hipStream_t st) {
   p.aux_off = (int)lds;
   lds += aux_bytes(p, PRO, 8, 64);
   auto kern = conv_dlds_bf16<KS, PRO, DUAL>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  IDF_ENSURE_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
 }
 
@@ -1148,7 +1160,7 @@ void launch(C3P& p, hipStream_t st) {
   p.aux_off = (int)lds;
   lds += aux_bytes(p, PRO, NWM * 2, BN);
   auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL, PRO>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  IDF_ENSURE_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
 
@@ -1204,7 +1216,7 @@ bool ps_plan(int B, int H, int W, int Cin, int Cout, int KS, bool pro, bool want
 template <int KS, bool DUAL, bool PRO, bool RES>
 void launch_ps_r(C3P& p, const PsPlan& pl, int G, hipStream_t st) {
   auto kern = conv_ps_bf16<KS, DUAL, PRO, RES>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  IDF_ENSURE_LDS(kern, pl.lds);
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), pl.lds, st, p);
 }
 

@@ -146,9 +146,10 @@ def test_dropout_mask_consistency():
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16)])
+@pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (33, 64, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16)])
 def test_attention(B, C, H, dtype):
-    """16x16 bf16 cases run the fused kernels (idf_attn_fwd / idf_attn_bwd), the rest bmm + softmax."""
+    """16x16 and 8x8 bf16 cases (N = 256 / 64 tokens) run the fused kernels (idf_attn_fwd / idf_attn_bwd), the rest
+    bmm + softmax."""
     qkv = rnd(1, B, 3 * C, H, H).to(dtype).float()
     qr = qkv.clone().requires_grad_(True)
     q, k, v = [t.permute(0, 2, 3, 1).reshape(B, H * H, C) for t in torch.chunk(qr, 3, dim=1)]

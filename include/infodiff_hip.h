@@ -111,21 +111,26 @@ int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, 
  * (halo tile in LDS, transposed LDS reads); also accumulates db[n] = sum dy when db != NULL.
  * accumulate = 0: dW / db are zeroed inside first; 1: the kernel adds onto what they hold (the
  * host's gradient arena: every parameter gradient zeroed by ONE memset per step).
+ * Cin / Cout are the operands' channel counts (multiples of 8: the image input and the epsilon / latent-head
+ * outputs are zero-padded by the host); Cin_w / Cout_w (0 = Cin / Cout) are the gradient's: dW is
+ * [Cout_w][taps][Cin_w] and db [Cout_w], so the padded convolutions write the parameter's own gradient layout
+ * (and join the gradient arena and the batched launch like every other conv).
  * Returns IDF_ERR_UNSUPPORTED for shapes it does not cover (use idf_conv2d_wgrad then). */
 int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W, int Cin,
-                        int Cout, int taps, int mode, int accumulate, void* stream);
+                        int Cout, int Cin_w, int Cout_w, int taps, int mode, int accumulate, void* stream);
 
 /* Batched form of the same kernel: ALL weight gradients of a backward pass in one launch per
  * (taps, mode) class (the reference computes them one aten::convolution_backward at a time; they are
  * only read by the optimizer, so the host defers them to the end of backward).  The host fills one
  * table entry per convolution (idf_wgrad_desc_bytes() bytes each; arguments as idf_conv_wgrad_bf16,
  * always accumulating: dW / db pre-zeroed), chaining blk0 = sum of the previous blocks_out, copies
- * the table to device memory and launches it.  target_blocks = grid budget per problem (<= 0:
- * default 128); lds_bytes = max of the entries' lds_out. */
+ * the table to device memory and launches it.  target_blocks = grid budget per problem (<= 0: blocks
+ * are sized by work -- IDF_WGRAD_TPB pixel tiles per block, at least IDF_WGRAD_MINB blocks per problem --
+ * because every problem shares the chip with the others); lds_bytes = max of the entries' lds_out. */
 int idf_wgrad_desc_bytes(void);
 int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy, float* dW,
-                        float* db, int B, int H, int W, int Cin, int Cout, int taps, int mode, int target_blocks,
-                        int blk0, int* blocks_out, int* lds_out);
+                        float* db, int B, int H, int W, int Cin, int Cout, int Cin_w, int Cout_w, int taps, int mode,
+                        int target_blocks, int blk0, int* blocks_out, int* lds_out);
 int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
                                 void* stream);
 

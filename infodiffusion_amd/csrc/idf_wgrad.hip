@@ -34,6 +34,7 @@ struct WgP {
   int tiles;          // B*H/R
   int tiles_per_blk;
   int c_tiles, n_tiles;
+  int Cw, Nw;         // dW is [Nw][taps][Cw] (Cw <= Cin, Nw <= Cout): channels the operands were zero-padded by get no gradient
 };
 
 #ifndef IDF_WGRAD_BLOCKS
@@ -195,11 +196,11 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int c = c0 + wc0 + j * 16 + (lane & 15);
-        if (c >= p.Cin) continue;
+        if (c >= p.Cw) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
-          if (n < p.Cout) atomicAdd(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cin + c, acc[kx][i][j][r]);
+          if (n < p.Nw) atomicAdd(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cw + c, acc[kx][i][j][r]);
         }
       }
     }
@@ -210,7 +211,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
     __syncthreads();
-    if (tid < 64 && n0 + tid < p.Cout) {
+    if (tid < 64 && n0 + tid < p.Nw) {
       float s = 0.f;
       for (int k = 0; k < 32; ++k) s += red[k * 64 + tid];
       atomicAdd(p.db + n0 + tid, s);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
             int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
-            int tiles_per_block = 0, int min_blocks = 0) {
+            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -273,7 +274,10 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: two-source input needs C1 %% 64 == 0 (C1 %d) and stride 1", C1);
   p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
   p.a2 = (const bf16_t*)a2; p.C1 = a2 ? C1 : Cin;
+  if (Cin_w < 0 || Cin_w > Cin || Cout_w < 0 || Cout_w > Cout)
+    IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16: gradient extents %d x %d exceed the operands' %d x %d", Cout_w, Cin_w, Cout, Cin);
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
+  p.Cw = Cin_w > 0 ? Cin_w : Cin; p.Nw = Cout_w > 0 ? Cout_w : Cout;
   p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
   p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
   p.tiles = B * (H / R);
@@ -317,20 +321,21 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
 // outputs) for shapes this kernel does not cover; the caller then uses idf_conv2d_wgrad.
 // dW / db are zeroed inside.
 extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int B, int H, int W,
-                                   int Cin, int Cout, int taps, int mode, int accumulate, void* stream) {
+                                   int Cin, int Cout, int Cin_w, int Cout_w, int taps, int mode, int accumulate,
+                                   void* stream) {
   WgP p;
   int gx, gy;
   size_t lds;
-  int rc = wg_plan(p, gx, gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, 0);
+  int rc = wg_plan(p, gx, gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, 0, nullptr, 0, 0, 0, Cin_w, Cout_w);
   if (rc != IDF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const size_t nW = (size_t)Cout * taps * Cin;
+  const size_t nW = (size_t)p.Nw * taps * p.Cw;
   hipError_t e = hipSuccess;
   if (accumulate) {}                     // dW / db already hold zeros or a running sum (gradient arena)
-  else if (db == dW + nW) e = idf_zero_f32(dW, nW + Cout, st);   // caller packed dW | db: one launch
+  else if (db == dW + nW) e = idf_zero_f32(dW, nW + p.Nw, st);   // caller packed dW | db: one launch
   else {
     e = idf_zero_f32(dW, nW, st);
-    if (e == hipSuccess && db) e = idf_zero_f32(db, (size_t)Cout, st);
+    if (e == hipSuccess && db) e = idf_zero_f32(db, (size_t)p.Nw, st);
   }
   if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: zero fill failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
@@ -348,8 +353,8 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
 extern "C" int idf_wgrad_desc_bytes(void) { return (int)sizeof(WgDesc); }
 
 extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy,
-                                   float* dW, float* db, int B, int H, int W, int Cin, int Cout, int taps, int mode,
-                                   int target_blocks, int blk0, int* blocks_out, int* lds_out) {
+                                   float* dW, float* db, int B, int H, int W, int Cin, int Cout, int Cin_w, int Cout_w,
+                                   int taps, int mode, int target_blocks, int blk0, int* blocks_out, int* lds_out) {
   if (!host_table || index < 0 || !blocks_out || !lds_out) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: null argument");
   if (B <= 0) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: empty batch");
   WgDesc d;
@@ -360,7 +365,7 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 48;
   static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 48;
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
-                   a2, C1, target_blocks > 0 ? 0 : tpb, minb);
+                   a2, C1, target_blocks > 0 ? 0 : tpb, minb, Cin_w, Cout_w);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;

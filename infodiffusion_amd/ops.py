@@ -395,10 +395,16 @@ def _pad_channels(t, mult=8):
     Cp = -(-C // mult) * mult
     if Cp == C:
         return t
-    out = torch.empty((t.shape[0], Cp, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=CL)
-    out.zero_()
-    out[:, :C] = t
-    return out
+    # one launch (cat with a cached block of zeros) instead of a fill and a strided copy
+    key = (t.shape[0], Cp - C, t.shape[2], t.shape[3], t.dtype, t.device)
+    z = _PAD_ZEROS.get(key)
+    if z is None:
+        z = _PAD_ZEROS[key] = torch.zeros(key[:4], dtype=t.dtype, device=t.device).contiguous(memory_format=CL)
+    out = torch.cat([t, z], dim=1)
+    return out if out.is_contiguous(memory_format=CL) else out.contiguous(memory_format=CL)
+
+
+_PAD_ZEROS = {}
 
 
 def _slot_views(w_slot, b_slot, want_bias, shape):
@@ -418,7 +424,7 @@ class WgradBatch:
     backward pass computes them all (`idf_conv_wgrad_bf16_batched`): no per-conv launch, small
     problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
     enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
-    pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1)
+    pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1, Cin_w, Cout_w)
     _bufs = {}         # (taps, mode) -> [pinned host table, device table, key]   (eager: reused)
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
@@ -442,7 +448,7 @@ class WgradBatch:
         capturing = torch.cuda.is_current_stream_capturing()
         for (taps, mode), grp in groups.items():
             n = len(grp)
-            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] + (_p(it[11]), it[12]) for it in grp)
+            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] + (_p(it[11]), it[12], it[13], it[14]) for it in grp)
             buf = cls._bufs.get((taps, mode))
             if buf is None or buf[0].numel() < n * nb:
                 dev = grp[0][0].device
@@ -462,9 +468,10 @@ class WgradBatch:
                 host = buf[0].data_ptr()
                 blk, lds = 0, 0
                 nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
-                for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1) in enumerate(grp):
-                    _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout, taps,
-                                                       mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)), 'idf_wgrad_desc_fill')
+                for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1, Cin_w, Cout_w) in enumerate(grp):
+                    _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout, Cin_w,
+                                                       Cout_w, taps, mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)),
+                               'idf_wgrad_desc_fill')
                     blk += nblk.value
                     lds = max(lds, nlds.value)
                 buf[1][:n * nb].copy_(buf[0][:n * nb], non_blocking=True)
@@ -491,26 +498,23 @@ def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, 
         ap, dyp = _pad_channels(a), _pad_channels(dy)
         Cip, Cop = ap.shape[1], dyp.shape[1]
         if _fast_wgrad_ok(Cip, Cop, Ho, Wo, a.dtype, mode, taps):
-            views = _slot_views(w_slot, b_slot, want_bias, (Cout, Cin, k, k)) if (Cip == Cin and Cop == Cout) else None
+            # the kernel writes the parameter's own [Cout][taps][Cin] layout whatever the operands were padded to
+            views = _slot_views(w_slot, b_slot, want_bias, (Cout, Cin, k, k))
             if views is not None:
                 dW, db = views
                 if defer and WgradBatch.enabled:
                     # slot ADDRESSES, not the tensors: AccumulateGrad adopts a gradient only if nobody else holds it
-                    WgradBatch.add((ap, dyp, _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, None, 0))
+                    WgradBatch.add((ap, dyp, _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, None, 0, Cin, Cout))
                 else:
-                    call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 1,
+                    call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, Cin, Cout, taps, mode, 1,
                          _st())
                 return dW, db
-            nW = Cop * k * k * Cip
-            buf = torch.empty((nW + Cop,), dtype=torch.float32, device=a.device)   # dW | db: one memset
-            dW = buf[:nW].view(Cop, k, k, Cip)
+            nW = Cout * k * k * Cin
+            buf = torch.empty((nW + Cout,), dtype=torch.float32, device=a.device)   # dW | db: one memset
+            dW = buf[:nW].view(Cout, k, k, Cin)
             db = buf[nW:] if want_bias else None
-            call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, taps, mode, 0, _st())
-            dW = dW.permute(0, 3, 1, 2)
-            if Cip != Cin or Cop != Cout:
-                dW = dW[:Cout, :Cin]
-                db = db[:Cout] if db is not None else None
-            return dW, db
+            call('idf_conv_wgrad_bf16', _p(ap), _p(dyp), _p(dW), _p(db), B, Ho, Wo, Cip, Cop, Cin, Cout, taps, mode, 0, _st())
+            return dW.permute(0, 3, 1, 2), db
     dW = conv_wgrad_raw(a, dy, None, None, None, 0, 0.0, mode, taps, 0)
     db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)) if want_bias else None
     return dW, db
@@ -698,7 +702,7 @@ def _defer_or_launch_wgrad(a, dy, w_slot, b_slot, taps, a2=None):
     views = _slot_views(w_slot, b_slot, True, (Cout, Cin, k, k))
     if views is None:
         return None
-    WgradBatch.add((a, dy, _p(views[0]), _p(views[1]), B, H, W, Cin, Cout, taps, S1, a2, Cin1))
+    WgradBatch.add((a, dy, _p(views[0]), _p(views[1]), B, H, W, Cin, Cout, taps, S1, a2, Cin1, Cin, Cout))
     return views
 
 

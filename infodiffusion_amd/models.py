@@ -235,14 +235,18 @@ class Encoder(_UNetSkeleton):
             init.zeros_(fc.bias)
         self._init_tail()
 
-    def forward(self, x):
+    def forward(self, x, want_q=True):
+        """-> (a, a_q, mu, log_var) as models.py:510-516.  want_q=False (the caller does not read a_q: InfoDiff with
+        kld_weight == 0): the reparameterisation noise is still DRAWN -- the reference draws it on every call, so the
+        RNG stream keeps its order -- but a_q is None and its three elementwise launches are skipped."""
         x = self._prep(x)
         h = self._run(x, lambda blk, hh, **kw: blk(hh, **kw))
         h = torch.flatten(h, start_dim=1).float()
         a = ops.linear(h, self.fc_a.weight, self.fc_a.bias)
         mu = ops.linear(a, self.fc_mu.weight, self.fc_mu.bias)
         log_var = ops.linear(a, self.fc_var.weight, self.fc_var.bias)
-        a_q = mu + torch.randn_like(mu) * torch.exp(0.5 * log_var)
+        noise = torch.randn_like(mu)
+        a_q = torch.addcmul(mu, noise, torch.exp(0.5 * log_var)) if want_q else None
         return a, a_q, mu, log_var
 
 
@@ -348,6 +352,8 @@ class InfoDiff(nn.Module):
             self._C_epoch = curr_epoch
 
     def loss_fn(self, args, x, idx=None, curr_epoch=0):
+        if x.is_cuda and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)     # once: q_sample, the encoder and the loss all read NHWC
         output, epsilon, a, mu, log_var = self.forward(x, idx=idx, get_target=True)
         terms = ops.diff_loss(output, epsilon, x, self._rec_c0, self._rec_c1, 1.0 / args.diffusion_steps)
         loss = terms[0] + terms[1]
@@ -369,9 +375,9 @@ class InfoDiff(nn.Module):
             return args.kld_weight * kld_loss
 
         if self.mmd_weight != 0 and self.kld_weight != 0:
-            loss = loss + args.mmd_weight * compute_mmd(prior_samples(a), mu) + kl_term()
+            loss = torch.add(loss, compute_mmd(prior_samples(a), mu), alpha=args.mmd_weight) + kl_term()
         elif args.mmd_weight != 0:
-            loss = loss + args.mmd_weight * compute_mmd(prior_samples(a), a)
+            loss = torch.add(loss, compute_mmd(prior_samples(a), a), alpha=args.mmd_weight)
         elif args.kld_weight != 0:
             loss = loss + kl_term()
         return loss
@@ -379,17 +385,17 @@ class InfoDiff(nn.Module):
     def forward(self, x, idx=None, a=None, get_target=False):
         if idx is None:
             idx = self._draw_idx(x.size(0))
-            epsilon = torch.randn_like(x)
+            epsilon = torch.randn_like(x, memory_format=torch.channels_last if x.dim() == 4 else torch.preserve_format)
             x_tilde = ops.q_sample(x, epsilon, idx, self._qs_tables, self.act_dtype)
         else:
             if not torch.is_tensor(idx):
                 idx = torch.full((x.size(0),), int(idx), dtype=torch.long, device=self.device)
             x_tilde = x
+        use_q = self.kld_weight != 0     # models.py:714-721
         if a is None:
-            a, a_q, mu, log_var = self.encoder(x)
+            a, a_q, mu, log_var = self.encoder(x, want_q=use_q)
         else:
             a_q = a
-        use_q = self.kld_weight != 0     # models.py:714-721
         lat = a_q if use_q else a
         sync = getattr(self, '_dp_sync', None)
         if sync is not None and torch.is_grad_enabled() and lat.requires_grad:

@@ -531,7 +531,7 @@ def main():
         if 'attn' in fam:
             n, ms, fl, by = fam['attn']
             ach = fl / (ms * 1e-3) / 1e12
-            out['roofline_attn'] = {'kernel': 'attn_fwd_kernel (N = 256 tokens, d = 128: QK^T, softmax, PV in one launch)',
+            out['roofline_attn'] = {'kernel': 'attn_fwd_kernel (N = 256 tokens at 16x16, N = 64 at the 8x8 middle block; d = 128: QK^T, softmax, PV in one launch)',
                                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                     'frac': round(ach / peak, 4), 'traffic': pmc_traffic_r02(['attn_fwd_kernel']),
                                     'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),

@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats -d $out/${tag}_p1 -o train -- python3 bench.py 
 db=$(find $out/${tag}_p1 -name '*results.db' | head -1)
 python tools/step_inventory.py $db 80 > $out/${tag}_step_inventory.txt
 python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv
-tail -1 $out/${tag}_p1.log > $out/${tag}_bench_under_rocprof.json
+grep "\"metric\"" $out/${tag}_p1.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 rocprofv3 --kernel-trace -d $out/${tag}_p2 -o samp -- python3 tools/run_sampling.py 256 100 2 > $out/${tag}_p2.log 2>&1
 db2=$(find $out/${tag}_p2 -name '*results.db' | head -1)
 python tools/eval_inventory.py $db2 45 > $out/${tag}_sampling_eval_inventory_b256.txt

@@ -305,7 +305,9 @@ def test_wgrad_bf16_batched_matches_single_launches():
     from infodiffusion_amd.grad_arena import GradArena, slot_of
     cases = [(4, 32, 32, 32, 32, 9, ops.S1), (4, 64, 16, 16, 128, 9, ops.S1), (2, 128, 8, 8, 128, 1, ops.S1),
              (4, 32, 32, 32, 64, 9, ops.S1), (4, 128, 8, 8, 128, 9, ops.S1), (2, 64, 16, 16, 64, 9, ops.S2),
-             (2, 64, 16, 16, 64, 9, ops.UP2), (2, 64, 64, 64, 64, 9, ops.S1)]
+             (2, 64, 16, 16, 64, 9, ops.UP2), (2, 64, 64, 64, 64, 9, ops.S1),
+             # operands zero-padded to 8 channels, gradient in the parameter's own extents (image input, epsilon / latent heads)
+             (3, 3, 32, 32, 64, 9, ops.S1), (3, 64, 32, 32, 3, 9, ops.S1), (2, 64, 16, 16, 1, 9, ops.S1)]
     ws, bs, data, refs = [], [], [], []
     for i, (B, Cin, H, W, Cout, taps, mode) in enumerate(cases):
         k = 3 if taps == 9 else 1

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void gn_finalize(const float2* __restrict__ pa
 }
 
 // ------------------------------------------------------------------ backward
+#ifndef IDF_GN_GV
+#define IDF_GN_GV 4
+#endif
 template <typename T>
 __device__ __forceinline__ void du_vec(const float* dav, const float* xv, const float* scv, const float* shv,
                                        int act, const uint64_t* seed, uint32_t salt, uint32_t thr, float dscale,
@@ -155,9 +158,13 @@ __device__ __forceinline__ void du_vec(const float* dav, const float* xv, const 
   constexpr int VE = Elem<T>::VE;
   const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;   // one hash per vector
   const int l0 = (int)(e0 & 7);
+  constexpr int GV = IDF_GN_GV;   // elements whose exp / rcp chains interleave (8 at once costs ~10 registers more: spills at 128)
   if (act == 2) {
-    if (seed) idf_dact_vec_t<VE, true, true>(dav, xv, scv, shv, h, l0, thr, dscale, du);
-    else idf_dact_vec_t<VE, true, false>(dav, xv, scv, shv, h, l0, thr, dscale, du);
+#pragma unroll
+    for (int g0 = 0; g0 < VE; g0 += GV) {
+      if (seed) idf_dact_vec_t<GV, true, true>(dav + g0, xv + g0, scv + g0, shv + g0, h, l0 + g0, thr, dscale, du + g0);
+      else idf_dact_vec_t<GV, true, false>(dav + g0, xv + g0, scv + g0, shv + g0, h, l0 + g0, thr, dscale, du + g0);
+    }
   } else {
     idf_dact_vec_t<VE, false, false>(dav, xv, scv, shv, h, l0, thr, dscale, du);
   }
@@ -504,6 +511,22 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     shv[e] = live ? sh[(size_t)b * C + c0 + v * VE + e] : 0.f;
     s1[e] = s2[e] = 0.f;
   }
+  // the per-channel parameters of the coefficient phase are independent of the statistics: fetch them now, beside the
+  // x / dA loads, instead of after the reduction (one dependent memory round trip less on the small maps, where the
+  // launch is nothing but such round trips)
+  constexpr bool PF = KEEP == 2;              // the small-map variant: registers to spare
+  const bool pf_ok = PF && tid < CS;
+  float pf[7] = {0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+  if (pf_ok) {
+    const int c = c0 + tid, g = c / cpg;
+    pf[0] = mean[b * G + g]; pf[1] = rstd[b * G + g];
+    if (gamma) pf[2] = gamma[c];
+    if (beta) pf[3] = beta[c];
+    if (film_t) { pf[4] = film_t[(size_t)b * ld_t + c]; pf[5] = film_t[(size_t)b * ld_t + C + c]; }
+    if (film_a) pf[6] = film_a[(size_t)b * ld_a + c];
+  }
+  float pg[2] = {0.f, 0.f};
+  if (PF && tid < GS) { pg[0] = mean[b * G + c0 / cpg + tid]; pg[1] = rstd[b * G + c0 / cpg + tid]; }
   const T* src = x;             // two-source input (see gn_small_fwd); dx goes back to the matching tensor
   T* dst = dx;
   int spitch = C, sc0 = c0 + v * VE;
@@ -540,12 +563,16 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     const int c = c0 + cl, g = c / cpg;
     float S1 = 0.f, S2 = 0.f;
     for (int w = 0; w < nw; ++w) { S1 += red[(w * CS + cl) * 2]; S2 += red[(w * CS + cl) * 2 + 1]; }
-    float mu = mean[b * G + g], r = rstd[b * G + g];
+    float mu, r, ga, be, st = 0.f, bt = 0.f, sa = 0.f;
+    if (cl == tid && pf_ok) {       // fetched before the statistics phase (see below): no memory round trip here
+      mu = pf[0]; r = pf[1]; ga = pf[2]; be = pf[3]; st = pf[4]; bt = pf[5]; sa = pf[6];
+    } else {
+      mu = mean[b * G + g]; r = rstd[b * G + g];
+      ga = gamma ? gamma[c] : 1.f; be = beta ? beta[c] : 0.f;
+      if (film_t) { st = film_t[(size_t)b * ld_t + c]; bt = film_t[(size_t)b * ld_t + C + c]; }
+      if (film_a) { sa = film_a[(size_t)b * ld_a + c]; }
+    }
     float D1 = S1, D2 = r * (S2 - mu * S1);
-    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    float st = 0.f, bt = 0.f, sa = 0.f;
-    if (film_t) { st = film_t[(size_t)b * ld_t + c]; bt = film_t[(size_t)b * ld_t + C + c]; }
-    if (film_a) { sa = film_a[(size_t)b * ld_a + c]; }
     float f = (1.f + st) * (1.f + sa);
     float Gf = ga * D2 + be * D1, Ge = D1;
     if (dfilm_t) { dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
@@ -563,7 +590,9 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
     float P1 = 0.f, P2 = 0.f;
     for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) { P1 += pc[c * 2]; P2 += pc[c * 2 + 1]; }
     const int g = c0 / cpg + gl;
-    float mu = mean[b * G + g], r = rstd[b * G + g];
+    float mu, r;
+    if (PF && gl == tid) { mu = pg[0]; r = pg[1]; }
+    else { mu = mean[b * G + g]; r = rstd[b * G + g]; }
     float invN = 1.f / ((float)HW * cpg);
     kk[gl * 2] = -r * r * P2 * invN;
     kk[gl * 2 + 1] = (-r * P1 + r * r * mu * P2) * invN;
@@ -843,13 +872,17 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   static const int keep_env = getenv("IDF_GN_KEEP") ? atoi(getenv("IDF_GN_KEEP")) : 1;
   const int nvt = idf_cdiv((long)HW * sp.VS, sp.NT);             // vectors per thread
   const bool keep = keep_env && nvt <= 4;
+  const bool keep2 = keep && nvt <= 2;      // small maps: half the kept vectors, the coefficient phase's parameters prefetched
   static const int pre = getenv("IDF_GN_PREFETCH_RES") ? atoi(getenv("IDF_GN_PREFETCH_RES")) : 1;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
                      (const T*)x2, C1, (const T*)dres, (const T*)dres2, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
                      dfilm_a, dgb, dgamma_acc, dbeta_acc, HW, C, sp.CS, sp.VS, act, sd, salt, thr, dscale, pre)
-  if (dtype == IDF_F32) { if (keep) IDF_GN_BWD(float, 4); else if (nvt > SNV) IDF_GN_BWD(float, -1); else IDF_GN_BWD(float, 0); }
-  else { if (keep) IDF_GN_BWD(bf16_t, 4); else if (nvt > SNV) IDF_GN_BWD(bf16_t, -1); else IDF_GN_BWD(bf16_t, 0); }
+  if (dtype == IDF_F32) {
+    if (keep2) IDF_GN_BWD(float, 2); else if (keep) IDF_GN_BWD(float, 4); else if (nvt > SNV) IDF_GN_BWD(float, -1); else IDF_GN_BWD(float, 0);
+  } else {
+    if (keep2) IDF_GN_BWD(bf16_t, 2); else if (keep) IDF_GN_BWD(bf16_t, 4); else if (nvt > SNV) IDF_GN_BWD(bf16_t, -1); else IDF_GN_BWD(bf16_t, 0);
+  }
 #undef IDF_GN_BWD
   IDF_CHECK_LAUNCH();
   return IDF_OK;

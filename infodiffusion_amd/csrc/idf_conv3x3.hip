@@ -68,13 +68,25 @@ __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1
 // In-block fold of the GroupNorm statistics + gamma / beta + FiLM pairs into cof[c] = (sc, sh) (the fold of
 // idf_groupnorm.hip's gn_finalize, from per-channel partial sums).  One image per block; the partials are summed
 // in a fixed order, so the result does not depend on which block computes it.
-template <int NT>
+// PF: this thread's first channel's gamma / beta / FiLM values are fetched together with the partials (they do not depend on
+// them): one memory round trip in front of the block's first MFMA instead of two.
+#ifndef IDF_PRO_PF
+#define IDF_PRO_PF true
+#endif
+template <int NT, bool PF = IDF_PRO_PF>
 __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool writer, float* cof, float* chs, int tid) {
   const int C = p.Cin, cpg = C >> 5;
   if (p.cof_in) {                 // folded once per image by pro_coef_kernel: just fetch
     for (int c = tid; c < 2 * C; c += NT) cof[c] = p.cof_in[(size_t)b * 2 * C + c];
     __syncthreads();
     return;
+  }
+  float pf[6] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // gamma, beta, FiLM_t scale / shift, FiLM_a scale / shift of channel `tid`
+  if (PF && tid < C) {
+    if (p.gamma) pf[0] = p.gamma[tid];
+    if (p.beta) pf[1] = p.beta[tid];
+    if (p.film_t) { pf[2] = p.film_t[(size_t)b * p.ld_t + tid]; pf[3] = p.film_t[(size_t)b * p.ld_t + C + tid]; }
+    if (p.film_a) { pf[4] = p.film_a[(size_t)b * p.ld_a + tid]; pf[5] = p.film_a[(size_t)b * p.ld_a + C + tid]; }
   }
   for (int c = tid; c < C; c += NT) {
     const float* st = p.st1;
@@ -99,10 +111,17 @@ __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool write
     double mu = a / n, var = d / n - mu * mu;
     if (var < 0.0) var = 0.0;
     const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
-    float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    float ga, be, ft0 = 0.f, ft1 = 0.f, fa0 = 0.f, fa1 = 0.f;
+    if (PF && c == tid) {
+      ga = pf[0]; be = pf[1]; ft0 = pf[2]; ft1 = pf[3]; fa0 = pf[4]; fa1 = pf[5];
+    } else {
+      ga = p.gamma ? p.gamma[c] : 1.f; be = p.beta ? p.beta[c] : 0.f;
+      if (p.film_t) { ft0 = p.film_t[(size_t)b * p.ld_t + c]; ft1 = p.film_t[(size_t)b * p.ld_t + C + c]; }
+      if (p.film_a) { fa0 = p.film_a[(size_t)b * p.ld_a + c]; fa1 = p.film_a[(size_t)b * p.ld_a + C + c]; }
+    }
     float sc = r * ga, sh = be - mf * sc;
-    if (p.film_t) { float f = 1.f + p.film_t[(size_t)b * p.ld_t + c]; sc *= f; sh = sh * f + p.film_t[(size_t)b * p.ld_t + C + c]; }
-    if (p.film_a) { float f = 1.f + p.film_a[(size_t)b * p.ld_a + c]; sc *= f; sh = sh * f + p.film_a[(size_t)b * p.ld_a + C + c]; }
+    if (p.film_t) { float f = 1.f + ft0; sc *= f; sh = sh * f + ft1; }
+    if (p.film_a) { float f = 1.f + fa0; sc *= f; sh = sh * f + fa1; }
     cof[2 * c] = sc; cof[2 * c + 1] = sh;
     if (writer && p.sc_out) {
       p.sc_out[(size_t)b * C + c] = sc; p.sh_out[(size_t)b * C + c] = sh;

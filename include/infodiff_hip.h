@@ -100,6 +100,23 @@ int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, in
                      float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
                      int Cout, int taps, void* stream);
 
+/* Backward counterpart of the fused block on the small maps (H*W <= 256: the 16x16 / 8x8 / 4x4 levels, where one workgroup
+ * tile is a whole image): the stride-1 data-gradient conv (taps 9 or 1; w = the data-gradient weights [Cout][taps][Cin]
+ * with flipped taps, as idf_pack_conv_weight writes them) with the GroupNorm / FiLM / SiLU / dropout BACKWARD of
+ * modules.py:264-288, 312-319 as its epilogue.  The conv result dA (gradient w.r.t. the activated tensor) never leaves the
+ * chip: the block owns every pixel of its 64 channels, so it forms du = dA * act'(x*sc+sh) * mask, the per-(sample, channel)
+ * sums, and dx = sc*du + k1*x + k0 (+ dres + dres2) itself -- arguments and side outputs (dfilm_t / dfilm_a [B,2C],
+ * dgb [B,2,C] or the dgamma_acc / dbeta_acc accumulators) exactly as idf_gn_fused_bwd.  Cin = channels of dy, Cout = C =
+ * channels of x and dx (a multiple of 64).  idf_conv_dgrad_gn_ok(): 0 not covered, 1 covered and measured faster than the
+ * two launches it replaces, 2 covered only (the 1x1 q/k/v convs, maps above IDF_DGRAD_GN_MAXHW). */
+int idf_conv_dgrad_gn_ok(int B, int H, int W, int Cin, int Cout, int taps);
+int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void* x, const void* dres, const void* dres2, void* dx,
+                           const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                           int ld_a, const float* mean, const float* rstd, const float* sc, const float* sh,
+                           float* dfilm_t, float* dfilm_a, float* dgb, float* dgamma_acc, float* dbeta_acc,
+                           const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int H, int W, int Cin,
+                           int Cout, int taps, void* stream);
+
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */
 int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, const float* sh,

@@ -50,6 +50,14 @@ struct C3P {
   const float* cof_in;  // [B][Cin][2] (sc, sh) folded by pro_coef_kernel beforehand (big launches: many blocks per image)
   bf16_t* a_out;        // training: the activated tensor [B, H, W, Cin] (dense), kept for the weight gradient
   float* mean_out; float* rstd_out; float* sc_out; float* sh_out;   // training: saved for the GroupNorm backward
+  // ---- GroupNorm backward in the epilogue of a data-gradient conv (GNB; the tile is a whole image, so the block owns
+  // every pixel of its 64 channels and the (sample, group) sums need no other block): the accumulator tile is dA, the
+  // gradient w.r.t. the activated tensor a = act(x * sc + sh); the block turns it into dx as idf_gn_fused_bwd does.
+  // res / gnb_res2 = gradients arriving over the residual / skip branches, y = dx, gamma .. ld_a / act / seed .. as above.
+  const bf16_t* gnb_x;          // the GroupNorm's input [B, H, W, Cout]
+  const bf16_t* gnb_res2;
+  const float* gnb_sc; const float* gnb_sh; const float* gnb_mean; const float* gnb_rstd;
+  float* gnb_dfilm_t; float* gnb_dfilm_a; float* gnb_dgb; float* gnb_dgam; float* gnb_dbet;
   // ---- persistent wave-specialised form (conv_ps_bf16): a pixel tile = NI images x R rows x W columns = 256 pixels
   int ps_NI, ps_rwshift;        // images per tile, log2(R * W)
   int ps_npi;                   // halo pixels per image, (R + 2 halo)(W + 2 halo)
@@ -246,6 +254,182 @@ __device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[
   }
 }
 
+// Epilogue of a data-gradient conv whose tile is one whole image: the GroupNorm / FiLM / SiLU / dropout backward of
+// idf_groupnorm.hip's gn_small_bwd on the accumulator tile (same sums, same coefficient algebra, same outputs), so the
+// 16x16 / 8x8 levels need no GroupNorm-backward launch.  dA never leaves the chip (and is not rounded to bf16 on the way).
+// What the epilogue reads from memory -- x, the branch gradient, the coefficients -- does not depend on the conv: it is
+// fetched BEFORE the conv's main loop (GnbPre, ~50 registers of a kernel that runs at two waves per SIMD anyway), so the
+// epilogue starts with its operands in registers instead of with a memory round trip.
+template <int NI>
+struct GnbPre {
+  uint4 xr[NI], rr[NI];
+  float scv[8], shv[8], pf[7];
+  uint64_t seedv;
+};
+
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void gnb_prefetch(const C3P& p, int b, int n0, int KT, int tid, GnbPre<BM * (BN / 8) / NT>& g) {
+  constexpr int CPR = BN / 8, NI = BM * CPR / NT;
+  const int C = p.Cout, cpg = C >> 5, HW = KT;
+  const int cc = (tid % CPR) * 8;                  // this thread's 8 channels (fixed: NT % CPR == 0)
+  const size_t cbase = (size_t)b * C + n0 + cc;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    float4 a4 = *reinterpret_cast<const float4*>(p.gnb_sc + cbase + 4 * q), b4 = *reinterpret_cast<const float4*>(p.gnb_sh + cbase + 4 * q);
+    g.scv[4 * q] = a4.x; g.scv[4 * q + 1] = a4.y; g.scv[4 * q + 2] = a4.z; g.scv[4 * q + 3] = a4.w;
+    g.shv[4 * q] = b4.x; g.shv[4 * q + 1] = b4.y; g.shv[4 * q + 2] = b4.z; g.shv[4 * q + 3] = b4.w;
+  }
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int pl = (tid + k * NT) / CPR;
+    g.xr[k] = g.rr[k] = make_uint4(0, 0, 0, 0);
+    if (pl < KT) {
+      const size_t e0 = ((size_t)b * HW + pl) * C + n0 + cc;
+      g.xr[k] = *reinterpret_cast<const uint4*>(p.gnb_x + e0);
+      if (p.res) g.rr[k] = *reinterpret_cast<const uint4*>(p.res + e0);
+    }
+  }
+  // the coefficient phase's per-channel parameters (thread c < BN owns channel n0 + c)
+  g.pf[0] = 0.f; g.pf[1] = 0.f; g.pf[2] = 1.f; g.pf[3] = 0.f; g.pf[4] = 0.f; g.pf[5] = 0.f; g.pf[6] = 0.f;
+  if (tid < BN) {
+    const int c = n0 + tid, gr = c / cpg;
+    g.pf[0] = p.gnb_mean[b * 32 + gr]; g.pf[1] = p.gnb_rstd[b * 32 + gr];
+    if (p.gamma) g.pf[2] = p.gamma[c];
+    if (p.beta) g.pf[3] = p.beta[c];
+    if (p.film_t) { g.pf[4] = p.film_t[(size_t)b * p.ld_t + c]; g.pf[5] = p.film_t[(size_t)b * p.ld_t + C + c]; }
+    if (p.film_a) g.pf[6] = p.film_a[(size_t)b * p.ld_a + c];
+  }
+  g.seedv = (p.act == 2 && p.seed != nullptr) ? *p.seed : 0;
+}
+
+template <int TM, int TN, int BM, int BN, int NT>
+__device__ __forceinline__ void gnb_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int n0,
+                                             int KT, int tid, int wm0, int wn0, const GnbPre<BM * (BN / 8) / NT>& g) {
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  constexpr int PF = BN + 4, CPR = BN / 8, NI = BM * CPR / NT, NW = NT / 64;
+  const int C = p.Cout, cpg = C >> 5, HW = KT, GS = BN / cpg;
+  float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]: dA, then du in place
+  float* part = reinterpret_cast<float*>(smem + p.aux_off);     // [NW][BN][2]
+  float* pc = part + NW * BN * 2;                  // [BN][2]
+  float* kk = pc + BN * 2;                         // [GS][2]
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      int nl = wn0 + a * 16 + fq * 4;
+      *reinterpret_cast<float4*>(Os + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+    }
+  }
+  const int cc = (tid % CPR) * 8;
+  const uint4 (&xr)[NI] = g.xr;
+  const uint4 (&rr)[NI] = g.rr;
+  const float (&scv)[8] = g.scv;
+  const float (&shv)[8] = g.shv;
+  const float (&pf)[7] = g.pf;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const bool drop = p.act == 2 && p.seed != nullptr;
+  const uint64_t seedv = g.seedv;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int pl = (tid + k * NT) / CPR;
+    if (pl < KT) {
+      float dav[8], xv[8], du[8];
+      float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc), v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
+      dav[0] = v0.x; dav[1] = v0.y; dav[2] = v0.z; dav[3] = v0.w; dav[4] = v1.x; dav[5] = v1.y; dav[6] = v1.z; dav[7] = v1.w;
+      const uint32_t w4[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xv[2 * i] = __uint_as_float(w4[i] << 16); xv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+      const size_t e0 = ((size_t)b * HW + pl) * C + n0 + cc;
+      const uint32_t h = drop ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
+      if (p.act == 2) {
+#pragma unroll
+        for (int g0 = 0; g0 < 8; g0 += 4) {
+          if (drop) idf_dact_vec_t<4, true, true>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
+          else idf_dact_vec_t<4, true, false>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) du[e] = dav[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += du[e]; s2[e] += du[e] * xv[e]; }
+      *reinterpret_cast<float4*>(Os + pl * PF + cc) = make_float4(du[0], du[1], du[2], du[3]);
+      *reinterpret_cast<float4*>(Os + pl * PF + cc + 4) = make_float4(du[4], du[5], du[6], du[7]);
+    }
+  }
+  // lanes CPR apart hold the same channels: fold them, then the waves through LDS
+#pragma unroll
+  for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+  if (lane < CPR) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[(wave * BN + lane * 8 + e) * 2] = s1[e]; part[(wave * BN + lane * 8 + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    const int c = n0 + tid;
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { S1 += part[(w * BN + tid) * 2]; S2 += part[(w * BN + tid) * 2 + 1]; }
+    const float mu = pf[0], r = pf[1], ga = pf[2], be = pf[3], st = pf[4], bt = pf[5], sa = pf[6];
+    const float D1 = S1, D2 = r * (S2 - mu * S1);
+    const float f = (1.f + st) * (1.f + sa);
+    const float Gf = ga * D2 + be * D1, Ge = D1;
+    if (p.gnb_dfilm_t) { p.gnb_dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); p.gnb_dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
+    if (p.gnb_dfilm_a) { p.gnb_dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; p.gnb_dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
+    if (p.gnb_dgb) { p.gnb_dgb[((size_t)b * 2 + 0) * C + c] = f * D2; p.gnb_dgb[((size_t)b * 2 + 1) * C + c] = f * D1; }
+    if (p.gnb_dgam) atomicAdd(p.gnb_dgam + c, f * D2);
+    if (p.gnb_dbet) atomicAdd(p.gnb_dbet + c, f * D1);
+    pc[tid * 2] = ga * f * D1; pc[tid * 2 + 1] = ga * f * D2;
+  }
+  __syncthreads();
+  if (tid < GS) {
+    float P1 = 0.f, P2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { P1 += pc[c * 2]; P2 += pc[c * 2 + 1]; }
+    const int g = n0 / cpg + tid;
+    const float mu = p.gnb_mean[b * 32 + g], r = p.gnb_rstd[b * 32 + g];
+    const float invN = 1.f / ((float)HW * cpg);
+    kk[tid * 2] = -r * r * P2 * invN;
+    kk[tid * 2 + 1] = (-r * P1 + r * r * mu * P2) * invN;
+  }
+  __syncthreads();
+  float k1v[8], k0v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int gl = (cc + e) / cpg; k1v[e] = kk[gl * 2]; k0v[e] = kk[gl * 2 + 1]; }
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int pl = (tid + k * NT) / CPR;
+    if (pl < KT) {
+      float du[8], xv[8], o[8];
+      float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc), v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
+      du[0] = v0.x; du[1] = v0.y; du[2] = v0.z; du[3] = v0.w; du[4] = v1.x; du[5] = v1.y; du[6] = v1.z; du[7] = v1.w;
+      const uint32_t w4[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xv[2 * i] = __uint_as_float(w4[i] << 16); xv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = scv[e] * du[e] + k1v[e] * xv[e] + k0v[e];
+      const size_t e0 = ((size_t)b * HW + pl) * C + n0 + cc;
+      if (p.res) {
+        const uint32_t r4[4] = {rr[k].x, rr[k].y, rr[k].z, rr[k].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] += __uint_as_float(r4[i] << 16); o[2 * i + 1] += __uint_as_float(r4[i] & 0xffff0000u); }
+      }
+      if (p.gnb_res2) {
+        float rv[8];
+        Vec16<bf16_t>::load(p.gnb_res2 + e0, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rv[e];
+      }
+      Vec16<bf16_t>::store(p.y + e0, o);
+    }
+  }
+}
+
 // NWM = waves along the pixel axis (2 -> 256 threads; 4 -> 512 threads: a 256-pixel tile shares one
 // weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
 // KS = 3 (3x3, pad 1) or 1 (1x1: the same pipeline without the halo -- the AttnBlock q/k/v and proj
@@ -253,7 +437,8 @@ __device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[
 // DUAL: the input is the never-materialised channel concatenation x | x2 (skip connection): a 32-channel
 // chunk is fetched from the tensor it lies in (C1 % 32 == 0).
 // PRO: GroupNorm / FiLM / SiLU / dropout applied to the staged tile (MODE 0 only), coefficients folded in-block.
-template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false>
+// GNB: the epilogue is the GroupNorm backward (gnb_epilogue): a data-gradient conv whose tile is one whole image.
+template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false, bool GNB = false>
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
@@ -385,6 +570,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   };
 
   load_chunk(0);
+  GnbPre<GNB ? BM * (BN / 8) / NT : 1> gpre;
+  if constexpr (GNB) gnb_prefetch<BM, BN, NT>(p, b, n0, KT, tid, gpre);
   if (PRO) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   for (int ck = 0; ck < nchunks; ++ck) {
     store_chunk(ck);
@@ -415,6 +602,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   // (the staging buffers are free now) and is written back as whole 16-byte chunks, consecutive lanes
   // covering one pixel's contiguous couts: full-line HBM writes, coalesced bias/residual reads.
   const int ncols = min(BN, p.Cout - n0);          // valid couts of this tile
+  if constexpr (GNB) {
+    gnb_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, n0, KT, tid, wm0, wn0, gpre);
+    return;
+  }
   if ((p.Cout & 7) == 0) {
     lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
     return;
@@ -1183,12 +1374,27 @@ void launch(C3P& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
 
+template <int TM, int NWM, int KS>
+void launch_gnb(C3P& p, hipStream_t st) {
+  constexpr int BN = 64;
+  size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
+  size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
+  if (olds > lds) lds = olds;
+  p.aux_off = (int)lds;
+  lds += (size_t)NWM * 2 * BN * 8 + BN * 8 + 32 * 8;                   // wave partials | per-channel products | per-group k1, k0
+  auto kern = conv3x3_halo_bf16<0, TM, BN, NWM, KS, false, false, true>;
+  IDF_ENSURE_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.n_tiles), dim3(NWM * 128), lds, st, p);
+}
+
 void clear_pro(C3P& p) {
   p.st_out = nullptr; p.aux_off = 0;
   p.st1 = p.st2 = nullptr; p.T1 = p.T2 = 0;
   p.gamma = p.beta = p.film_t = p.film_a = nullptr; p.ld_t = p.ld_a = 0; p.eps = 0.f;
   p.act = 0; p.seed = nullptr; p.salt = 0; p.thr = 0; p.dscale = 1.f;
   p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr; p.cof_in = nullptr;
+  p.gnb_x = p.gnb_res2 = nullptr; p.gnb_sc = p.gnb_sh = p.gnb_mean = p.gnb_rstd = nullptr;
+  p.gnb_dfilm_t = p.gnb_dfilm_a = p.gnb_dgb = p.gnb_dgam = p.gnb_dbet = nullptr;
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
   static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
   p.ps_dbg = dbg;
@@ -1408,6 +1614,77 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
   hipStream_t st = (hipStream_t)stream;
   if (x2) dispatch1<true, false>(p, BM, st);
   else dispatch1<false, false>(p, BM, st);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// ---- data-gradient conv with the GroupNorm backward as its epilogue (the 16x16 / 8x8 / 4x4 levels: a tile = one image)
+namespace {
+const int g_dgn_maxhw = getenv("IDF_DGRAD_GN_MAXHW") ? atoi(getenv("IDF_DGRAD_GN_MAXHW")) : 256;
+bool dgrad_gn_plan(int H, int W, int Cin, int Cout, int taps, int* BM) {       // coverage (not the policy)
+  if ((taps != 9 && taps != 1) || H * W > 256 || (Cout % 64) || (Cin % CK) || W < 4 || (W & (W - 1))) return false;
+  *BM = H * W <= 64 ? 64 : (H * W <= 128 ? 128 : 256);
+  const int halo = taps == 9 ? 2 : 0;
+  return (H + halo) * (W + halo) * 4 <= (*BM == 256 ? HALO_VEC_MAX_512 : HALO_VEC_MAX_256);
+}
+}  // namespace
+
+// 1: covered AND expected to beat the data-gradient conv + idf_gn_fused_bwd pair; 2: covered only.  Measured in the B = 32
+// train step: 3x3 at 8x8 13.6 vs 9.4 + 6.6 us, at 16x16 18.9 vs 10.4 + 8.9 us (a 256-pixel tile = 64 workgroups instead of
+// 256); 1x1 (the AttnBlock's q/k/v conv, 384 -> 128 channels) loses -- 16x16: 20.9 vs 7.0 + 8.2 us, 8x8: 14.4 vs 5.7 + 6.6 us.
+extern "C" int idf_conv_dgrad_gn_ok(int B, int H, int W, int Cin, int Cout, int taps) {
+  int BM;
+  (void)B;
+  if (!dgrad_gn_plan(H, W, Cin, Cout, taps, &BM)) return 0;
+  static const int one = getenv("IDF_DGRAD_GN_1X1") ? atoi(getenv("IDF_DGRAD_GN_1X1")) : 0;
+  return ((taps == 9 || one) && H * W <= g_dgn_maxhw) ? 1 : 2;
+}
+
+// dx = GroupNormBackward( conv(dy, w) ), stride 1, taps 9 or 1: dy [B,H,W,Cin] bf16 is the gradient of the forward conv's
+// output, w its data-gradient weights [Cout][taps][Cin] (flipped taps, idf_pack_conv_weight), the conv result is dA, the
+// gradient w.r.t. a = act(GroupNorm(x)) -- which the epilogue turns into dx [B,H,W,Cout] exactly as idf_gn_fused_bwd would
+// (same arguments, same side outputs), without dA ever being written.
+extern "C" int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void* x, const void* dres, const void* dres2,
+                                      void* dx, const float* gamma, const float* beta, const float* film_t,
+                                      const float* film_a, int ld_t, int ld_a, const float* mean, const float* rstd,
+                                      const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,
+                                      float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt,
+                                      float p_drop, int act, int B, int H, int W, int Cin, int Cout, int taps,
+                                      void* stream) {
+  int BM;
+  if (!dgrad_gn_plan(H, W, Cin, Cout, taps, &BM) || (act != 1 && act != 2))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_gn_bf16: B%d H%d W%d Cin%d Cout%d taps%d act%d not covered", B, H, W, Cin, Cout,
+             taps, act);
+  if (!dy || !w || !x || !dx || !mean || !rstd || !sc || !sh) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_gn_bf16: null argument");
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)dy; p.x2 = nullptr; p.C1 = Cin; p.w = (const bf16_t*)w; p.bias = nullptr;
+  p.res = (const bf16_t*)dres; p.y = (bf16_t*)dx;
+  p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout;
+  int ws = 0;
+  while ((1 << ws) < W) ++ws;
+  p.wshift = ws;
+  p.R = H; p.tiles_per_img = 1; p.n_tiles = Cout / 64;
+  const int halo = taps == 9 ? 2 : 0;
+  p.wh_magic = wh_magic(W + halo, (H + halo) * (W + halo));
+  if (!p.wh_magic || (long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_gn_bf16: tensor too large for 32-bit offsets");
+  p.gnb_x = (const bf16_t*)x; p.gnb_res2 = (const bf16_t*)dres2;
+  p.gnb_sc = sc; p.gnb_sh = sh; p.gnb_mean = mean; p.gnb_rstd = rstd;
+  p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * Cout; p.ld_a = ld_a ? ld_a : 2 * Cout;
+  p.gnb_dfilm_t = dfilm_t; p.gnb_dfilm_a = dfilm_a; p.gnb_dgb = dgb; p.gnb_dgam = dgamma_acc; p.gnb_dbet = dbeta_acc;
+  p.act = act; p.salt = salt;
+  p.thr = idf_drop_thresh(p_drop);
+  p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (taps == 9) {
+    if (BM == 256) launch_gnb<4, 4, 3>(p, st); else if (BM == 128) launch_gnb<4, 2, 3>(p, st); else launch_gnb<2, 2, 3>(p, st);
+  } else {
+    if (BM == 256) launch_gnb<4, 4, 1>(p, st); else if (BM == 128) launch_gnb<4, 2, 1>(p, st); else launch_gnb<2, 2, 1>(p, st);
+  }
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

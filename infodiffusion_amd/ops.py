@@ -372,6 +372,45 @@ def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, see
     return dx, dgam[:C], dgam[C:], dft, dfa
 
 
+_DGRAD_GN = os.environ.get('IDF_DGRAD_GN', '1') != '0'
+
+
+@functools.lru_cache(maxsize=None)
+def _dgrad_gn_shape_ok(B, H, W, Cin, Cout, taps):
+    return int(_lib.load().idf_conv_dgrad_gn_ok(B, H, W, Cin, Cout, taps))
+
+
+def conv_dgrad_gn_ok(dy, x, mode, taps, advice=True):
+    """The data-gradient conv can carry the GroupNorm backward as its epilogue (idf_conv_dgrad_gn_bf16: small maps, bf16)
+    -- and, with `advice`, the library's measured policy prefers that to the two launches."""
+    if not (_DGRAD_GN and mode == S1 and x.is_cuda and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16):
+        return False
+    B, C, H, W = x.shape
+    ok = _dgrad_gn_shape_ok(B, H, W, dy.shape[1], C, taps)
+    return ok == 1 or (ok == 2 and not advice)
+
+
+def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, taps,
+                      acc=None, dres=None, dres2=None):
+    """dx and the GroupNorm's parameter / FiLM gradients from dy in ONE launch: the stride-1 data-gradient conv with the
+    GroupNorm backward as its epilogue.  Returns what gn_fused_bwd_raw returns."""
+    B, C, H, W = x.shape
+    dev = x.device
+    dx = torch.empty_like(x, memory_format=CL)
+    dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
+    dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
+    acc = _gn_acc(acc)
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    call('idf_conv_dgrad_gn_bf16', _p(dy), _p(w_dgrad), _p(x), _p(dres), _p(dres2), _p(dx), _p(gamma), _p(beta), _p(film_t),
+         _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
+         _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop), act, B, H, W,
+         dy.shape[1], C, taps, _st())
+    if acc:
+        return dx, acc[0], acc[1], dft, dfa
+    dgam = colsum_raw(dgb)
+    return dx, dgam[:C], dgam[C:], dft, dfa
+
+
 def gn_apply_raw(x, sc, sh, seed, salt, p_drop, act):
     """a = act(x*sc + sh) (+ dropout): one read + one write."""
     B, C, H, W = x.shape
@@ -623,13 +662,20 @@ class _FusedConv(torch.autograd.Function):
             dres2_in = _nhwc(dxp2.to(x.dtype)) if dxp2 is not None else None
             if dres_in is None:
                 dres_in, dres2_in = dres2_in, None
-            if not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
+            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
+            fused_bwd = bool(act) and conv_dgrad_gn_ok(dy, x, mode, taps)
+            if fused_bwd:
+                dA = None
+            elif not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
                 dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
                 dres_in = None
             else:
                 dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
-            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
-            if act and gn_small_ok(x):
+            if fused_bwd:
+                # small maps: the data-gradient conv's tile is a whole image, its epilogue IS the GroupNorm backward
+                dx, dgw, dgb, dft, dfa = conv_dgrad_gn_raw(dy, w_dgrad, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
+                                                           seed, salt, p_drop, act, taps, gacc, dres_in, dres2_in)
+            elif act and gn_small_ok(x):
                 dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                                                           seed, salt, p_drop, act, gacc, dres_in, dres2=dres2_in)
             elif act:

@@ -145,6 +145,55 @@ def test_dropout_mask_consistency():
     assert rel(dW, wr.grad) < 1e-4
 
 
+@pytest.mark.parametrize('case', [
+    # (B, Cin of dy, C of x, H, W, taps, act, film, p_drop, n_res)
+    (3, 128, 128, 16, 16, 9, 2, True, 0.1, 1), (2, 256, 128, 8, 8, 9, 2, True, 0.1, 2), (33, 128, 128, 16, 16, 9, 2, False, 0.0, 0),
+    (2, 384, 128, 16, 16, 1, 1, False, 0.0, 1), (3, 128, 256, 8, 8, 9, 2, True, 0.0, 1), (2, 64, 64, 4, 4, 9, 2, False, 0.1, 0),
+    (2, 128, 64, 8, 16, 9, 2, True, 0.1, 1),
+])
+def test_dgrad_conv_with_groupnorm_backward_epilogue(case):
+    """idf_conv_dgrad_gn_bf16 (data-gradient conv whose epilogue is the GroupNorm / FiLM / SiLU / dropout backward) against
+    the two launches it replaces (data-gradient conv, then idf_gn_fused_bwd on the bf16 dA): dx, FiLM and affine gradients."""
+    B, Cin, C, H, W, taps, act, film, p_drop, n_res = case
+    k = 3 if taps == 9 else 1
+    x = (0.3 + rnd(1, B, C, H, W)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dy = rnd(2, B, Cin, H, W).to(DEV).bfloat16().contiguous(memory_format=CL)
+    wgt = (rnd(3, Cin, C, k, k) / (C * taps) ** 0.5).to(DEV)          # forward conv C -> Cin; its data gradient maps dy -> dA
+    _, wd = ops.pack_weight(wgt, torch.bfloat16, True, True)
+    gam, bet = (1 + 0.1 * rnd(4, C)).to(DEV), (0.1 * rnd(5, C)).to(DEV)
+    ft = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(7, B, 2 * C)).to(DEV) if film else None
+    seed = torch.tensor([987654321], dtype=torch.int64, device=DEV) if p_drop else None
+    res = [rnd(8 + i, B, C, H, W).to(DEV).bfloat16().contiguous(memory_format=CL) for i in range(n_res)]
+    dres, dres2 = (res + [None, None])[:2]
+    _, mean, rstd, sc, sh = ops.gn_fused_fwd_raw(x, gam, bet, ft, fa, seed, 5, p_drop, act)
+    assert ops.conv_dgrad_gn_ok(dy, x, ops.S1, taps, advice=False)          # coverage, not the policy
+    dA = ops.conv_dgrad_raw(dy, wd, ops.S1, taps, x.shape)
+    ref = ops.gn_fused_bwd_raw(dA, x, gam, bet, ft, fa, mean, rstd, sc, sh, seed, 5, p_drop, act, dres=dres, dres2=dres2)
+    got = ops.conv_dgrad_gn_raw(dy, wd, x, gam, bet, ft, fa, mean, rstd, sc, sh, seed, 5, p_drop, act, taps, dres=dres,
+                                dres2=dres2)
+    assert rel(got[0], ref[0]) < 1e-2                     # dx (dA is not rounded to bf16 on the fused path)
+    for g, r in zip(got[1:], ref[1:]):
+        assert (g is None) == (r is None)
+        if g is not None:
+            assert rel(g, r) < 1e-2
+    # exactness where rounding plays no part: the accumulate-into-slots form gives the same sums as the per-sample form
+    class Slot:
+        def __init__(self, n):
+            self.t = torch.zeros(n, device=DEV)
+
+        def available(self):
+            return True
+
+        def take(self):
+            return self.t
+    acc = (Slot(C), Slot(C))
+    got2 = ops.conv_dgrad_gn_raw(dy, wd, x, gam, bet, ft, fa, mean, rstd, sc, sh, seed, 5, p_drop, act, taps, acc=acc,
+                                 dres=dres, dres2=dres2)
+    assert torch.equal(got2[0], got[0])
+    assert rel(got2[1], got[1]) < 1e-5 and rel(got2[2], got[2]) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (33, 64, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16)])
 def test_attention(B, C, H, dtype):

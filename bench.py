@@ -212,6 +212,14 @@ class LaunchRecorder:
             if a[22]:
                 bufs.append((22, px * Cin * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_dgrad_gn_bf16':      # small maps: data-gradient conv + GroupNorm backward in one launch
+            B, H, W, Cin, Cout, taps = a[25:31]
+            if taps != 9:
+                return None
+            px = B * H * W
+            bufs = [(0, px * Cin * 2), (2, px * Cout * 2), (5, px * Cout * 2)]
+            bufs += [(i, px * Cout * 2) for i in (3, 4) if a[i]]
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
         if name == 'idf_gn_fused_bwd':
             C1 = a[3]
             B, HW, C, dt = a[27:31]
@@ -273,6 +281,11 @@ class LaunchRecorder:
                     t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
                     keep.append(t)
                     al[20], al[21], al[22] = t.data_ptr(), None, None
+                if name == 'idf_conv_dgrad_gn_bf16':
+                    B_, C_ = al[25], al[29]
+                    t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
+                    keep.append(t)
+                    al[18], al[19], al[20] = t.data_ptr(), None, None
                 al[-1] = None
                 sets.append((al, keep))
             reps = max(1, -(-reps_min // K))
@@ -509,7 +522,7 @@ def main():
             n, ms, fl, by = fam['conv3x3']
             ach = fl / (ms * 1e-3) / 1e12
             out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16: forward incl. '
-                                         'GroupNorm-prologue launches + data-gradient launches)',
+                                         'GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the GroupNorm backward)',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
                                'traffic': pmc_traffic_r02(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16']),

@@ -1,6 +1,8 @@
 """Fused global-norm clip + AdamW (the optimizer tail of reference run.py:177, 199-200) as three
 kernel launches over a device-side chunk table -- same arithmetic as
 `clip_grad_norm_(params, max_norm)` followed by `torch.optim.AdamW(...).step()`."""
+import os
+
 import numpy as np
 import torch
 
@@ -8,7 +10,7 @@ from . import ops
 from .grad_arena import GradArena
 from ._lib import call
 
-_CHUNK = 65536
+_CHUNK = int(os.environ.get('IDF_OPT_CHUNK', '8192'))    # elements per workgroup: 65536 ran at 3.3 TB/s, 8192 at 4.9 (tools/bench_optim.py)
 
 
 class FusedClipAdamW(torch.optim.Optimizer):

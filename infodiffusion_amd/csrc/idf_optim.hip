@@ -46,12 +46,18 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const Chunk* __restrict__ t
 }
 
 // state: [0] step count (float), [1] clip coef, [2] 1-b1^t, [3] 1-b2^t, [4] total grad norm
-__global__ void opt_scalars_kernel(const float* __restrict__ partial, int n, float max_norm, float b1, float b2,
-                                   float* __restrict__ state) {
+// one 1024-thread block (thousands of partials: a single wave walked them in a 17-us chain of dependent loads)
+__global__ __launch_bounds__(1024) void opt_scalars_kernel(const float* __restrict__ partial, int n, float max_norm, float b1,
+                                                          float b2, float* __restrict__ state) {
+  __shared__ float red[16];
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  for (int i = threadIdx.x; i < n; i += 1024) s += partial[i];
   float t = wave_sum((float)s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
     float total = sqrtf(t);
     float coef = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
     float step = state[0] + 1.0f;
@@ -126,7 +132,7 @@ extern "C" int idf_clip_adamw(const void* table, int nchunks, float* partial, fl
   const Chunk* tab = reinterpret_cast<const Chunk*>(table);
   hipLaunchKernelGGL(sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, tab, partial);
   IDF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(64), 0, st, partial, nchunks, max_norm, b1, b2, state);
+  hipLaunchKernelGGL(opt_scalars_kernel, dim3(1), dim3(1024), 0, st, partial, nchunks, max_norm, b1, b2, state);
   IDF_CHECK_LAUNCH();
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, st, tab, state, lr, b1, b2, eps, wd, write_clipped_grads);
   IDF_CHECK_LAUNCH();

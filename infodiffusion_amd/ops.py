@@ -464,7 +464,7 @@ class WgradBatch:
     problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
     enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
     pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1, Cin_w, Cout_w)
-    _bufs = {}         # (taps, mode) -> [pinned host table, device table, key]   (eager: reused)
+    _bufs = {}         # classes of a flush -> [pinned host table, device table, key, launch plan, copy event]   (eager: reused)
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
     @classmethod
@@ -479,50 +479,59 @@ class WgradBatch:
     @classmethod
     def flush(cls):
         items, cls.pending = cls.pending, []
+        if not items:
+            return
         groups = {}
         for it in items:
             groups.setdefault((it[9], it[10]), []).append(it)
         lib = _lib.load()
         nb = lib.idf_wgrad_desc_bytes()
         capturing = torch.cuda.is_current_stream_capturing()
-        for (taps, mode), grp in groups.items():
-            n = len(grp)
-            key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:9] + (_p(it[11]), it[12], it[13], it[14]) for it in grp)
-            buf = cls._bufs.get((taps, mode))
-            if buf is None or buf[0].numel() < n * nb:
-                dev = grp[0][0].device
-                buf = [torch.empty((max(n, 16) * nb,), dtype=torch.uint8).pin_memory(),
-                       torch.empty((max(n, 16) * nb,), dtype=torch.uint8, device=dev), None, 0, 0]
-                cls._bufs[(taps, mode)] = buf
-            if capturing:
-                # the captured copy node reads this pinned table at every replay: retire the pair from
-                # eager use (the warm-up step allocated it; later eager steps get a fresh one)
-                cls._graph_bufs.append(cls._bufs.pop((taps, mode)))
-                buf[2] = None
-            if buf[2] != key:
-                if not capturing and len(buf) > 5 and buf[5] is not None:
-                    buf[5].synchronize()        # the previous step's copy out of this pinned table has been issued AND done
-                    # (under capture nothing may be synchronised -- and nothing needs to be: the capture follows a
-                    # device-wide synchronisation, and the pair is retired to the graph)
-                host = buf[0].data_ptr()
+        classes = list(groups.items())
+        total = len(items)
+        # ONE table (and one host-to-device copy) for all the (taps, mode) classes of this flush; each class launches on
+        # its slice.  `slot` = which classes the flush carries (under data parallelism the early backbone flush and the
+        # final one are different tables).
+        slot = tuple(c for c, _ in classes)
+        key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:11] + (_p(it[11]), it[12], it[13], it[14])
+                    for _, grp in classes for it in grp)
+        buf = cls._bufs.get(slot)
+        if buf is None or buf[0].numel() < total * nb:
+            dev = items[0][0].device
+            buf = [torch.empty((max(total, 16) * nb,), dtype=torch.uint8).pin_memory(),
+                   torch.empty((max(total, 16) * nb,), dtype=torch.uint8, device=dev), None, [], None]
+            cls._bufs[slot] = buf
+        if capturing:
+            # the captured copy node reads this pinned table at every replay: retire the pair from
+            # eager use (the warm-up step allocated it; later eager steps get a fresh one)
+            cls._graph_bufs.append(cls._bufs.pop(slot))
+            buf[2] = None
+        if buf[2] != key:
+            if not capturing and buf[4] is not None:
+                buf[4].synchronize()        # the previous step's copy out of this pinned table has been issued AND done
+                # (under capture nothing may be synchronised -- and nothing needs to be: the capture follows a
+                # device-wide synchronisation, and the pair is retired to the graph)
+            plan, off = [], 0
+            nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
+            for (taps, mode), grp in classes:
+                host = buf[0].data_ptr() + off * nb
                 blk, lds = 0, 0
-                nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
                 for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1, Cin_w, Cout_w) in enumerate(grp):
                     _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout, Cin_w,
                                                        Cout_w, taps, mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)),
                                'idf_wgrad_desc_fill')
                     blk += nblk.value
                     lds = max(lds, nlds.value)
-                buf[1][:n * nb].copy_(buf[0][:n * nb], non_blocking=True)
-                buf[2], buf[3], buf[4] = key, blk, lds
-                if not capturing:               # eager runs can be a step ahead of the GPU: guard the table's next rewrite
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    if len(buf) > 5:
-                        buf[5] = ev
-                    else:
-                        buf.append(ev)
-            call('idf_conv_wgrad_bf16_batched', _p(buf[1]), n, buf[3], buf[4], taps, mode, _st())
+                plan.append((off, len(grp), blk, lds, taps, mode))
+                off += len(grp)
+            buf[1][:total * nb].copy_(buf[0][:total * nb], non_blocking=True)
+            buf[2], buf[3] = key, plan
+            if not capturing:               # eager runs can be a step ahead of the GPU: guard the table's next rewrite
+                buf[4] = torch.cuda.Event()
+                buf[4].record()
+        base = buf[1].data_ptr()
+        for off, n, blk, lds, taps, mode in buf[3]:
+            call('idf_conv_wgrad_bf16_batched', base + off * nb, n, blk, lds, taps, mode, _st())
 
 
 def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, defer=False):

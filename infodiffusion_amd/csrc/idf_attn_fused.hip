@@ -19,6 +19,7 @@
 //   bwd-B : LDS = Q, dO      rows = keys      P^T, dS^T from the saved row statistics
 //                                             dV = P^T dO, dK = dS^T Q
 #include "idf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -135,20 +136,24 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // ------------------------------------------------------------------ forward
+// rb_per_block: 64-row blocks one workgroup walks with K and V staged ONCE (big batches: B = 256 sampling launches 1024
+// workgroups of which every four re-staged the same 128 KB; at B = 32 one row block per workgroup keeps 128 CUs busy)
 template <int D, int AN>
 __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                       float* __restrict__ lse, float scale) {
+                                                       float* __restrict__ lse, float scale, int rb_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Vs = Ks + AN * ACfg<D>::PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, r0 = blockIdx.x * 64 + wave * 16;
+  const int b = blockIdx.y;
   const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
   stage_rows<D, AN>(base + D, 3 * D, Ks, tid);
   stage_rows<D, AN>(base + 2 * D, 3 * D, Vs, tid);
+  __syncthreads();
+  for (int rb = blockIdx.x * rb_per_block; rb < (int)(blockIdx.x + 1) * rb_per_block; ++rb) {
+  const int r0 = rb * 64 + wave * 16;
   bf16x8_t qf[ACfg<D>::KS];
   load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
-  __syncthreads();
   f32x4_t s[AN / 16];
   scores<D, AN>(s, Ks, qf, lane);
   float mx = -INFINITY;
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict_
   outprod<D, AN>(out, Vs, pk, lane);
   store_out<D>(o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
   if (lse && lane < 16) lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
+  }
 }
 
 // ------------------------------------------------- backward A: dQ and the row sums  sum_j P dP
@@ -287,8 +293,10 @@ template <int D, int AN>
 void launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, hipStream_t st) {
   raise_lds_once<D, AN>();
   const size_t lds = ACfg<D, AN>::LDS;
-  hipLaunchKernelGGL((attn_fwd_kernel<D, AN>), dim3(AN / 64, B), dim3(ANT), lds, st, (const bf16_t*)qkv,
-                     (bf16_t*)o, lse, scale);
+  static const int rb_min_b = getenv("IDF_ATTN_RB_MINB") ? atoi(getenv("IDF_ATTN_RB_MINB")) : 128;
+  const int rb = (B >= rb_min_b) ? AN / 64 : 1;       // whole image per workgroup once the batch alone fills the chip
+  hipLaunchKernelGGL((attn_fwd_kernel<D, AN>), dim3(AN / 64 / rb, B), dim3(ANT), lds, st, (const bf16_t*)qkv,
+                     (bf16_t*)o, lse, scale, rb);
 }
 
 template <int D, int AN>

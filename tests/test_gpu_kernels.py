@@ -195,7 +195,8 @@ def test_dgrad_conv_with_groupnorm_backward_epilogue(case):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (33, 64, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16)])
+@pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (33, 64, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16),
+                                   (130, 128, 16), (129, 64, 16)])      # B >= 128: one workgroup walks all four row blocks
 def test_attention(B, C, H, dtype):
     """16x16 and 8x8 bf16 cases (N = 256 / 64 tokens) run the fused kernels (idf_attn_fwd / idf_attn_bwd), the rest
     bmm + softmax."""

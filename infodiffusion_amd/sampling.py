@@ -22,7 +22,7 @@ _DDPM, _DDIM, _REV = 0, 1, 2
 ETA = 0.01     # sampling.py:45
 GRAPH = os.environ.get('IDF_SAMPLER_GRAPH', '1') != '0'
 GRAPH_MIN_STEPS = 8
-GRAPH_MAX_PIXELS = 64 * 64 * 64      # batch x H x W up to which a step is launch-bound (64 CelebA images)
+GRAPH_MAX_PIXELS = int(os.environ.get('IDF_SAMPLER_GRAPH_MAXPIX', 64 * 64 * 64))   # batch x H x W up to which a step is launch-bound (64 CelebA images)
 
 
 def _tables(args, device):

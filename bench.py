@@ -151,19 +151,6 @@ def cpu_baseline(margs, budget_s=240):
     return res
 
 
-def pmc_traffic(prefix):
-    """Average HBM bytes per launch of the kernels named `prefix*`, from the committed rocprofv3 PMC
-    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-            d = json.load(f)
-        ks = [v for k, v in d.items() if k.startswith(prefix)]
-        n = sum(v['launches'] for v in ks)
-        return round(sum(v['launches'] * v['hbm_bytes_avg'] for v in ks) / n) if n else None
-    except (OSError, ValueError, KeyError):
-        return None
-
-
 def pmc_traffic_r02(names):
     """Average HBM bytes per launch over the kernels whose name contains one of `names`, from the committed rocprofv3
     PMC passes of this round (profiles/r02_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
@@ -390,82 +377,35 @@ def main():
         else None
     if sync is not None:
         sync.broadcast_parameters()
-        model.attach_grad_sync(sync)      # backbone slice of the exchange overlaps the encoder's backward pass
 
     g = torch.Generator(device='cpu')
     g.manual_seed(64 + rank)
     # synthetic batches in the layout the input pipeline delivers (data.py / idf_prep_u8: NHWC-dense fp32)
     pool = [(torch.rand(a.batch, 3, 64, 64, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
             for _ in range(8)]
-    xbuf = pool[0].clone()
 
     def fwd_bwd():
-        loss = model.loss_fn(margs, xbuf)
+        loss = model.loss_fn(margs, pool[0])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         return loss
 
-    def tail():
-        if sync is not None:
-            sync.all_reduce_grads()
-        if not a.fused_opt:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()      # FusedClipAdamW: global-norm clip (1.0) + AdamW in three launches
-
-    def step_eager(i):
-        xbuf.copy_(pool[i % 8])
-        fwd_bwd()
-        tail()
-
-    graph = None
-    used_graph = False
-    sync_in_graph = sync is not None    # the exchange (side stream, RCCL) and the optimizer are captured too
-    # warm-up (eager) -- also builds allocator pools and weight shadows
-    for i in range(max(2, a.warmup if not a.graph else 3)):
-        step_eager(i)
-    torch.cuda.synchronize()
-    if a.graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step_eager(0)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            # thread_local: RCCL's watchdog thread keeps querying events while this thread captures
-            try:
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    fwd_bwd()
-                    tail()
-            except Exception as e:  # noqa: BLE001
-                if sync is None:
-                    raise
-                if rank == 0:
-                    print('capture with the gradient exchange failed (%s: %s); capturing forward + backward only'
-                          % (type(e).__name__, str(e)[:200]), file=sys.stderr)
-                torch.cuda.synchronize()
-                sync_in_graph = False
-                graph = torch.cuda.CUDAGraph()
-                opt.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    fwd_bwd()
-            used_graph = True
-        except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print('graph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+    # the product's own training step (run.py's): loss_fn -> zero_grad -> backward -> [exchange] -> clip + AdamW, two
+    # eager steps, then the whole step captured once and replayed (trainer.GraphedTrainStep; with a gradient exchange
+    # the all-reduces and the optimizer are inside the graph, and a capture that fails on any rank takes every rank
+    # down the same fallback)
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    pre = None if a.fused_opt else (lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
+    trainer = GraphedTrainStep(model, margs, opt, sync=sync, use_graph=bool(a.graph), pre_step=pre)
 
     def step(i):
-        if graph is not None:
-            xbuf.copy_(pool[i % 8])
-            graph.replay()
-            if sync is not None and not sync_in_graph:
-                tail()
-        else:
-            step_eager(i)
+        trainer(pool[i % 8], 0)
+
+    for i in range(max(4, a.warmup)):      # eager warm-up, capture (if any), first replay
+        step(i)
+    torch.cuda.synchronize()
+    used_graph = trainer.graph is not None
+    sync_in_graph = trainer.sync_in_graph
 
     for i in range(a.warmup):
         step(i)
@@ -513,6 +453,8 @@ def main():
         # dominant kernel family: the 3x3 convs (forward incl. the GroupNorm-prologue form, and data gradients)
         rec = LaunchRecorder()
         rec.install()
+        if sync is not None:
+            sync.early_enabled = False      # rank 0 alone runs this pass: no collective may be issued from its hooks
         fwd_bwd()       # every launch of a step; no exchange / optimizer: the other ranks are not in this block
         rec.remove()
         torch.cuda.synchronize()

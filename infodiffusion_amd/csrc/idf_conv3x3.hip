@@ -64,9 +64,18 @@ struct C3P {
   unsigned ps_magic_img;        // (pix * magic) >> 16 == pix / ps_npi over the tile's halo pixels
   int ps_nptiles, ps_work;      // pixel tiles, work items (= pixel tiles x cout tiles)
   int ps_hbytes;                // bytes of one halo ring slot (whole 1-KB groups)
-  int ps_dbg;                   // timing-only ablations (IDF_CONV_PS_DBG; results are wrong when set): 1 no halo loads
-                                // after a block's first stage, 2 no MFMAs, 4 no epilogue stores, 8 no prologue arithmetic
+#ifdef IDF_PS_DBG
+  int ps_dbg;                   // timing-only ablation build (tools/build_variant.sh ... -DIDF_PS_DBG; env IDF_CONV_PS_DBG;
+                                // results are wrong when set): 1 no halo loads after a block's first stage, 2 no MFMAs,
+                                // 4 no epilogue stores, 8 no prologue arithmetic, 16 no statistics, 32 no epilogue
+#endif
 };
+// the shipped library has no ablation switches: PS_DBG() folds to false
+#ifdef IDF_PS_DBG
+#define PS_DBG(p, bit) (((p).ps_dbg & (bit)) != 0)
+#else
+#define PS_DBG(p, bit) false
+#endif
 
 constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 = 1536;   // (R+2)*(W+2)*4 budget per block size
 constexpr int CK = 32;
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
     }
     unsigned char* const stg = reinterpret_cast<unsigned char*>(stw + 512) + wave * (16 * SROW);
     float* const swv = stw + wave * 128;                    // this wave's statistics [64 couts][2]
-    const bool wants = p.st_out != nullptr && !(p.ps_dbg & 16);
+    const bool wants = p.st_out != nullptr && !PS_DBG(p, 16);
 
     PsPos pos;
     pos.init(p, w0);
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
       const unsigned char* Xs = Hring + hs * HSZ;
       const unsigned char* Ws = Wring + (s & 1) * WSZ;
       hs = hs == 2 ? 0 : hs + 1;
-      if (!(p.ps_dbg & 2))
+      if (!PS_DBG(p, 2))
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
         const int toff = (tap / KS) * WH + (tap % KS);
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
           for (int i = 0; i < 4; ++i)
             acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
       }
-      if (pos.ck + 1 == nchunks && !(p.ps_dbg & 32)) {
+      if (pos.ck + 1 == nchunks && !PS_DBG(p, 32)) {
         // ------------------------------------------------ epilogue of work item pos.wi
         // A lane holds 4 couts of a pixel (8 bytes): stored as they stand, 32-byte pieces land in 16 different
         // lines per instruction and the memory side crawls (5.7 us per tile measured).  Each wave therefore passes
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
         u32x4_t rres0[4], rres1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          rowok[i] = (b0 + rimg[i]) < p.B && colok && !(p.ps_dbg & 4);
+          rowok[i] = (b0 + rimg[i]) < p.B && colok && !PS_DBG(p, 4);
           erow[i] = ((size_t)(b0 * p.H + oy0) * W + rpix[i]) * p.Cout + n0 + rcol;
           if constexpr (RES) {                              // residual rows of all four slices first: one round trip
             const bf16_t* rp = rowok[i] ? p.res + erow[i] : zero;
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
     int nh_now = 0;
     if (sL < S) {
       if (pL.ck == 0) plan(pL);
-      if (!(p.ps_dbg & 1) || sL == 0) {
+      if (!PS_DBG(p, 1) || sL == 0) {
         issue_halo(hL, pL.ck * CK);
         nh_now = nhg;
         nissued += nhg;
@@ -1305,7 +1314,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
           bT = pT.b0;
         }
         wait_vmcnt(nissued);                               // everything older than this period's loads has landed
-        if (!(p.ps_dbg & 8)) transform(hT, pT.ck * CK);
+        if (!PS_DBG(p, 8)) transform(hT, pT.ck * CK);
       }
       hT = hT == 2 ? 0 : hT + 1;
       ++sT;
@@ -1396,8 +1405,10 @@ void clear_pro(C3P& p) {
   p.gnb_x = p.gnb_res2 = nullptr; p.gnb_sc = p.gnb_sh = p.gnb_mean = p.gnb_rstd = nullptr;
   p.gnb_dfilm_t = p.gnb_dfilm_a = p.gnb_dgb = p.gnb_dgam = p.gnb_dbet = nullptr;
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
+#ifdef IDF_PS_DBG
   static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
   p.ps_dbg = dbg;
+#endif
 }
 
 // ---- persistent form: geometry and the decision to use it

@@ -50,6 +50,7 @@ class GradSync:
         self._plan = None       # [(flat buffer, [views shaped/strided like the grads], [grad indices])]
         self._cut = None        # arena offset (floats) where the early slice ends; None: no early slice
         self._early_done = False
+        self.early_enabled = True   # cleared by the trainer when the exchange stays outside a captured forward + backward
 
     # ---------------------------------------------------------------- overlap with backward
     def attach(self, early_module):
@@ -75,11 +76,19 @@ class GradSync:
         self._cut = lo_rest
         return True
 
+    def begin_step(self):
+        """Start of a forward + backward pass: nothing of the previous step's exchange is pending (an exception between
+        `reduce_early` and `all_reduce_grads` must not make the next step skip the early slice)."""
+        self._early_done = False
+
     @torch.no_grad()
     def reduce_early(self):
         """All-reduce the early slice of the arena on the side stream (everything enqueued so far on the current
-        stream has produced it); the rest of backward keeps running on the current stream."""
-        if self._cut is None or self._early_done or (self.world == 1 and not self.force):
+        stream has produced it); the rest of backward keeps running on the current stream.  `all_reduce_grads` joins
+        the side stream again -- so this must not run inside a stream capture that ends before that call
+        (`early_enabled`)."""
+        if (self._cut is None or not self.early_enabled or self._early_done
+                or (self.world == 1 and not self.force)):
             return
         flat = self.arena.flat
         if not flat.is_cuda:

@@ -1,22 +1,27 @@
 """The training step of reference run.py:195-200 (loss_fn -> zero_grad -> backward -> [gradient exchange]
 -> clip + AdamW) as a captured hipGraph.
 
-Eagerly a CelebA step issues ~800 kernel launches from Python and is host-bound (~30 ms); replayed from a
-graph it runs at the GPU's pace (~12 ms).  The step is captured after two eager warm-up steps (they build
-the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) only
-forward + backward are captured; the all-reduce and the optimizer then run eagerly, as RCCL wants.
-A batch whose shape differs from the captured one (the last, short batch of an epoch) runs eagerly, after which the
-step is captured afresh (the eager pass re-homes gradients the graph's kernels write).  Objectives whose draws are
-made on the host every step (--prior 10mix / roll: numpy samplers, models.py:654-657) are never captured; the KL
-capacity of --use_C lives in a device scalar refreshed per call, so its schedule needs no re-capture."""
+Eagerly a CelebA step issues ~550 kernel launches from Python and is host-bound (~30 ms); replayed from a
+graph it runs at the GPU's pace (~10 ms).  The step is captured after two eager warm-up steps (they build
+the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) the
+all-reduces (RCCL on a side stream, event-joined) and the optimizer are captured too: the whole data-parallel
+step is one graph.  Should that capture fail on ANY rank, every rank drops it together and captures forward +
+backward only at its next step (exchange and optimizer then run eagerly after each replay, and the overlap of
+the backbone's slice with the encoder's backward pass is switched off: a collective forked inside a capture
+must be joined inside it).  A batch whose shape differs from the captured one (the last, short batch of an
+epoch) runs eagerly, after which the step is captured afresh (the eager pass re-homes gradients the graph's
+kernels write).  Objectives whose draws are made on the host every step (--prior 10mix / roll: numpy samplers,
+models.py:654-657) are never captured; the KL capacity of --use_C lives in a device scalar refreshed per call,
+so its schedule needs no re-capture."""
 import sys
 
 import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, args, opt, sync=None, use_graph=True, warmup=2):
+    def __init__(self, model, args, opt, sync=None, use_graph=True, warmup=2, pre_step=None):
         self.model, self.args, self.opt, self.sync = model, args, opt, sync
+        self.pre_step = pre_step      # e.g. clip_grad_norm_ in front of a stock optimizer (between exchange and step)
         self.use_graph, self.warmup = use_graph, warmup
         self.graph = None
         self.xbuf = None
@@ -30,6 +35,8 @@ class GraphedTrainStep:
             model.attach_grad_sync(sync)
 
     def _fwd_bwd(self, x, epoch):
+        if self.sync is not None:
+            self.sync.begin_step()
         loss = self.model.loss_fn(args=self.args, x=x, curr_epoch=epoch)
         self.opt.zero_grad()
         loss.backward()
@@ -38,6 +45,8 @@ class GraphedTrainStep:
     def _tail(self):
         if self.sync is not None:
             self.sync.all_reduce_grads()
+        if self.pre_step is not None:
+            self.pre_step()
         self.opt.step()
 
     def _capture(self, x, epoch):
@@ -61,14 +70,37 @@ class GraphedTrainStep:
                 self._tail()
         self.graph = g
 
-    def _all_ranks_agree(self, ok):
+    def _try_capture(self, x, epoch):
+        """-> (captured, stepped).  Never raises: under data parallelism every rank must come out of here and meet
+        the others in `_agree` before anyone decides how to go on."""
+        try:
+            self._capture(x, epoch)
+            return True, True
+        except Exception as e:  # noqa: BLE001
+            # _capture's warm-up pass is a full optimisation step: if the failure came after it, this batch has been
+            # trained on already
+            stepped = bool(self.loss is not None and self.xbuf is not None and self.xbuf.shape == x.shape
+                           and getattr(self, '_warm_done', False))
+            print('graph capture %sfailed (%s: %s)' % ('with the gradient exchange ' if self.sync is not None and
+                                                       self.sync_in_graph else '', type(e).__name__, str(e)[:200]),
+                  file=sys.stderr)
+            self.graph = None
+            if self.sync is not None:
+                self.sync.begin_step()              # a half-issued exchange must not leak into the next step
+            torch.cuda.synchronize()
+            return False, stepped
+
+    def _agree(self, ok, stepped):
         """Under data parallelism every rank must take the same path (a rank that replays and a rank that steps
-        eagerly issue different numbers of collectives): capture counts only if it worked everywhere."""
+        eagerly issue different numbers of collectives): ONE collective settles (capture worked everywhere, this
+        batch's step ran everywhere, ... anywhere)."""
         if self.sync is None or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
-            return ok
-        flag = torch.tensor([1.0 if ok else 0.0], device=self.loss.device if self.loss is not None else 'cuda')
+            return ok, stepped, stepped
+        dev = self.loss.device if self.loss is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
+        flag = torch.tensor([float(ok), float(stepped), -float(stepped)], device=dev)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        return bool(flag.item() > 0.5)
+        ok_all, st_all, st_any = (float(v) for v in flag.cpu())
+        return ok_all > 0.5, st_all > 0.5, st_any < -0.5
 
     def __call__(self, x, epoch=0):
         """One optimisation step on batch x; returns the loss as a device scalar (no host sync)."""
@@ -77,31 +109,22 @@ class GraphedTrainStep:
             self.model.set_epoch(self.args, epoch)        # --use_C: the KL capacity's device scalar (no re-capture)
         if (self.use_graph and self.graph is None and self.seen > self.warmup
                 and (self.xbuf is None or x.shape == self.xbuf.shape)):
-            stepped = False
-            try:
-                self._capture(x, epoch)
-                stepped, ok = True, True
-            except Exception as e:  # noqa: BLE001
-                # _capture's warm-up pass is a full optimisation step: if the failure came after it, this batch has
-                # been trained on already
-                stepped = self.loss is not None and self.xbuf is not None and self.xbuf.shape == x.shape and \
-                    getattr(self, '_warm_done', False)
-                ok = False
+            ok, stepped = self._try_capture(x, epoch)
+            ok, stepped, stepped_any = self._agree(ok, stepped)      # every rank, before any rank retries or returns
+            if stepped != stepped_any:
+                raise RuntimeError('graph capture: the warm-up step ran on some ranks only; the ranks\' weights '
+                                   'have diverged')
+            if not ok:
+                self.graph = None
                 if self.sync is not None and self.sync_in_graph:
-                    # retry once with the exchange and the optimizer outside the graph
+                    # together, at the next step: forward + backward only in the graph, exchange + optimizer eagerly
+                    # after each replay, no collective forked inside the capture
                     self.sync_in_graph = False
-                    print('graph capture with the gradient exchange failed (%s: %s); retrying with forward + '
-                          'backward only' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
-                    torch.cuda.synchronize()
-                    self.seen -= 1
-                    if stepped:
-                        return self.loss
-                    return self.__call__(x, epoch)
-                print('graph capture failed (%s: %s); training eagerly' % (type(e).__name__, str(e)[:200]),
-                      file=sys.stderr)
-                torch.cuda.synchronize()
-            if not self._all_ranks_agree(ok):
-                self.use_graph, self.graph = False, None
+                    self.sync.early_enabled = False
+                    print('retrying at the next step with forward + backward only in the graph', file=sys.stderr)
+                else:
+                    self.use_graph = False
+                    print('training eagerly', file=sys.stderr)
             if stepped:
                 # the capture's warm-up pass WAS this batch's optimisation step (capturing itself executes nothing):
                 # replaying / stepping now would train on the batch a second time

@@ -17,6 +17,12 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2 (the stricter reading of "relative error" next to rel()'s max-norm)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 def gold(name):
     z = np.load(os.path.join(GOLD, name + '.npz'))
     return {k: torch.from_numpy(z[k]) for k in z.files}

@@ -111,3 +111,74 @@ def test_grad_allreduce_world2():
     assert torch.equal(T(a['early_first'][2]), T(a['local'][2]))          # late slice untouched so far
     assert a['dead_none'] and b['dead_none']
     assert a['shard'] == (0, 5) and b['shard'] == (5, 10)
+
+
+def _trainer_worker(rank, world, port, q):
+    """GraphedTrainStep's decisions under a capture that fails on ONE rank only (stubbed capture: there is no GPU
+    here): every rank must reach the agreement collective, then fall back together -- first to forward + backward only
+    in the graph (exchange outside, early overlap off), then, when that fails on the other rank, to eager steps."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from infodiffusion_amd.dist import GradSync
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    net = torch.nn.Linear(4, 2)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def loss_fn(self, args, x, curr_epoch=0):
+            return self.net(x).square().mean()
+
+    model = Model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    sync = GradSync(model, world)
+    step = GraphedTrainStep(model, None, opt, sync=sync, use_graph=True, warmup=1)
+    log = []
+    fails = {2: 0, 3: 1}       # call number -> the rank whose capture fails in that call
+
+    def fake_try_capture(x, epoch):
+        call = step.seen
+        step.xbuf = x.clone()
+        step.loss = step._fwd_bwd(x, epoch)         # the warm-up pass: a full step, collectives included
+        step._tail()
+        ok = fails.get(call) != rank
+        if ok:
+            step.graph = 'captured'                  # never replayed below: the other rank's failure drops it
+        log.append(('capture', call, ok, step.sync_in_graph, sync.early_enabled))
+        return ok, True
+    step._try_capture = fake_try_capture
+    torch.manual_seed(10 + rank)
+    xs = [torch.randn(3, 4) for _ in range(5)]
+    states = []
+    for x in xs:
+        step(x, 0)
+        states.append((step.graph is not None, step.use_graph, step.sync_in_graph, sync.early_enabled))
+    q.put((rank, {'log': log, 'states': states, 'w': net.weight.detach().tolist()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_takes_every_rank_down_the_same_path():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0                         # nobody hung in a mismatched collective
+    a, b = got[0], got[1]
+    assert a['states'] == b['states']
+    # call 1 eager; call 2: capture fails on rank 0 -> both drop it, exchange leaves the graph, early overlap off;
+    # call 3: capture (forward + backward only) fails on rank 1 -> both train eagerly from then on
+    assert a['states'] == [(False, True, True, True), (False, True, False, False), (False, False, False, False),
+                           (False, False, False, False), (False, False, False, False)]
+    assert [e[:3] for e in a['log']] == [('capture', 2, False), ('capture', 3, True)]
+    assert [e[:3] for e in b['log']] == [('capture', 2, True), ('capture', 3, False)]
+    assert torch.equal(torch.tensor(a['w']), torch.tensor(b['w']))      # replicas still identical after 5 steps

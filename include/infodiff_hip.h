@@ -117,6 +117,44 @@ int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void* x, const v
                            const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int H, int W, int Cin,
                            int Cout, int taps, void* stream);
 
+/* The same backward at the BIG maps (64x64 / 32x32: a workgroup tile is a slice of an image, so the GroupNorm backward's
+ * per-(sample, group) sums cannot close inside one block) -- the backward mirror of idf_conv_gn_bf16's producer-side
+ * statistics (reference modules.py:264-288, 309-320 backward; run.py:197 loss.backward()).
+ *
+ *   out = conv(g, w),  w = data-gradient weights [Cout][taps][Cin] (flipped taps), stride 1, taps 9 or 1.
+ *
+ * du EPILOGUE (x != NULL): the forward conv read a = dropout(act(x*sc+sh)) (x [B,H,W,Cout], or the pair x [..,C1] |
+ *   x2 [..,Cout-C1] with C1 % 64 == 0; sc / sh [B,Cout] as saved by idf_conv_gn_bf16; act / seed / salt / p_drop as
+ *   there): out = du = dA * act'(x*sc+sh) * mask (bf16) and part_out [B][T][Cout][2] = per-pixel-tile partial sums
+ *   (sum du, sum du*x) of the rounded du, T = idf_conv_dgrad_chain_tiles().  What is left of the GroupNorm backward is
+ *   reduction-free: idf_gn_bwd_apply (a streaming pass), or --
+ * dy PROLOGUE (in_x != NULL): -- the NEXT data-gradient conv (the one in front of that GroupNorm) takes (du, partials) in
+ *   place of its input gradient: `dy` = du_in, in_x = the GroupNorm's input, in_part [B][in_T][Cin][2]; every block folds the
+ *   partials with in_mean / in_rstd [B,32], in_sc [B,Cin], in_gamma / in_beta [Cin], in_film_t / in_film_a (layout and
+ *   strides as idf_gn_coef_fwd) into g = A*du_in + K1*in_x + K0 while it stages its tile.  One block per image stores that
+ *   GroupNorm's parameter / FiLM gradients (in_dfilm_t .. in_dbeta_acc: as idf_gn_fused_bwd's dfilm_t .. dbeta_acc), and g
+ *   itself is written once to dy_out (optional; the weight gradient of the conv in front needs it).
+ * With x == NULL the epilogue is the plain one (out = dA).  bf16; Cin % 32 == 0, Cout % 64 == 0, W a power of two in
+ * [4, 128]; idf_conv_dgrad_chain_tiles() < 0: shape not covered. */
+int idf_conv_dgrad_chain_tiles(int B, int H, int W, int Cin, int Cout, int taps);
+int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T, const float* in_mean,
+                              const float* in_rstd, const float* in_sc, const float* in_gamma, const float* in_beta,
+                              const float* in_film_t, const float* in_film_a, int in_ld_t, int in_ld_a,
+                              float* in_dfilm_t, float* in_dfilm_a, float* in_dgb, float* in_dgamma_acc,
+                              float* in_dbeta_acc, void* dy_out, const void* w, const void* x, const void* x2, int C1,
+                              const float* sc, const float* sh, const uint64_t* seed, uint32_t salt, float p_drop,
+                              int act, void* out, float* part_out, int B, int H, int W, int Cin, int Cout, int taps,
+                              void* stream);
+/* dx = A*du + K1*x + K0 (+ dres + dres2) from the (du, part [B][T][C][2]) pair idf_conv_dgrad_chain_bf16 leaves behind: the
+ * GroupNorm / FiLM backward of modules.py:312-318 without its reduction (one read of du, x and the branch gradients, one
+ * write of dx; every block folds its image's partials first).  x may be the pair x [..,C1] | x2 (then dx2 is written too).
+ * Side outputs (dfilm_t / dfilm_a [B,2C], dgb [B,2,C] or the dgamma_acc / dbeta_acc accumulators) as idf_gn_fused_bwd. */
+int idf_gn_bwd_apply(const void* du, const float* part, int T, const void* x, const void* x2, int C1, const void* dres,
+                     const void* dres2, void* dx, void* dx2, const float* gamma, const float* beta, const float* film_t,
+                     const float* film_a, int ld_t, int ld_a, const float* mean, const float* rstd, const float* sc,
+                     float* dfilm_t, float* dfilm_a, float* dgb, float* dgamma_acc, float* dbeta_acc, int B, int HW,
+                     int C, void* stream);
+
 /* dW[n][tap][c] (fp32, zeroed inside) = sum_m dy[m,n] * act(x[gather(m,tap),c]);
  * same prologue arguments as the forward so the activated input is recomputed. */
 int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const float* sc, const float* sh,

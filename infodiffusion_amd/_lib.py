@@ -28,6 +28,10 @@ SIGNATURES = {
     'idf_conv_gn_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _u32, _f] + [_p] * 11 + [_i] * 6 + [_p], C.c_int),
     'idf_conv_dgrad_gn_ok': ([_i] * 6, C.c_int),
     'idf_conv_dgrad_gn_bf16': ([_p] * 10 + [_i, _i] + [_p] * 10 + [_u32, _f] + [_i] * 7 + [_p], C.c_int),
+    'idf_conv_dgrad_chain_tiles': ([_i] * 6, C.c_int),
+    'idf_conv_dgrad_chain_bf16': ([_p, _p, _p, _i] + [_p] * 7 + [_i, _i] + [_p] * 5 + [_p] + [_p, _p, _p, _i] + [_p] * 3 +
+                                  [_u32, _f, _i] + [_p, _p] + [_i] * 6 + [_p], C.c_int),
+    'idf_gn_bwd_apply': ([_p, _p, _i, _p, _p, _i] + [_p] * 8 + [_i, _i] + [_p] * 8 + [_i] * 3 + [_p], C.c_int),
     'idf_gn_partials_chunks': ([_i, _i], C.c_int),
     'idf_gn_partials': ([_p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_conv2d_wgrad': ([_p, _p, _p, _p, _p, _p, _u32, _f] + [_i] * 11 + [_p], C.c_int),

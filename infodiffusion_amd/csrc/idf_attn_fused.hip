@@ -19,6 +19,7 @@
 //   bwd-B : LDS = Q, dO      rows = keys      P^T, dS^T from the saved row statistics
 //                                             dV = P^T dO, dK = dS^T Q
 #include "idf_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -277,38 +278,46 @@ __global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restri
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + D, 3 * D, out, lane, scale);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: raised once per (kernel set, device), not per
+// launch; a failure is reported to the caller (the launch would otherwise run without the LDS opt-in).
 template <int D, int AN>
-void raise_lds_once() {       // hipFuncAttributeMaxDynamicSharedMemorySize: once per kernel, not per launch
-  static const int done = [] {
-    const int lds = (int)ACfg<D, AN>::LDS;
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    return 1;
-  }();
-  (void)done;
+hipError_t raise_lds_once() {
+  static std::atomic<unsigned> done{0};        // bit d: device d has the attribute (devices >= 32: set every time)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 32 && (done.load(std::memory_order_relaxed) >> dev) & 1u) return hipSuccess;
+  const int lds = (int)ACfg<D, AN>::LDS;
+  e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_q_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
+  return e;
 }
 
 template <int D, int AN>
-void launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, hipStream_t st) {
-  raise_lds_once<D, AN>();
+hipError_t launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, hipStream_t st) {
+  if (hipError_t e = raise_lds_once<D, AN>(); e != hipSuccess) return e;
   const size_t lds = ACfg<D, AN>::LDS;
   static const int rb_min_b = getenv("IDF_ATTN_RB_MINB") ? atoi(getenv("IDF_ATTN_RB_MINB")) : 128;
   const int rb = (B >= rb_min_b) ? AN / 64 : 1;       // whole image per workgroup once the batch alone fills the chip
   hipLaunchKernelGGL((attn_fwd_kernel<D, AN>), dim3(AN / 64 / rb, B), dim3(ANT), lds, st, (const bf16_t*)qkv,
                      (bf16_t*)o, lse, scale, rb);
+  return hipGetLastError();
 }
 
 template <int D, int AN>
-void launch_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, float scale,
-                hipStream_t st) {
-  raise_lds_once<D, AN>();
+hipError_t launch_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, float scale,
+                      hipStream_t st) {
+  if (hipError_t e = raise_lds_once<D, AN>(); e != hipSuccess) return e;
   const dim3 g(AN / 64, B);
   const size_t lds = ACfg<D, AN>::LDS;
   hipLaunchKernelGGL((attn_bwd_q_kernel<D, AN>), g, dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
                      (bf16_t*)dqkv, dsum, scale);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;       // a failure here is the q launch's, not the kv launch's
   hipLaunchKernelGGL((attn_bwd_kv_kernel<D, AN>), g, dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
                      lse, dsum, (bf16_t*)dqkv, scale);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -322,9 +331,10 @@ extern "C" int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, 
   if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
   if (B == 0) return IDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (N == 256) { if (D == 128) launch_fwd<128, 256>(qkv, o, lse, B, scale, st); else launch_fwd<64, 256>(qkv, o, lse, B, scale, st); }
-  else { if (D == 128) launch_fwd<128, 64>(qkv, o, lse, B, scale, st); else launch_fwd<64, 64>(qkv, o, lse, B, scale, st); }
-  IDF_CHECK_LAUNCH();
+  hipError_t e;
+  if (N == 256) e = D == 128 ? launch_fwd<128, 256>(qkv, o, lse, B, scale, st) : launch_fwd<64, 256>(qkv, o, lse, B, scale, st);
+  else e = D == 128 ? launch_fwd<128, 64>(qkv, o, lse, B, scale, st) : launch_fwd<64, 64>(qkv, o, lse, B, scale, st);
+  if (e != hipSuccess) IDF_FAIL((int)e, "attn_fwd: %s", hipGetErrorString(e));
   return IDF_OK;
 }
 
@@ -333,13 +343,9 @@ extern "C" int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, f
   if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_bwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
   if (B == 0) return IDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (N == 256) {
-    if (D == 128) launch_bwd<128, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
-    else launch_bwd<64, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
-  } else {
-    if (D == 128) launch_bwd<128, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
-    else launch_bwd<64, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
-  }
-  IDF_CHECK_LAUNCH();
+  hipError_t e;
+  if (N == 256) e = D == 128 ? launch_bwd<128, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st) : launch_bwd<64, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
+  else e = D == 128 ? launch_bwd<128, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st) : launch_bwd<64, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
+  if (e != hipSuccess) IDF_FAIL((int)e, "attn_bwd: %s (query / key-value launch)", hipGetErrorString(e));
   return IDF_OK;
 }

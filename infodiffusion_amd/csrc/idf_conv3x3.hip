@@ -16,6 +16,7 @@
 // LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-ed with
 // 2*((row>>2)&1), which makes ds_read_b128 of any 16 consecutive rows conflict-free.
 #include "idf_common.h"
+#include "idf_gnfold.h"
 #include <atomic>
 #include <stdlib.h>
 
@@ -58,6 +59,16 @@ struct C3P {
   const bf16_t* gnb_res2;
   const float* gnb_sc; const float* gnb_sh; const float* gnb_mean; const float* gnb_rstd;
   float* gnb_dfilm_t; float* gnb_dfilm_a; float* gnb_dgb; float* gnb_dgam; float* gnb_dbet;
+  // ---- backward chain at the big maps (BWD & 2, "du epilogue"): the accumulator tile is dA, the gradient w.r.t. the activated
+  // tensor a = dropout(act(x * sc + sh)) of a GroupNorm stage; the epilogue writes du = dA * act'(x*sc+sh) * mask (bf16) into y
+  // and the per-(image, pixel tile, channel) partial sums (sum du, sum du * x) into st_out.  x may be the pair x | x2.
+  const bf16_t* due_x; const bf16_t* due_x2; int due_C1;
+  const float* due_sc; const float* due_sh;
+  // (BWD & 1, "dy prologue"): the conv input is itself the gradient of a GroupNorm stage that exists only as (du, partials):
+  // dy = A * du + K1 * xg + K0 with x = du, dyp_x = xg (that GroupNorm's input), coefficients folded in-block from dyp_f
+  // (gn_bwd_fold; block (row tile 0, cout tile 0) of an image stores that GroupNorm's parameter / FiLM gradients);
+  // dyp_out: dy written once (interior vectors of cout tile 0), kept for the weight gradient of the conv that produced xg
+  const bf16_t* dyp_x; bf16_t* dyp_out; GnFoldP dyp_f;
   // ---- persistent wave-specialised form (conv_ps_bf16): a pixel tile = NI images x R rows x W columns = 256 pixels
   int ps_NI, ps_rwshift;        // images per tile, log2(R * W)
   int ps_npi;                   // halo pixels per image, (R + 2 halo)(W + 2 halo)
@@ -439,6 +450,105 @@ __device__ __forceinline__ void gnb_epilogue(const C3P& p, const f32x4_t (&acc)[
   }
 }
 
+// Epilogue of a data-gradient conv at the big maps (a tile is a slice of an image): du = dA * act'(x*sc+sh) * mask goes out
+// in place of dA, together with the per-channel partial sums the GroupNorm backward needs (sum du, sum du * x) -- the
+// backward mirror of lds_epilogue's statistics.  x is fetched at the top (its latency hides behind the accumulators' trip
+// through LDS); the sums are of the bf16-rounded du, i.e. of what the consumer of du will read.
+template <int TM, int TN, int BM, int BN, int NT>
+__device__ __forceinline__ void due_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,
+                                             int n0, int KT, int tid, int wm0, int wn0) {
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int W = p.W, R = p.R, C = p.Cout;
+  constexpr int PF = BN + 4, CPR = BN / 8, NI = BM * CPR / NT;
+  static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "a thread keeps one channel slot");
+  float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]
+  const int cc = (tid % CPR) * 8;                  // this thread's 8 channels of the tile
+  // the GroupNorm's input: x [.., C1] | x2 [.., C - C1] (C1 % BN == 0: a cout tile lies in one of them)
+  const bf16_t* xs = p.due_x;
+  int xpitch = C, xc = n0 + cc;
+  if (p.due_x2) {
+    if (n0 < p.due_C1) xpitch = p.due_C1;
+    else { xs = p.due_x2; xpitch = C - p.due_C1; xc -= p.due_C1; }
+  }
+  uint4 xr[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int pl = (tid + k * NT) / CPR;
+    xr[k] = make_uint4(0, 0, 0, 0);
+    if (pl < KT) xr[k] = *reinterpret_cast<const uint4*>(xs + ((size_t)(b * p.H + oy0) * W + pl) * xpitch + xc);
+  }
+  float scv[8], shv[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 a4 = *reinterpret_cast<const float4*>(p.due_sc + (size_t)b * C + n0 + cc + 4 * q);
+    const float4 b4 = *reinterpret_cast<const float4*>(p.due_sh + (size_t)b * C + n0 + cc + 4 * q);
+    scv[4 * q] = a4.x; scv[4 * q + 1] = a4.y; scv[4 * q + 2] = a4.z; scv[4 * q + 3] = a4.w;
+    shv[4 * q] = b4.x; shv[4 * q + 1] = b4.y; shv[4 * q + 2] = b4.z; shv[4 * q + 3] = b4.w;
+  }
+  const bool drop = p.act == 2 && p.seed != nullptr;
+  const uint64_t seedv = drop ? *p.seed : 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      int nl = wn0 + a * 16 + fq * 4;
+      *reinterpret_cast<float4*>(Os + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+    }
+  }
+  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int pl = (tid + k * NT) / CPR;
+    if (pl < KT) {
+      float dav[8], xv[8], du[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc), v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
+      dav[0] = v0.x; dav[1] = v0.y; dav[2] = v0.z; dav[3] = v0.w; dav[4] = v1.x; dav[5] = v1.y; dav[6] = v1.z; dav[7] = v1.w;
+      const uint32_t w4[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xv[2 * i] = __uint_as_float(w4[i] << 16); xv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+      const size_t e0 = ((size_t)(b * p.H + oy0) * W + pl) * C + n0 + cc;      // index in the dense activated tensor
+      const uint32_t h = drop ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
+      if (p.act == 2) {
+#pragma unroll
+        for (int g0 = 0; g0 < 8; g0 += 4) {
+          if (drop) idf_dact_vec_t<4, true, true>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
+          else idf_dact_vec_t<4, true, false>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) du[e] = dav[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        du[e] = bf16_to_f32(f32_to_bf16(du[e]));
+        s1[e] += du[e]; s2[e] += du[e] * xv[e];
+      }
+      Vec16<bf16_t>::store(p.y + e0, du);
+    }
+  }
+  // lanes CPR apart hold the same channels: fold them, then the waves through LDS (outside the fp32 tile)
+#pragma unroll
+  for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+  float* part = reinterpret_cast<float*>(smem + p.aux_off);     // [waves][BN][2]
+  if (lane < CPR) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[(wave * BN + lane * 8 + e) * 2] = s1[e]; part[(wave * BN + lane * 8 + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < BN; c += NT) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + c) * 2]; q += part[(w * BN + c) * 2 + 1]; }
+    reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (oy0 / R)) * C + n0 + c] = make_float2(a, q);
+  }
+}
+
 // NWM = waves along the pixel axis (2 -> 256 threads; 4 -> 512 threads: a 256-pixel tile shares one
 // weight slab, halving the slab re-reads from L2 and cutting the halo overhead from 2x to 1.5x).
 // KS = 3 (3x3, pad 1) or 1 (1x1: the same pipeline without the halo -- the AttnBlock q/k/v and proj
@@ -447,8 +557,11 @@ __device__ __forceinline__ void gnb_epilogue(const C3P& p, const f32x4_t (&acc)[
 // chunk is fetched from the tensor it lies in (C1 % 32 == 0).
 // PRO: GroupNorm / FiLM / SiLU / dropout applied to the staged tile (MODE 0 only), coefficients folded in-block.
 // GNB: the epilogue is the GroupNorm backward (gnb_epilogue): a data-gradient conv whose tile is one whole image.
-template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false, bool GNB = false>
+// BWD: the backward chain at the big maps (MODE 0, BN 64, Cout % 64 == 0) -- bit 0: dy prologue (the staged input is
+// A * du + K1 * xg + K0, two tensors per vector), bit 1: du epilogue (due_epilogue).
+template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false, bool GNB = false, int BWD = 0>
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
+  constexpr bool DYP = (BWD & 1) != 0, DUE = (BWD & 2) != 0;
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
   constexpr int TAPS = KS * KS, HALO = KS / 2;
@@ -493,6 +606,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   uint4 hreg[HV], wreg[WV];
+  uint4 xreg[DYP ? HV : 1];    // DYP: the GroupNorm input xg beside du
   const int nchunks = p.Cin / CK;
 
   // chunk-invariant staging plan: global element offsets (-1 = zero fill) and LDS byte offsets
@@ -509,7 +623,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
       int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;
       int iy = ST * oy0 + hy - HALO, ix = hx - HALO;
       bool ok = (unsigned)iy < (unsigned)(ST * p.H) && (unsigned)ix < (unsigned)(ST * W);
-      if (PRO && ok && p.a_out && n0 == 0 && (unsigned)(hy - HALO) < (unsigned)R && (unsigned)(hx - HALO) < (unsigned)W)
+      if (((PRO && p.a_out) || (DYP && p.dyp_out)) && ok && n0 == 0 && (unsigned)(hy - HALO) < (unsigned)R &&
+          (unsigned)(hx - HALO) < (unsigned)W)
         amask |= 1u << k;
       if (MODE == 3) ok = ok && !((iy | ix) & 1);
       if (MODE >= 2) { iy >>= 1; ix >>= 1; }
@@ -544,6 +659,11 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 #pragma unroll
     for (int k = 0; k < HV; ++k)
       hreg[k] = hoff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.x + hoff[k] + c0) : make_uint4(0, 0, 0, 0);
+    if constexpr (DYP) {
+#pragma unroll
+      for (int k = 0; k < HV; ++k)
+        xreg[k] = hoff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.dyp_x + hoff[k] + c0) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int k = 0; k < WV; ++k)
       wreg[k] = woff[k] >= 0 ? *reinterpret_cast<const uint4*>(p.w + woff[k] + c0) : make_uint4(0, 0, 0, 0);
@@ -553,6 +673,29 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   bool drop = false;
   if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
   auto store_chunk = [&](int ck) {
+    if constexpr (DYP) {
+      const int cb = ck * CK + (tid & 3) * 8;         // this thread's 8 channels of the chunk (idx & 3 == tid & 3)
+      float av[8], k1v[8], k0v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float4 t4 = *reinterpret_cast<const float4*>(cof + 4 * (cb + e));
+        av[e] = t4.x; k1v[e] = t4.y; k0v[e] = t4.z;
+      }
+#pragma unroll
+      for (int k = 0; k < HV; ++k)
+        if (hoff[k] >= 0) {                           // padding pixels stay zero
+          const uint32_t d4[4] = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w}, x4[4] = {xreg[k].x, xreg[k].y, xreg[k].z, xreg[k].w};
+          uint32_t o4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = av[2 * i] * __uint_as_float(d4[i] << 16) + k1v[2 * i] * __uint_as_float(x4[i] << 16) + k0v[2 * i];
+            const float hi = av[2 * i + 1] * __uint_as_float(d4[i] & 0xffff0000u) + k1v[2 * i + 1] * __uint_as_float(x4[i] & 0xffff0000u) + k0v[2 * i + 1];
+            o4[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+          }
+          hreg[k] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+          if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.dyp_out + (unsigned)(hoff[k] + ck * CK)) = hreg[k];
+        }
+    }
     if (PRO) {
       const int cb = ck * CK + (tid & 3) * 8;         // this thread's 8 channels of the chunk (idx & 3 == tid & 3)
       float scv[8], shv[8];
@@ -582,6 +725,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   GnbPre<GNB ? BM * (BN / 8) / NT : 1> gpre;
   if constexpr (GNB) gnb_prefetch<BM, BN, NT>(p, b, n0, KT, tid, gpre);
   if (PRO) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
+  if constexpr (DYP) gn_bwd_fold<NT>(p.dyp_f, b, oy0 == 0 && n0 == 0, cof, cof + 4 * p.Cin, tid);
   for (int ck = 0; ck < nchunks; ++ck) {
     store_chunk(ck);
     __syncthreads();
@@ -604,6 +748,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
           acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
     }
     __syncthreads();
+  }
+  if constexpr (DUE) {
+    due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+    return;
   }
 
   // epilogue.  A lane holds couts n..n+3 of one pixel, i.e. 8-byte pieces scattered over 16 pixel
@@ -1396,6 +1544,20 @@ void launch_gnb(C3P& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.B * p.n_tiles), dim3(NWM * 128), lds, st, p);
 }
 
+template <int TM, int NWM, int KS, int BWD>
+void launch_bwd_chain(C3P& p, hipStream_t st) {
+  constexpr int BN = 64;
+  size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
+  size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
+  if (olds > lds) lds = olds;
+  p.aux_off = (int)lds;
+  const size_t a = (BWD & 1) ? (size_t)p.Cin * 24 : 0, s = p.st_out ? (size_t)NWM * 2 * BN * 8 : 0;    // (A, K1, K0, -) + scratch | wave partials
+  lds += a > s ? a : s;
+  auto kern = conv3x3_halo_bf16<0, TM, BN, NWM, KS, false, false, false, BWD>;
+  IDF_ENSURE_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
+}
+
 void clear_pro(C3P& p) {
   p.st_out = nullptr; p.aux_off = 0;
   p.st1 = p.st2 = nullptr; p.T1 = p.T2 = 0;
@@ -1404,6 +1566,8 @@ void clear_pro(C3P& p) {
   p.a_out = nullptr; p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr; p.cof_in = nullptr;
   p.gnb_x = p.gnb_res2 = nullptr; p.gnb_sc = p.gnb_sh = p.gnb_mean = p.gnb_rstd = nullptr;
   p.gnb_dfilm_t = p.gnb_dfilm_a = p.gnb_dgb = p.gnb_dgam = p.gnb_dbet = nullptr;
+  p.due_x = p.due_x2 = nullptr; p.due_C1 = 0; p.due_sc = p.due_sh = nullptr;
+  p.dyp_x = nullptr; p.dyp_out = nullptr; memset(&p.dyp_f, 0, sizeof(p.dyp_f));
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
 #ifdef IDF_PS_DBG
   static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
@@ -1792,6 +1956,86 @@ extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const flo
   }
   if (taps == 9) { if (x2) dispatch3<true, true>(p, 0, BM, st); else dispatch3<false, true>(p, 0, BM, st); }
   else { if (x2) dispatch1<true, true>(p, BM, st); else dispatch1<false, true>(p, BM, st); }
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// ---- the backward chain at the big maps (64x64 / 32x32: a tile is a slice of an image, so the GroupNorm backward's
+// per-(sample, group) sums cannot close inside one block as they do in idf_conv_dgrad_gn_bf16)
+//
+//   out = conv(g, w)   with w the data-gradient weights [Cout][taps][Cin] (flipped taps, idf_pack_conv_weight), stride 1
+//
+// INPUT.  in_x == NULL: g = dy [B,H,W,Cin], an ordinary gradient tensor.  in_x != NULL ("dy prologue"): dy does not exist --
+//   the conv that differentiated the GroupNorm stage BEHIND this conv left (du_in = `dy`, in_part [B][in_T][Cin][2]) and
+//   g = A*du_in + K1*in_x + K0 is formed while the tile is staged (in_x = that GroupNorm's input; in_mean .. in_film_a its
+//   saved statistics / parameters; coefficients: idf_gnfold.h).  That GroupNorm's parameter / FiLM gradients
+//   (in_dfilm_t .. in_dbeta_acc, as idf_gn_fused_bwd) are stored by one block per image, and g is written once to dy_out
+//   (optional) for the weight gradient of the conv in front of it.
+// OUTPUT.  x == NULL: out = dA, a plain data gradient (+ no epilogue extras).  x != NULL ("du epilogue"): the conv input
+//   was a = dropout(act(x*sc+sh)) (x possibly the pair x | x2, C1 % 64 == 0); out = du = dA * act'(x*sc+sh) * mask and
+//   part_out [B][T][Cout][2] = per-tile (sum du, sum du*x), T = idf_conv_dgrad_chain_tiles(...): feed both to
+//   idf_gn_bwd_apply, or to the next call of this function as (dy, in_part).
+// bf16, Cin % 32 == 0, Cout % 64 == 0, W a power of two in [4, 128].
+extern "C" int idf_conv_dgrad_chain_tiles(int B, int H, int W, int Cin, int Cout, int taps) {
+  int BM, R;
+  if ((taps != 9 && taps != 1) || (Cout % 64) || (Cin % CK)) return -1;
+  if (taps == 9) { if (!shape3_ok(H, W, Cin, Cout, 0) || !plan3(B, H, W, Cout, 0, &BM, &R)) return -1; }
+  else { if (!shape1_ok(W, Cin, Cout) || !plan1(B, H, W, Cout, &BM, &R)) return -1; }
+  return H / R;
+}
+
+extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T,
+                                         const float* in_mean, const float* in_rstd, const float* in_sc,
+                                         const float* in_gamma, const float* in_beta, const float* in_film_t,
+                                         const float* in_film_a, int in_ld_t, int in_ld_a, float* in_dfilm_t,
+                                         float* in_dfilm_a, float* in_dgb, float* in_dgamma_acc, float* in_dbeta_acc,
+                                         void* dy_out, const void* w, const void* x, const void* x2, int C1,
+                                         const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
+                                         float p_drop, int act, void* out, float* part_out, int B, int H, int W, int Cin,
+                                         int Cout, int taps, void* stream) {
+  if (idf_conv_dgrad_chain_tiles(B, H, W, Cin, Cout, taps) < 0)
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_chain_bf16: B%d H%d W%d Cin%d Cout%d taps%d not covered", B, H, W, Cin, Cout, taps);
+  if (!dy || !w || !out) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_bf16: null argument");
+  if (in_x && (!in_part || in_T < 1 || !in_mean || !in_rstd || !in_sc))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_bf16: dy prologue needs partials, mean, rstd and sc");
+  if (x && (!sc || !sh || !part_out || (act != 1 && act != 2))) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_bf16: du epilogue needs sc, sh, part_out, act 1|2");
+  if (!x2) C1 = Cout;
+  if (x && x2 && (C1 <= 0 || C1 >= Cout || (C1 % 64))) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_chain_bf16: C1 %d of %d", C1, Cout);
+  if (!in_x && !x) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_bf16: neither prologue nor epilogue asked for (use idf_conv3x3_bf16)");
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)dy; p.x2 = nullptr; p.C1 = Cin; p.w = (const bf16_t*)w; p.bias = nullptr; p.res = nullptr;
+  p.y = (bf16_t*)out;
+  int BM;
+  if (int e = fill_common(p, B, H, W, Cin, Cout, 0, taps == 9 ? 3 : 1, &BM))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv_dgrad_chain_bf16: tile too large (H%d W%d)" : "conv_dgrad_chain_bf16: tensor too large for 32-bit offsets", H, W);
+  p.n_tiles = Cout / 64;
+  if (in_x) {
+    p.dyp_x = (const bf16_t*)in_x; p.dyp_out = (bf16_t*)dy_out;
+    GnFoldP& f = p.dyp_f;
+    f.part = in_part; f.T = in_T; f.mean = in_mean; f.rstd = in_rstd; f.sc = in_sc; f.gamma = in_gamma; f.beta = in_beta;
+    f.film_t = in_film_t; f.film_a = in_film_a; f.ld_t = in_ld_t ? in_ld_t : 2 * Cin; f.ld_a = in_ld_a ? in_ld_a : 2 * Cin;
+    f.dfilm_t = in_dfilm_t; f.dfilm_a = in_dfilm_a; f.dgb = in_dgb; f.dgam = in_dgamma_acc; f.dbet = in_dbeta_acc;
+    f.C = Cin; f.HW = H * W;
+  }
+  if (x) {
+    p.due_x = (const bf16_t*)x; p.due_x2 = (const bf16_t*)x2; p.due_C1 = C1; p.due_sc = sc; p.due_sh = sh;
+    p.st_out = part_out;
+    p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
+    p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+    p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int bwd = (in_x ? 1 : 0) | (x ? 2 : 0);
+#define IDF_CHAIN(KS)                                                                                     \
+  do {                                                                                                    \
+    if (BM == 256) { if (bwd == 3) launch_bwd_chain<4, 4, KS, 3>(p, st); else if (bwd == 2) launch_bwd_chain<4, 4, KS, 2>(p, st); else launch_bwd_chain<4, 4, KS, 1>(p, st); } \
+    else if (BM == 128) { if (bwd == 3) launch_bwd_chain<4, 2, KS, 3>(p, st); else if (bwd == 2) launch_bwd_chain<4, 2, KS, 2>(p, st); else launch_bwd_chain<4, 2, KS, 1>(p, st); } \
+    else { if (bwd == 3) launch_bwd_chain<2, 2, KS, 3>(p, st); else if (bwd == 2) launch_bwd_chain<2, 2, KS, 2>(p, st); else launch_bwd_chain<2, 2, KS, 1>(p, st); } \
+  } while (0)
+  if (taps == 9) IDF_CHAIN(3); else IDF_CHAIN(1);
+#undef IDF_CHAIN
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

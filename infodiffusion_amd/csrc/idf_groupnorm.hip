@@ -14,6 +14,7 @@
 //   dx = sc*du + k1[b,g]*x + k0[b,g]      (+ dres)
 // with k1, k0, dgamma, dbeta and the FiLM gradients derived from S1, S2 only.
 #include "idf_common.h"
+#include "idf_gnfold.h"
 #include <stdlib.h>
 
 namespace {
@@ -645,6 +646,61 @@ __global__ __launch_bounds__(1024) void gn_small_bwd(const T* __restrict__ dA, c
   }
 }
 
+// ---------------------------------------------------------- streaming backward from conv-epilogue partials
+// The data-gradient conv that produced dA already formed du = dA * act'(x*sc+sh) * mask and the per-channel sums
+// (idf_conv_dgrad_du_bf16): what is left of the GroupNorm backward is a streaming pass with no reduction in it --
+//   dx = A*du + K1*x + K0 (+ dres + dres2)
+// grid (chunks, B).  Every block folds its image's partials into (A, K1, K0) per channel (gn_bwd_fold; the block of chunk
+// 0 also stores dgamma / dbeta / dFiLM), then streams its pixel chunk: a thread keeps one 16-byte channel slot for its
+// whole pixel loop.  x may be the never-materialised concatenation x | x2 (dx goes back to the matching tensor).
+__global__ __launch_bounds__(256) void gn_bwd_apply_part(const bf16_t* __restrict__ du, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ x2, int C1,
+                                                         const bf16_t* __restrict__ dres, const bf16_t* __restrict__ dres2,
+                                                         bf16_t* __restrict__ dx, bf16_t* __restrict__ dx2, const GnFoldP f,
+                                                         int chunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // cof [C][4] | pc [C][2]
+  const int C = f.C, HW = f.HW, tid = threadIdx.x, b = blockIdx.y;
+  float* cof = sm;
+  gn_bwd_fold<256>(f, b, blockIdx.x == 0, cof, sm + 4 * C, tid);
+  const int vpp = C / 8, lanes = 256 / vpp, v = tid % vpp, pl = tid / vpp;
+  if (pl >= lanes) return;
+  float av[8], k1v[8], k0v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float4 t4 = *reinterpret_cast<const float4*>(cof + 4 * (v * 8 + e));
+    av[e] = t4.x; k1v[e] = t4.y; k0v[e] = t4.z;
+  }
+  const bf16_t* src = x;
+  bf16_t* dst = dx;
+  int spitch = C, sc0 = v * 8;
+  if (x2) {
+    if (sc0 < C1) spitch = C1;
+    else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
+  }
+  const int pend = min(HW, (int)(blockIdx.x + 1) * chunk);
+  for (int p = blockIdx.x * chunk + pl; p < pend; p += lanes) {
+    const size_t e0 = ((size_t)b * HW + p) * C + v * 8, es = ((size_t)b * HW + p) * spitch + sc0;
+    float xv[8], dv[8], o[8];
+    Vec16<bf16_t>::load(src + es, xv);
+    Vec16<bf16_t>::load(du + e0, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = av[e] * dv[e] + k1v[e] * xv[e] + k0v[e];
+    if (dres) {
+      float rv[8];
+      Vec16<bf16_t>::load(dres + e0, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += rv[e];
+    }
+    if (dres2) {
+      float rv[8];
+      Vec16<bf16_t>::load(dres2 + e0, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += rv[e];
+    }
+    Vec16<bf16_t>::store(dst + es, o);
+  }
+}
+
 // Slice plan for the one-launch kernels: CS channels per block (whole groups, whole 16-byte vectors,
 // CS/VE a power of two <= 64) and the block size.  Largest slice that still gives >= ~256 blocks.
 struct SmallPlan { int CS, NT, VS; };   // VS = lanes per pixel (power of two >= CS / VE)
@@ -884,6 +940,38 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
     if (keep2) IDF_GN_BWD(bf16_t, 2); else if (keep) IDF_GN_BWD(bf16_t, 4); else if (nvt > SNV) IDF_GN_BWD(bf16_t, -1); else IDF_GN_BWD(bf16_t, 0);
   }
 #undef IDF_GN_BWD
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// dx (and the GroupNorm's parameter / FiLM gradients) from du and the per-channel partials a data-gradient conv left
+// behind (idf_conv_dgrad_du_bf16): bf16, C % 32 == 0, C <= 1024.  part [B][T][C][2]; x may be the pair x [.., C1] |
+// x2 [.., C - C1] (then dx2 receives the second part's gradient).  Side outputs as idf_gn_fused_bwd.
+extern "C" int idf_gn_bwd_apply(const void* du, const float* part, int T, const void* x, const void* x2, int C1,
+                                const void* dres, const void* dres2, void* dx, void* dx2, const float* gamma,
+                                const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
+                                const float* mean, const float* rstd, const float* sc, float* dfilm_t, float* dfilm_a,
+                                float* dgb, float* dgamma_acc, float* dbeta_acc, int B, int HW, int C, void* stream) {
+  if (!x2) C1 = 0;
+  if (C % G || C % 8 || C > 1024 || C / 8 > 256 || T < 1 || C1 < 0 || C1 >= C || (C1 % 8) || (x2 && !dx2))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_bwd_apply: C=%d C1=%d T=%d not covered", C, C1, T);
+  if (!du || !part || !x || !dx || !mean || !rstd || !sc) IDF_FAIL(IDF_ERR_BADARG, "gn_bwd_apply: null argument");
+  if (B == 0) return IDF_OK;
+  GnFoldP f;
+  f.part = part; f.T = T; f.mean = mean; f.rstd = rstd; f.sc = sc; f.gamma = gamma; f.beta = beta;
+  f.film_t = film_t; f.film_a = film_a; f.ld_t = ld_t ? ld_t : 2 * C; f.ld_a = ld_a ? ld_a : 2 * C;
+  f.dfilm_t = dfilm_t; f.dfilm_a = dfilm_a; f.dgb = dgb; f.dgam = dgamma_acc; f.dbet = dbeta_acc; f.C = C; f.HW = HW;
+  // ~4 blocks per CU, all resident at once: the fold in front of every block's stream is paid once, in parallel
+  static const int want = getenv("IDF_GN_APPLY_BLOCKS") ? atoi(getenv("IDF_GN_APPLY_BLOCKS")) : 1024;
+  int nchunk = idf_cdiv(want, B);
+  int chunk = idf_cdiv(HW, nchunk);
+  const int lanes = 256 / (C / 8);
+  if (chunk < lanes) chunk = lanes;
+  if (chunk > HW) chunk = HW;
+  dim3 g(idf_cdiv(HW, chunk), B);
+  hipLaunchKernelGGL(gn_bwd_apply_part, g, dim3(256), (size_t)C * 6 * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)du, (const bf16_t*)x, (const bf16_t*)x2, C1, (const bf16_t*)dres, (const bf16_t*)dres2,
+                     (bf16_t*)dx, (bf16_t*)dx2, f, chunk);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

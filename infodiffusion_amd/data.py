@@ -37,27 +37,37 @@ class _Batches:
             self.n = len(arr) // (self.bs * world)
         self.seed = getattr(args, 'r_seed', 0)
         self.epoch = 0
-        # the reference shuffles every loader but CelebA's (data.py:184 vs 197-243)
-        self.shuffle = args.dataset != 'celeba' and getattr(args, 'mode', 'train') == 'train'
+        # the reference shuffles every loader but CelebA's, in every mode (data.py:184 vs 197-243)
+        self.shuffle = args.dataset != 'celeba'
         self.augment = args.dataset in ('celeba', 'ffhq') and getattr(args, 'mode', 'train') == 'train'   # data.py:165-166
 
     def __len__(self):
         return self.n
+
+    def set_epoch(self, epoch):
+        """The epoch the next iteration draws for (the trainer's own counter: a resumed run continues the sequence of
+        permutations / flip masks instead of replaying epoch 0's)."""
+        self.epoch = int(epoch)
+
+    def _seed(self, epoch, rank=None):
+        """Collision-free over (seed, epoch, rank): rank < world keeps its own residue class."""
+        s = (self.seed * 1000003 + epoch) * (self.world + 1)
+        return (s + (self.world if rank is None else rank)) & ((1 << 62) - 1)
 
     def __iter__(self):
         # fresh draws every epoch (flip masks, random pixels), different per rank; ONE permutation per epoch shared by
         # all ranks for the datasets the reference shuffles
         epoch, self.epoch = self.epoch, self.epoch + 1
         g = torch.Generator(device='cpu')
-        g.manual_seed((self.seed * 1000003 + epoch) * 64 + self.rank)
+        g.manual_seed(self._seed(epoch, self.rank))
         on_gpu = torch.device(self.device).type == 'cuda'
         if on_gpu and self.array is None:
             gd = torch.Generator(device=self.device)          # random pixels are drawn where they are consumed:
-            gd.manual_seed((self.seed * 1000003 + epoch) * 64 + self.rank)   # a host draw + H2D copy costs more than a step
+            gd.manual_seed(self._seed(epoch, self.rank))      # a host draw + H2D copy costs more than a step
         perm = None
         if self.array is not None and self.shuffle:
             gp = torch.Generator(device='cpu')
-            gp.manual_seed(self.seed * 1000003 + epoch)
+            gp.manual_seed(self._seed(epoch))                # shared by all ranks
             perm = torch.randperm(len(self.array), generator=gp).numpy()
         for i in range(self.n):
             if self.array is None and on_gpu:

@@ -121,7 +121,7 @@ class _UNetSkeleton(nn.Module):
                 h = block_call(layer, (h, skips.pop()))      # the block reads the pair in place (no torch.cat)
         assert len(skips) == 0
         gn, conv = self.tail[0], self.tail[-1]
-        return ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias)
+        return ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias, x_single_use=True)
 
 
 class UNet(_UNetSkeleton):

@@ -326,15 +326,17 @@ class _ResBase(nn.Module):
         if isinstance(self.shortcut, nn.Conv2d):
             self._cfg_sc = _cfg(_Shadows(self.shortcut), ops.S1, 1, _ACT_NONE)
 
-    def _gn_conv(self, name, x, film_t=None, film_a=None, drop_site=None, residual=None, passthrough=False):
+    def _gn_conv(self, name, x, film_t=None, film_a=None, drop_site=None, residual=None, passthrough=False, single=False):
         blk = getattr(self, name)
         gn, conv = blk[0], blk[-1]
         seed = self.ctx.seed if (drop_site is not None and self.training) else None
         cfg = _cfg(getattr(self, '_sh_' + name), ops.S1, 9, _ACT_SILU, self.p_drop, self.salt + (drop_site or 0))
         # every conv of a block feeds a GroupNorm (the next stage, the next block, the AttnBlock or the tail):
         # its epilogue leaves the statistics of its output behind
+        # single: x is the previous stage's conv output and nobody else reads it -- the GroupNorm backward may then be
+        # folded into that conv's data-gradient launch (ops.LazyGrad)
         return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
-                              passthrough, want_stats=True)
+                              passthrough, want_stats=True, x_single_use=single)
 
     def _block1(self, x, want_alias=False):
         """(h, residual[, alias of x]) of the block's first stage.  x may be the pair (h_prev, skip) of an
@@ -377,8 +379,8 @@ class ResBlock(_ResBase):
         ft = self._film.pop('t', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
-        h = self._gn_conv('block2', h, film_t=ft, drop_site=1)
-        h = self._gn_conv('block3', h, drop_site=2, residual=res)
+        h = self._gn_conv('block2', h, film_t=ft, drop_site=1, single=True)
+        h = self._gn_conv('block3', h, drop_site=2, residual=res, single=True)
         h = self.attn(h)
         return (h, alias[0]) if want_alias else h
 
@@ -407,8 +409,8 @@ class AuxResBlock(_ResBase):
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
         if fa is None:
             fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
-        h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1)
-        h = self._gn_conv('block3', h, drop_site=2, residual=res)
+        h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1, single=True)
+        h = self._gn_conv('block3', h, drop_site=2, residual=res, single=True)
         h = self.attn(h)
         if self.use_crossattn:
             h = self.crossattn(h, aemb)
@@ -428,7 +430,7 @@ class ResBlock_encoder(_ResBase):
 
     def forward(self, x, want_alias=False):
         h, res, *alias = self._block1(x, want_alias)
-        h = self._gn_conv('block2', h, drop_site=1, residual=res)
+        h = self._gn_conv('block2', h, drop_site=1, residual=res, single=True)
         h = self.attn(h)
         return (h, alias[0]) if want_alias else h
 

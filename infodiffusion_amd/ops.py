@@ -411,6 +411,104 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
     return dx, dgam[:C], dgam[C:], dft, dfa
 
 
+# ------------------------------------------------------------ backward chain at the big maps
+_BWD_CHAIN = os.environ.get('IDF_BWD_CHAIN', '1') != '0'     # du epilogue + streaming apply instead of the one-launch GroupNorm backward
+# ... and the apply pass folded into the NEXT data-gradient conv's prologue (LazyGrad).  Built, oracle-tested, measured, and
+# OFF by default: the prologue (in-block coefficient fold + two tensors staged per vector + the side write of dy) costs the
+# conv +25 us at 64->64 @64^2, B = 32, against the 12 us streaming pass it removes -- 10.89 vs 10.43 ms per step on one box
+# (profiles/r03_c_ab_chain_lazy.txt, r03_d_step_inventory_chain_lazy.txt)
+_BWD_LAZY = os.environ.get('IDF_BWD_LAZY', '0') != '0'
+
+
+@functools.lru_cache(maxsize=None)
+def chain_tiles(B, H, W, Cin, Cout, taps):
+    """Pixel tiles per image of idf_conv_dgrad_chain_bf16 for this data-gradient conv (Cin = channels of dy, Cout = channels
+    of dx); < 0: not covered."""
+    return int(_lib.load().idf_conv_dgrad_chain_tiles(B, H, W, Cin, Cout, taps))
+
+
+class LazyGrad:
+    """The gradient w.r.t. a GroupNorm stage's input that exists only as (du, per-tile partial sums): the data-gradient conv
+    in FRONT of that GroupNorm forms dx = A*du + K1*x + K0 while staging its tile (idf_conv_dgrad_chain_bf16's dy prologue)
+    and stores the GroupNorm's parameter / FiLM gradients where the autograd node that owns those parameters has already
+    promised them: dft / dfa (returned as the FiLM pairs' gradients; read by the batched projection's backward, after every
+    block) and acc = the ADDRESSES of the gamma / beta arena slots (addresses, not tensors: AccumulateGrad adopts a
+    gradient only while nobody else holds it -- a second reference makes it clone the still-empty view)."""
+    __slots__ = ('du', 'part', 'x', 'gn_w', 'gn_b', 'film_t', 'film_a', 'mean', 'rstd', 'sc', 'dft', 'dfa', 'acc')
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    def materialize(self):
+        """dx as a tensor (the streaming apply pass): for a consumer that cannot take the pair."""
+        acc = self.acc
+        call('idf_gn_bwd_apply', _p(self.du), _p(self.part), self.part.shape[1], _p(self.x), None, 0, None, None,
+             _p(self.du), None, _p(self.gn_w), _p(self.gn_b), _p(self.film_t), _p(self.film_a), _ld(self.film_t),
+             _ld(self.film_a), _p(self.mean), _p(self.rstd), _p(self.sc), _p(self.dft), _p(self.dfa), None,
+             acc[0] if acc else None, acc[1] if acc else None, self.du.shape[0], self.du.shape[2] * self.du.shape[3],
+             self.du.shape[1], _st())
+        return self.du        # in place: du -> dx (each element is read and written by the same thread)
+
+
+_LAZY_PENDING = {}     # du.data_ptr() -> LazyGrad on its way to the producing conv's backward
+
+
+def _lazy_check_consumed():
+    """End of a backward pass: a pair nobody consumed means a gradient tensor holding du was taken for dx."""
+    if _LAZY_PENDING:
+        n = len(_LAZY_PENDING)
+        _LAZY_PENDING.clear()
+        raise RuntimeError('infodiffusion_amd: %d lazy GroupNorm gradient(s) reached no data-gradient conv (IDF_BWD_LAZY=0 '
+                           'disables the hand-off)' % n)
+
+
+def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=None, x2=None, sc=None, sh=None, seed=None,
+                         salt=0, p_drop=0.0, act=0):
+    """Stride-1 data-gradient conv of the backward chain -> (out, part, dy_mat).  lazy: `dy` is lazy.du and the real input
+    gradient is formed in the prologue (written to dy_mat when want_dy); x (+ x2): du epilogue, out = du and part = its
+    per-tile partial sums -- else out = dA."""
+    B, Cin, H, W = dy.shape
+    out = empty_nhwc(B, Cout, H, W, dy.dtype, dy.device)
+    part = None
+    C1 = x.shape[1] if (x is not None and x2 is not None) else 0
+    if x is not None:
+        part = torch.empty((B, chain_tiles(B, H, W, Cin, Cout, taps), Cout, 2), dtype=torch.float32, device=dy.device)
+    dy_mat = torch.empty_like(dy, memory_format=CL) if (lazy is not None and want_dy) else None
+    L = lazy
+    acc = L.acc if L is not None else None
+    call('idf_conv_dgrad_chain_bf16', _p(dy), _p(L.x) if L else None, _p(L.part) if L else None, L.part.shape[1] if L else 0,
+         _p(L.mean) if L else None, _p(L.rstd) if L else None, _p(L.sc) if L else None, _p(L.gn_w) if L else None,
+         _p(L.gn_b) if L else None, _p(L.film_t) if L else None, _p(L.film_a) if L else None,
+         _ld(L.film_t) if L else 0, _ld(L.film_a) if L else 0, _p(L.dft) if L else None, _p(L.dfa) if L else None, None,
+         acc[0] if acc else None, acc[1] if acc else None, _p(dy_mat), _p(w_dgrad), _p(x), _p(x2), C1, _p(sc), _p(sh),
+         _p(seed), salt, float(p_drop), act, _p(out), _p(part), B, H, W, Cin, Cout, taps, _st())
+    return out, part, dy_mat
+
+
+def gn_bwd_apply_raw(du, part, x, gamma, beta, film_t, film_a, mean, rstd, sc, acc=None, dres=None, dres2=None, x2=None):
+    """dx (+ parameter / FiLM gradients) from the (du, part) pair a du-epilogue conv left behind: what gn_fused_bwd_raw
+    returns, by a streaming pass (no reduction left in it)."""
+    B, C1, H, W = x.shape
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
+    dev = x.device
+    dx = torch.empty_like(x, memory_format=CL)
+    dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
+    dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
+    dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
+    acc = _gn_acc(acc)
+    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    call('idf_gn_bwd_apply', _p(du), _p(part), part.shape[1], _p(x), _p(x2), C1 if x2 is not None else 0, _p(dres), _p(dres2),
+         _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc),
+         _p(dft), _p(dfa), _p(dgb), _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, B, H * W, C, _st())
+    if x2 is not None:
+        dx = (dx, dx2)
+    if acc:
+        return dx, acc[0], acc[1], dft, dfa
+    dgam = colsum_raw(dgb)
+    return dx, dgam[:C], dgam[C:], dft, dfa
+
+
 def gn_apply_raw(x, sc, sh, seed, salt, p_drop, act):
     """a = act(x*sc + sh) (+ dropout): one read + one write."""
     B, C, H, W = x.shape
@@ -464,7 +562,8 @@ class WgradBatch:
     problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
     enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
     pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1, Cin_w, Cout_w)
-    _bufs = {}         # classes of a flush -> [pinned host table, device table, key, launch plan, copy event]   (eager: reused)
+    _bufs = {}         # key of a flush -> [pinned host table, device table, key, launch plan, copy event]   (eager: LRU, insertion-ordered)
+    _LRU = 6
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
     @classmethod
@@ -490,25 +589,38 @@ class WgradBatch:
         classes = list(groups.items())
         total = len(items)
         # ONE table (and one host-to-device copy) for all the (taps, mode) classes of this flush; each class launches on
-        # its slice.  `slot` = which classes the flush carries (under data parallelism the early backbone flush and the
-        # final one are different tables).
-        slot = tuple(c for c, _ in classes)
+        # its slice.  Tables are kept per KEY (every operand address of the flush): a step's flushes -- under data
+        # parallelism the early backbone flush and the final one carry the same classes -- each find their own table
+        # again at the next step and neither synchronises nor rebuilds; a small LRU bounds the set.
         key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:11] + (_p(it[11]), it[12], it[13], it[14])
                     for _, grp in classes for it in grp)
-        buf = cls._bufs.get(slot)
-        if buf is None or buf[0].numel() < total * nb:
-            dev = items[0][0].device
-            buf = [torch.empty((max(total, 16) * nb,), dtype=torch.uint8).pin_memory(),
-                   torch.empty((max(total, 16) * nb,), dtype=torch.uint8, device=dev), None, [], None]
-            cls._bufs[slot] = buf
+        buf = cls._bufs.pop(key, None)
+        if buf is None:
+            reuse = None
+            if capturing:
+                # no pinned allocation inside a capture: take over a table an eager step made (the capture's own
+                # warm-up pass left one of the right size; the capture follows a device-wide synchronisation)
+                fit = [k for k, v in cls._bufs.items() if v[0].numel() >= total * nb]
+                if fit:
+                    reuse = cls._bufs.pop(fit[-1])
+            elif len(cls._bufs) >= cls._LRU:
+                reuse = cls._bufs.pop(next(iter(cls._bufs)))          # least recently used
+            if reuse is not None and reuse[0].numel() >= total * nb:
+                buf = reuse
+                buf[2] = None
+            else:
+                dev = items[0][0].device
+                buf = [torch.empty((max(total, 16) * nb,), dtype=torch.uint8).pin_memory(),
+                       torch.empty((max(total, 16) * nb,), dtype=torch.uint8, device=dev), None, [], None]
         if capturing:
             # the captured copy node reads this pinned table at every replay: retire the pair from
             # eager use (the warm-up step allocated it; later eager steps get a fresh one)
-            cls._graph_bufs.append(cls._bufs.pop(slot))
-            buf[2] = None
-        if buf[2] != key:
+            cls._graph_bufs.append(buf)
+        else:
+            cls._bufs[key] = buf                                       # most recently used
+        if buf[2] != key or capturing:
             if not capturing and buf[4] is not None:
-                buf[4].synchronize()        # the previous step's copy out of this pinned table has been issued AND done
+                buf[4].synchronize()        # the previous copy out of this pinned table has been issued AND done
                 # (under capture nothing may be synchronised -- and nothing needs to be: the capture follows a
                 # device-wide synchronisation, and the pair is retired to the graph)
             plan, off = [], 0
@@ -598,7 +710,7 @@ class _FusedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None,
-                passthrough=False, xst=None, want_stats=False):
+                passthrough=False, xst=None, want_stats=False, lazy_out=False):
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the statistics output / unused aliases
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
@@ -626,6 +738,12 @@ class _FusedConv(torch.autograd.Function):
         ctx.cfg, ctx.p_drop, ctx.slots = cfg, p_drop, slots or (None, None, None, None)
         ctx.has_res = residual is not None
         ctx.has_st = st is not None
+        # the backward chain of the big maps (idf_conv_dgrad_chain_bf16) covers this conv's data gradient: its GroupNorm
+        # backward then leaves the one-launch kernel, and the conv may take the gradient of its OUTPUT as a LazyGrad pair
+        ctx.chain_ok = (_BWD_CHAIN and mode == S1 and x.dtype == torch.bfloat16 and x.is_cuda and
+                        chain_tiles(x.shape[0], x.shape[2], x.shape[3], Cout, x.shape[1], taps) > 0)
+        ctx.lazy_in_ok = ctx.chain_ok and _BWD_LAZY
+        ctx.lazy_out = bool(lazy_out)
         ctx.save_for_backward(x, a if act else None, weight, bias, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                               seed)
         outs = (y,)
@@ -653,10 +771,83 @@ class _FusedConv(torch.autograd.Function):
         if dy is None:        # y itself unused: only what arrived over the aliases flows on
             dy = torch.zeros((x.shape[0], weight.shape[0]) + out_hw(mode, x.shape[2], x.shape[3]), dtype=x.dtype,
                              device=x.device).contiguous(memory_format=CL)
-        dy = _nhwc(dy.to(x.dtype))
         need = ctx.needs_input_grad
+        want_dgrad = need[0] or (act and (need[3] or need[5] or need[6]))
+        # the gradient of y may arrive as a (du, partials) pair from the GroupNorm stage that read y (LazyGrad): this
+        # conv's data-gradient launch then forms it while staging its tile; anything else needs the tensor
+        lazy_in = _LAZY_PENDING.pop(dy.data_ptr(), None)
+        if lazy_in is not None and not (ctx.chain_ok and want_dgrad):
+            dy, lazy_in = lazy_in.materialize(), None
+        dy = _nhwc(dy.to(x.dtype))
         dW = db = dx = dgw = dgb = dft = dfa = dres = None
         want_b = bias is not None and need[2]
+        if want_dgrad:
+            w_dgrad = cfg['shadows'](x.dtype, True)[1]
+            dres_in = _nhwc(dxp.to(x.dtype)) if dxp is not None else None
+            dres2_in = _nhwc(dxp2.to(x.dtype)) if dxp2 is not None else None
+            if dres_in is None:
+                dres_in, dres2_in = dres2_in, None
+            gslots = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
+            fused_bwd = bool(act) and lazy_in is None and conv_dgrad_gn_ok(dy, x, mode, taps)
+            chain = not fused_bwd and ctx.chain_ok and (bool(act) or lazy_in is not None)
+            if chain:
+                # big maps: the conv's epilogue emits du and the per-tile sums; what is left of the GroupNorm backward
+                # is a streaming pass -- or nothing, when the conv in front of this GroupNorm takes the pair
+                want_dy = lazy_in is not None and (need[1] or want_b or (ctx.has_res and need[7]))
+                if act:
+                    du, part, dy_mat = conv_dgrad_chain_raw(dy, w_dgrad, taps, x.shape[1], lazy_in, want_dy, x=x, sc=sc, sh=sh,
+                                                            seed=seed, salt=salt, p_drop=p_drop, act=act)
+                    gacc = _gn_acc(gslots) if (ctx.lazy_out and dres_in is None) else None
+                    if ctx.lazy_out and dres_in is None and (gacc is not None or not (need[3] or need[4])):
+                        dft = torch.empty(film_t.shape, dtype=torch.float32, device=x.device) if film_t is not None else None
+                        dfa = torch.empty(film_a.shape, dtype=torch.float32, device=x.device) if film_a is not None else None
+                        _LAZY_PENDING[du.data_ptr()] = LazyGrad(du=du, part=part, x=x, gn_w=gn_w, gn_b=gn_b, film_t=film_t,
+                                                                film_a=film_a, mean=mean, rstd=rstd, sc=sc, dft=dft, dfa=dfa,
+                                                                acc=(_p(gacc[0]), _p(gacc[1])) if gacc is not None else None)
+                        if len(_LAZY_PENDING) == 1:
+                            try:
+                                torch.autograd.Variable._execution_engine.queue_callback(_lazy_check_consumed)
+                            except RuntimeError:
+                                pass
+                        dx = du
+                        if gacc is not None:
+                            dgw, dgb = gacc
+                    else:
+                        dx, dgw, dgb, dft, dfa = gn_bwd_apply_raw(du, part, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc,
+                                                                  gslots, dres_in, dres2_in)
+                else:
+                    dx, _, dy_mat = conv_dgrad_chain_raw(dy, w_dgrad, taps, x.shape[1], lazy_in, want_dy)
+                    for ex in (dres_in, dres2_in):
+                        if ex is not None:
+                            dx = dx + ex
+                if lazy_in is not None:
+                    dy = dy_mat           # None when nothing below reads it
+            elif fused_bwd:
+                # small maps: the data-gradient conv's tile is a whole image, its epilogue IS the GroupNorm backward
+                dx, dgw, dgb, dft, dfa = conv_dgrad_gn_raw(dy, w_dgrad, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
+                                                           seed, salt, p_drop, act, taps, gslots, dres_in, dres2_in)
+            else:
+                if not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
+                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
+                    dres_in = None
+                else:
+                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
+                if act and gn_small_ok(x):
+                    dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
+                                                              seed, salt, p_drop, act, gslots, dres_in, dres2=dres2_in)
+                elif act:
+                    if dres2_in is not None:
+                        dres_in = dres_in + dres2_in
+                    dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, dres_in, gn_w, gn_b, film_t, film_a, mean, rstd,
+                                                             sc, sh, seed, salt, p_drop, act, gslots)
+                else:
+                    dx = dA
+                    for ex in (dres_in, dres2_in):
+                        if ex is not None:
+                            dx = dx + ex
+        elif need[0] and (dxp is not None or dxp2 is not None):
+            dx = dxp if dxp2 is None else (dxp2 if dxp is None else dxp + dxp2)
+        # (after the data gradient: with a lazy input the gradient tensor itself is that launch's side output)
         if need[1]:
             # deferring is safe only when AccumulateGrad merely adopts the slot views (no kernel reads them
             # before the end-of-backward launch)
@@ -665,43 +856,9 @@ class _FusedConv(torch.autograd.Function):
         elif want_b:
             B, Co, Ho, Wo = dy.shape
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
-        if need[0] or (act and (need[3] or need[5] or need[6])):
-            w_dgrad = cfg['shadows'](x.dtype, True)[1]
-            dres_in = _nhwc(dxp.to(x.dtype)) if dxp is not None else None
-            dres2_in = _nhwc(dxp2.to(x.dtype)) if dxp2 is not None else None
-            if dres_in is None:
-                dres_in, dres2_in = dres2_in, None
-            gacc = (ctx.slots[2], ctx.slots[3]) if (need[3] and need[4]) else None
-            fused_bwd = bool(act) and conv_dgrad_gn_ok(dy, x, mode, taps)
-            if fused_bwd:
-                dA = None
-            elif not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
-                dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
-                dres_in = None
-            else:
-                dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
-            if fused_bwd:
-                # small maps: the data-gradient conv's tile is a whole image, its epilogue IS the GroupNorm backward
-                dx, dgw, dgb, dft, dfa = conv_dgrad_gn_raw(dy, w_dgrad, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                           seed, salt, p_drop, act, taps, gacc, dres_in, dres2_in)
-            elif act and gn_small_ok(x):
-                dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                          seed, salt, p_drop, act, gacc, dres_in, dres2=dres2_in)
-            elif act:
-                if dres2_in is not None:
-                    dres_in = dres_in + dres2_in
-                dx, dgw, dgb, dft, dfa = gn_coef_bwd_raw(dA, x, dres_in, gn_w, gn_b, film_t, film_a, mean, rstd,
-                                                         sc, sh, seed, salt, p_drop, act, gacc)
-            else:
-                dx = dA
-                for ex in (dres_in, dres2_in):
-                    if ex is not None:
-                        dx = dx + ex
-        elif need[0] and (dxp is not None or dxp2 is not None):
-            dx = dxp if dxp2 is None else (dxp2 if dxp is None else dxp + dxp2)
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None, None, None, None
 
 
 def _tag(t, st):
@@ -712,7 +869,7 @@ def _tag(t, st):
 
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None,
-               passthrough=False, want_stats=False):
+               passthrough=False, want_stats=False, x_single_use=False):
     """passthrough = 1 / 2 returns (y, x') / (y, x', x''): the extra outputs alias x, and gradients sent to
     them (the residual / shortcut branch of a ResBlock, a skip connection) are added to dx inside this
     op's GroupNorm backward kernel (or its data-gradient epilogue).
@@ -721,6 +878,11 @@ def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=N
     if passthrough and os.environ.get('IDF_PASSTHROUGH', '1') == '0':
         return (fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed, want_stats=want_stats),) + (x,) * int(passthrough)
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
+    # x_single_use: the caller promises that this op is the ONLY reader of x.  When x came out of a conv whose data-gradient
+    # launch can form its own input gradient (lazy_in_ok), this op's GroupNorm backward may hand (du, partials) back
+    # instead of dx (LazyGrad) -- one streaming pass less per stage on the 64x64 / 32x32 maps
+    lazy_out = bool(x_single_use and train and cfg['act'] and not passthrough and
+                    getattr(x.grad_fn, 'lazy_in_ok', False))
     slots = None
     if torch.is_grad_enabled():
         slots = (slot_of(weight), slot_of(bias), slot_of(gn_w), slot_of(gn_b))
@@ -731,7 +893,7 @@ def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=N
         xst = stats_of(x)
         in_st = xst
     out = _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, int(passthrough),
-                           xst, want_stats)
+                           xst, want_stats, lazy_out)
     if not isinstance(out, tuple):
         return out
     y, rest = out[0], list(out[1:])
@@ -790,6 +952,8 @@ class _BlockEntryCat(torch.autograd.Function):
              B, H, W, C, sw.shape[0], None, _st())
         ctx.cfg, ctx.cfg_sc, ctx.slots = cfg, cfg_sc, slots or (None,) * 6
         ctx.has_st = st is not None
+        ctx.chain_ok = _BWD_CHAIN and C1 % 64 == 0 and chain_tiles(B, H, W, w.shape[0], C, 9) > 0     # see _FusedConv
+        ctx.lazy_in_ok = ctx.chain_ok and _BWD_LAZY
         ctx.save_for_backward(x1, x2, a, w, b, gn_w, gn_b, sw, sb, mean, rstd, sc, sh)
         if st is not None:
             ctx.mark_non_differentiable(st)
@@ -807,6 +971,9 @@ class _BlockEntryCat(torch.autograd.Function):
             dh = torch.zeros((B, w.shape[0], H, W), dtype=x1.dtype, device=x1.device).contiguous(memory_format=CL)
         if ds is None:
             ds = torch.zeros((B, sw.shape[0], H, W), dtype=x1.dtype, device=x1.device).contiguous(memory_format=CL)
+        lazy_in = _LAZY_PENDING.pop(dh.data_ptr(), None)       # the gradient of h as a (du, partials) pair: see _FusedConv
+        if lazy_in is not None and not ctx.chain_ok:
+            dh, lazy_in = lazy_in.materialize(), None
         dh, ds = _nhwc(dh.to(x1.dtype)), _nhwc(ds.to(x1.dtype))
         # shortcut: weight gradient over the two-source input, data gradient dense (joins in the GN backward)
         got = _defer_or_launch_wgrad(x1, ds, sws, sbs, 1, a2=x2)
@@ -815,13 +982,23 @@ class _BlockEntryCat(torch.autograd.Function):
             got = conv_wgrad_bias_raw(xc, ds, S1, 1, True)
         dsW, dsb = got
         dxs = conv_dgrad_raw(ds, cfg_sc['shadows'](x1.dtype, True)[1], S1, 1, (B, C, H, W))
+        w_dgrad = cfg['shadows'](x1.dtype, True)[1]
+        if ctx.chain_ok:
+            # the conv's epilogue emits du and the per-tile sums over the two-source input; dx1 / dx2 by a streaming pass
+            du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc, sh=sh,
+                                                    act=cfg['act'])
+            if lazy_in is not None:
+                dh = dh_mat
+            (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, (gws, gbs),
+                                                           dres=dxs, x2=x2)
+        else:
+            dA = conv_dgrad_raw(dh, w_dgrad, S1, 9, a.shape)
+            (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None,
+                                                           cfg['salt'], 0.0, cfg['act'], (gws, gbs), dres=dxs, x2=x2)
         got = _defer_or_launch_wgrad(a, dh, ws, bs, 9)
         if got is None:
             got = conv_wgrad_bias_raw(a, dh, S1, 9, True)
         dW, db = got
-        dA = conv_dgrad_raw(dh, cfg['shadows'](x1.dtype, True)[1], S1, 9, a.shape)
-        (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None,
-                                                       cfg['salt'], 0.0, cfg['act'], (gws, gbs), dres=dxs, x2=x2)
         return dx1, dx2, dW, db, dgw, dgb, dsW, dsb, None, None, None, None, None, None
 
 

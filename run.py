@@ -67,8 +67,9 @@ def parse_args(argv=None):
     p.add_argument('--is_bottleneck', action='store_true')
     # extras
     p.add_argument('--act_dtype', default='bf16', choices=['fp32', 'bf16'],
-                   help='activation / weight-shadow storage of the kernels: bf16 (MFMA bf16, ~9x faster; within 1e-2 of '
-                        'the reference) or fp32 (exact-f32 MFMA; within 1e-4 of the reference)')
+                   help='activation / weight-shadow storage of the kernels: bf16 (MFMA bf16, ~9x faster; loss within 1e-2 of '
+                        'the reference, epsilon-hat within 2e-2: DESIGN.md section 2) or fp32 (exact-f32 MFMA; within '
+                        '1e-4 of the reference)')
     p.add_argument('--steps_per_epoch', type=int, default=100)
     p.add_argument('--graph', type=int, default=1, help='replay the train step from a captured hipGraph')
     return p.parse_args(argv)
@@ -119,6 +120,8 @@ def _fit(args, model, batches, world, rank, latent=False):
     step = GraphedTrainStep(model, args, opt, sync, use_graph=bool(args.graph))
     for epoch in range(args.epochs):
         total, n = torch.zeros((), device=model.device), 0      # accumulated on the device: no per-step host sync
+        if hasattr(batches, 'set_epoch'):
+            batches.set_epoch(epoch)      # per-epoch permutation / flip masks follow the trainer's epoch counter
         for data in batches:
             x = data[0] if isinstance(data, (tuple, list)) else data
             total += step(x.to(device=model.device), epoch)     # loss_fn, backward, [all-reduce], clip + AdamW

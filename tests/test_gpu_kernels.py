@@ -225,6 +225,135 @@ def test_dgrad_conv_with_groupnorm_backward_epilogue(case):
     assert rel(got2[1], got[1]) < 1e-5 and rel(got2[2], got[2]) < 1e-5
 
 
+@pytest.mark.parametrize('case', [
+    # (B, Cin of dy, C1, C2 of x, H, W, taps, act, film, p_drop, n_res)
+    (33, 64, 64, 0, 64, 64, 9, 2, True, 0.1, 1),      # 256-pixel tiles, 16 per image
+    (16, 128, 128, 0, 32, 32, 9, 2, True, 0.1, 2), (2, 64, 64, 0, 64, 64, 9, 2, False, 0.0, 0),      # 64-pixel tiles
+    (33, 64, 128, 64, 64, 64, 9, 2, False, 0.0, 1),   # two-source GroupNorm input (192 = 128 | 64 channels)
+    (4, 128, 128, 128, 16, 16, 9, 2, False, 0.0, 1), (3, 384, 128, 0, 16, 16, 1, 1, False, 0.0, 1),   # small maps, 1x1 + affine
+    (5, 128, 64, 0, 32, 32, 9, 2, True, 0.1, 0),
+])
+def test_backward_chain_du_epilogue_and_streaming_apply(case):
+    """The big-map backward of conv(dropout(act(FiLM(GroupNorm(x))))): idf_conv_dgrad_chain_bf16 with the du epilogue
+    (du + per-tile partial sums) followed by idf_gn_bwd_apply (the reduction-free rest) against fp32 PyTorch autograd:
+    dx (+ branch gradients; two-source inputs: dx1 | dx2), dgamma, dbeta, dFiLM_t, dFiLM_a <= 4e-2."""
+    B, Cin, C1, C2, H, W, taps, act, film, p_drop, n_res = case
+    C, k = C1 + C2, 3 if taps == 9 else 1
+    x1 = (0.3 + rnd(1, B, C1, H, W)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    x2 = (rnd(11, B, C2, H, W) - 0.2).to(DEV).bfloat16().contiguous(memory_format=CL) if C2 else None
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL) if C2 else x1
+    dy = rnd(2, B, Cin, H, W).to(DEV).bfloat16().contiguous(memory_format=CL)
+    wgt = (rnd(3, Cin, C, k, k) / (C * taps) ** 0.5).to(DEV).bfloat16().float()
+    _, wd = ops.pack_weight(wgt, torch.bfloat16, True, True)
+    gam, bet = (1 + 0.1 * rnd(4, C)).to(DEV), (0.1 * rnd(5, C)).to(DEV)
+    ft = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(7, B, 2 * C)).to(DEV) if film else None
+    seed = torch.tensor([987654321], dtype=torch.int64, device=DEV) if p_drop else None
+    res = [rnd(8 + i, B, C, H, W).to(DEV).bfloat16().contiguous(memory_format=CL) for i in range(n_res)]
+    dres, dres2 = (res + [None, None])[:2]
+    mask = ops.dropout_mask(seed, 5, p_drop, xc.numel()).view(B, H, W, C).permute(0, 3, 1, 2) if p_drop else None
+    want = _gn_act_conv_reference(xc, gam, bet, ft, fa, act, mask, wgt, dy, res)
+    _, mean, rstd, sc, sh = ops.gn_fused_fwd_raw(x1, gam, bet, ft, fa, seed, 5, p_drop, act, x2=x2) if ops.gn_small_ok(x1, x2) \
+        else (None,) + ops.gn_coef_fwd_raw(xc, gam, bet, ft, fa)
+    T = ops.chain_tiles(B, H, W, Cin, C, taps)
+    assert T > 0
+    du, part, _ = ops.conv_dgrad_chain_raw(dy, wd, taps, C, x=x1, x2=x2, sc=sc, sh=sh, seed=seed, salt=5, p_drop=p_drop, act=act)
+    assert part.shape == (B, T, C, 2)
+    # the partial sums are those of the du the launch wrote
+    s1 = du.double().sum(dim=(2, 3))
+    s2 = (du.double() * xc.double()).sum(dim=(2, 3))
+    got = part.double().sum(dim=1)
+    assert float((got[..., 0] - s1).abs().max()) < 1e-4 * (1 + float(s1.abs().max()))
+    assert float((got[..., 1] - s2).abs().max()) < 1e-4 * (1 + float(s2.abs().max()))
+    out = ops.gn_bwd_apply_raw(du, part, x1, gam, bet, ft, fa, mean, rstd, sc, dres=dres, dres2=dres2, x2=x2)
+    dx = torch.cat(out[0], dim=1) if C2 else out[0]
+    for nm, g, r in zip(('dx', 'dgamma', 'dbeta', 'dfilm_t', 'dfilm_a'), (dx,) + tuple(out[1:]), want):
+        assert (g is None) == (r is None), nm
+        if g is not None:
+            parts = [(g, r)] if g.dim() != 2 else [(g[:, :C], r[:, :C]), (g[:, C:], r[:, C:])]
+            for gg, rr in parts:
+                assert rel(gg, rr) < 4e-2, (nm, rel(gg, rr))
+
+
+@pytest.mark.parametrize('case', [
+    # (B, C0, C1, C2, H, film, p_drop, plain_tail): x [C0] -GN1-conv1-> y1 [C1] -GN2-conv2-> y2 [C2]
+    (33, 64, 64, 64, 64, True, 0.1, False), (16, 128, 128, 128, 32, True, 0.1, False), (2, 64, 64, 128, 64, False, 0.0, False),
+    (5, 64, 128, 64, 32, True, 0.0, True), (3, 128, 128, 128, 16, False, 0.0, False),
+])
+def test_backward_chain_dy_prologue(case):
+    """Two stacked stages y2 = conv2(act(GN2(conv1(act(GN1(x)))))): the gradient of y1 never exists as a tensor of its own
+    -- conv2's data-gradient launch leaves (du2, partials), conv1's data-gradient launch forms dy1 = A*du2 + K1*y1 + K0 in
+    its prologue (idf_conv_dgrad_chain_bf16), writes it once for the weight gradient and stores GN2's parameter / FiLM
+    gradients.  Against fp32 PyTorch autograd: dy1, dx, both GroupNorms' dgamma / dbeta / dFiLM.  plain_tail: conv1 has no
+    GroupNorm in front (plain epilogue behind the prologue)."""
+    B, C0, C1, C2, H, film, p_drop, plain = case
+    W = H
+    x = (0.3 + rnd(1, B, C0, H, W)).bfloat16().float()
+    w1 = (rnd(2, C1, C0, 3, 3) / (9 * C0) ** 0.5).bfloat16().float()
+    w2 = (rnd(3, C2, C1, 3, 3) / (9 * C1) ** 0.5).bfloat16().float()
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(4, C0), 0.1 * rnd(5, C0), 1 + 0.1 * rnd(6, C1), 0.1 * rnd(7, C1)
+    ft2 = 0.2 * rnd(8, B, 2 * C1) if film else None
+    fa2 = 0.2 * rnd(9, B, 2 * C1) if film else None
+    dy2 = rnd(10, B, C2, H, W).bfloat16().float()
+    d = lambda t: None if t is None else t.to(DEV)
+    xd = x.to(DEV).bfloat16().contiguous(memory_format=CL)
+    seed = torch.tensor([424243], dtype=torch.int64, device=DEV) if p_drop else None
+    # ---- forward through the product kernels (the tensors the backward reads are the bf16 ones the forward stored)
+    wf1, wd1 = ops.pack_weight(d(w1), torch.bfloat16, True, True)
+    wf2, wd2 = ops.pack_weight(d(w2), torch.bfloat16, True, True)
+    if plain:
+        y1 = ops.conv_raw(xd, wf1, None, None, None, None, None, 0, 0.0, ops.S1, 9, 0, C1)
+        sc1 = sh1 = m1 = r1 = None
+    else:
+        y1, _, m1, r1, sc1, sh1, _ = ops.conv_gn_raw(xd, None, ops.gn_partials_raw(xd), None, d(g1), d(b1), None, None, None, 3,
+                                                     0.0, 2, wf1, None, None, C1, 9, keep_coef=True)
+    _, _, m2, r2, sc2, sh2, _ = ops.conv_gn_raw(y1, None, ops.gn_partials_raw(y1), None, d(g2), d(b2), d(ft2), d(fa2), seed, 7,
+                                                p_drop, 2, wf2, None, None, C2, 9, keep_coef=True)
+    # ---- reference: fp32 autograd over the same graph
+    mask2 = ops.dropout_mask(seed, 7, p_drop, y1.numel()).view(B, H, W, C1).permute(0, 3, 1, 2).cpu() if p_drop else None
+    xr = x.clone().requires_grad_(True)
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (g1, b1, g2, b2, ft2, fa2)]
+    g1r, b1r, g2r, b2r, ft2r, fa2r = leaves
+    u1 = xr if plain else F.silu(F.group_norm(xr, 32, g1r, b1r, eps=1e-5))
+    y1r = F.conv2d(u1, w1, None, padding=1)
+    y1r.retain_grad()
+    u2 = F.group_norm(y1r, 32, g2r, b2r, eps=1e-5)
+    if film:
+        u2 = u2 * (1 + ft2r[:, :C1, None, None]) + ft2r[:, C1:, None, None]
+        u2 = u2 * (1 + fa2r[:, :C1, None, None]) + fa2r[:, C1:, None, None]
+    u2 = F.silu(u2)
+    if mask2 is not None:
+        u2 = u2 * mask2
+    F.conv2d(u2, w2, None, padding=1).backward(dy2)
+    assert rel(y1, y1r) < 2e-2
+    # ---- the chain
+    dy2d = dy2.to(DEV).bfloat16().contiguous(memory_format=CL)
+    du2, part2, _ = ops.conv_dgrad_chain_raw(dy2d, wd2, 9, C1, x=y1, sc=sc2, sh=sh2, seed=seed, salt=7, p_drop=p_drop, act=2)
+    dft = torch.empty(B, 2 * C1, device=DEV) if film else None
+    dfa = torch.empty(B, 2 * C1, device=DEV) if film else None
+    acc = (torch.zeros(C1, device=DEV), torch.zeros(C1, device=DEV))
+    lazy = ops.LazyGrad(du=du2, part=part2, x=y1, gn_w=d(g2), gn_b=d(b2), film_t=d(ft2), film_a=d(fa2), mean=m2, rstd=r2,
+                        sc=sc2, dft=dft, dfa=dfa, acc=(acc[0].data_ptr(), acc[1].data_ptr()))
+    if plain:
+        dx, _, dy1 = ops.conv_dgrad_chain_raw(du2, wd1, 9, C0, lazy=lazy, want_dy=True)
+    else:
+        du1, part1, dy1 = ops.conv_dgrad_chain_raw(du2, wd1, 9, C0, lazy=lazy, want_dy=True, x=xd, sc=sc1, sh=sh1, act=2)
+        dx, dg1, db1, _, _ = ops.gn_bwd_apply_raw(du1, part1, xd, d(g1), d(b1), None, None, m1, r1, sc1)
+        assert rel(dg1, g1r.grad) < 4e-2 and rel(db1, b1r.grad) < 4e-2
+    assert rel(dy1, y1r.grad) < 4e-2, rel(dy1, y1r.grad)
+    assert rel(dx, xr.grad) < 4e-2, rel(dx, xr.grad)
+    assert rel(acc[0], g2r.grad) < 4e-2 and rel(acc[1], b2r.grad) < 4e-2
+    if film:
+        for got, want in ((dft, ft2r.grad), (dfa, fa2r.grad)):
+            assert rel(got[:, :C1], want[:, :C1]) < 4e-2 and rel(got[:, C1:], want[:, C1:]) < 4e-2
+    # the same gradient through the streaming pass (LazyGrad.materialize: what a consumer that cannot take the pair gets)
+    acc2 = (torch.zeros(C1, device=DEV), torch.zeros(C1, device=DEV))
+    du2b, part2b, _ = ops.conv_dgrad_chain_raw(dy2d, wd2, 9, C1, x=y1, sc=sc2, sh=sh2, seed=seed, salt=7, p_drop=p_drop, act=2)
+    lazy2 = ops.LazyGrad(du=du2b, part=part2b, x=y1, gn_w=d(g2), gn_b=d(b2), film_t=d(ft2), film_a=d(fa2), mean=m2, rstd=r2,
+                         sc=sc2, dft=dft, dfa=dfa, acc=(acc2[0].data_ptr(), acc2[1].data_ptr()))
+    assert rel(lazy2.materialize(), y1r.grad) < 4e-2
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,C,H', [(2, 128, 16), (3, 128, 8), (33, 64, 8), (2, 64, 4), (5, 64, 16), (33, 128, 16),
                                    (130, 128, 16), (129, 64, 16)])      # B >= 128: one workgroup walks all four row blocks

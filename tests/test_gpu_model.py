@@ -479,11 +479,23 @@ def _oracle_step(cfg, sd, fix, masks=None):
     return lo.detach(), grads, gn
 
 
-def _check_named_grads(named, ref, clip, tol, what):
+# Per-parameter gradient error of the bf16 step, measured on MI355X against the fp32 product path (which matches the reference
+# to 3e-5) over all 732 trained parameters (tools/bf16_grad_profile.py, profiles/r03_bf16_grad_profile.txt):
+#   B = 2 :  max-abs / max-abs  median 5.9e-2  p90 9.8e-2  p99 1.4e-1  max 2.9e-1     rel-L2  median 6.2e-2  max 2.0e-1
+#   B = 32:                     median 3.0e-2  p90 1.0e-1  p99 1.7e-1  max 2.7e-1     rel-L2  median 3.2e-2  max 2.7e-1
+# and the SAME distribution with every fused GroupNorm kernel switched off (IDF_BWD_CHAIN=0 IDF_DGRAD_GN=0 IDF_GN_FUSE=0:
+# median 6.8e-2 / 3.2e-2, max 2.5e-1 / 1.7e-1): a gradient that has crossed ~100 bf16-rounded tensors carries 3-6 % of noise
+# per parameter, whatever the kernels.  A per-parameter bound of 5e-2 therefore cannot hold in bf16; what a defect looks like
+# is different in kind -- a missing or mis-scaled gamma / beta / FiLM gradient is off by 0.5 ... 1.0 (a LazyGrad that held
+# tensor references instead of addresses read exactly 1.0 here).  The bounds below sit between the two populations.
+GRAD_TOL_MAX, GRAD_TOL_L2, GRAD_TOL_MEDIAN = 0.40, 0.35, 0.10
+
+
+def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD_TOL_L2, tol_median=GRAD_TOL_MEDIAN):
     """Every reference gradient against the product's (p.grad / clip: the fused optimizer writes the clipped gradients
-    back as clip_grad_norm_ does).  max-abs error relative to the reference's max-abs, per parameter; gradients that
-    are mathematically zero (a conv bias in front of a GroupNorm, proj_k.bias) are pure rounding noise: they must stay
-    small against the largest gradient of the step instead."""
+    back as clip_grad_norm_ does): per parameter, max-abs error relative to the reference's max-abs AND rel-L2; over all
+    parameters, the median of the former.  Gradients that are mathematically zero (a conv bias in front of a GroupNorm,
+    proj_k.bias) are pure rounding noise: they must stay small against the largest gradient of the step instead."""
     worst, n = [], 0
     top = max(float(g.abs().max()) for g in ref.values())
     for k, gr in ref.items():
@@ -493,11 +505,14 @@ def _check_named_grads(named, ref, clip, tol, what):
         if scale < 1e-4 * top:
             assert float(got.abs().max()) < 1e-3 * top, (what, k, float(got.abs().max()), top)
             continue
-        e = float((got - gr).abs().max()) / scale
-        worst.append((e, k))
+        worst.append((float((got - gr).abs().max()) / scale, float((got - gr).norm() / gr.norm()), k))
         n += 1
     worst.sort(reverse=True)
-    assert worst[0][0] < tol, (what, worst[:8])
+    assert worst[0][0] < tol_max, (what, worst[:8])
+    byl2 = sorted(worst, key=lambda t: -t[1])
+    assert byl2[0][1] < tol_l2, (what, byl2[:8])
+    med = sorted(w[0] for w in worst)[len(worst) // 2]
+    assert med < tol_median, (what, med)
     return n, worst[:3]
 
 
@@ -507,8 +522,8 @@ def test_bf16_train_step_celeba(a_dim):
     mmd 0.1, bf16 activations, GroupNorm-prologue convs, data-gradient convs with GroupNorm-backward epilogues, fused
     attention, batched weight gradients, gradient arena -- two eager steps, the capturing step and a replayed step through
     GraphedTrainStep, EACH against the reference: loss within 1e-2, global gradient norm within 2e-2, and every named
-    gradient within 5e-2 of its own scale (a_dim 32: the 22 gradients of the reference fixture `model_celeba`; a_dim 256:
-    every parameter, against the CPU oracle on the same draws).  epsilon-hat: BF16_EPS_TOL in max-norm AND rel-L2."""
+    gradient inside the bf16 noise band (GRAD_TOL_*: a_dim 32: the 22 gradients of the reference fixture `model_celeba`;
+    a_dim 256: every parameter, against the CPU oracle on the same draws).  epsilon-hat: BF16_EPS_TOL in max-norm AND rel-L2."""
     from infodiffusion_amd.optim import FusedClipAdamW
     from infodiffusion_amd.trainer import GraphedTrainStep
     cfg = O.dataset_cfg('celeba', a_dim=a_dim, mmd_weight=0.1)
@@ -541,7 +556,7 @@ def test_bf16_train_step_celeba(a_dim):
             gn = float(opt.total_norm())
             assert abs(gn - ref_gn) / ref_gn < 2e-2, (k, gn, ref_gn)
             clip = min(1.0, 1.0 / (gn + 1e-6))
-            _check_named_grads(named, ref_grads, clip, 5e-2, 'step %d (%s)' % (k, 'replay' if k == 3 else 'eager'))
+            _check_named_grads(named, ref_grads, clip, 'step %d (%s)' % (k, 'replay' if k == 3 else 'eager'))
     if a_dim == 32:
         with torch.no_grad():
             e17 = model(g['samp_x'].to(DEV), 17, g['samp_a'].to(DEV))
@@ -571,12 +586,19 @@ def _product_dropout_masks(model, seed, B):
     return masks
 
 
-@pytest.mark.parametrize('train', [False, True])
-def test_bf16_train_step_celeba_at_the_benchmarked_batch(train):
+_B32_REF = {}
+
+
+@pytest.mark.parametrize('train,lazy', [(False, False), (True, False), (True, True)])
+def test_bf16_train_step_celeba_at_the_benchmarked_batch(train, lazy, monkeypatch):
     """The benchmark's own launch shapes: CelebA 64x64, a_dim 32, bf16 at B = 32 (persistent / direct-to-LDS / 256-pixel
-    conv tiles, which B = 2 fixtures never reach), eval mode and train mode (dropout on, the product's masks replayed in
-    the oracle): loss, gradient norm and EVERY parameter's gradient against the CPU oracle on the same draws."""
+    conv tiles, the du-epilogue data-gradient convs + streaming GroupNorm backward of the big maps -- which B = 2 fixtures
+    never reach), eval mode and train mode (dropout on, the product's masks replayed in the oracle): loss, gradient norm
+    and EVERY parameter's gradient against the CPU oracle on the same draws.  lazy: with the (du, partials) hand-off into
+    the next data-gradient conv's prologue switched on (ops.LazyGrad; off by default, see ops._BWD_LAZY)."""
+    from infodiffusion_amd import ops
     from infodiffusion_amd.optim import FusedClipAdamW
+    monkeypatch.setattr(ops, '_BWD_LAZY', bool(lazy))
     cfg = O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1)
     model, args, sd = make_infodiff(cfg, DEV, 'bf16', 'manifest_celeba')
     model.train(train)
@@ -603,13 +625,17 @@ def test_bf16_train_step_celeba_at_the_benchmarked_batch(train):
         finally:
             if train:
                 torch.randint = orig
-    if train:
-        masks = _product_dropout_masks(model, seed, B)
-    ref_loss, ref_grads, ref_gn = _oracle_step(cfg, sd, fix, masks)
+    if lazy:
+        assert not ops._LAZY_PENDING                   # every pair found its data-gradient conv
+    if train not in _B32_REF:                          # (the masks depend on seed and salts only: one oracle pass per mode)
+        if train:
+            masks = _product_dropout_masks(model, seed, B)
+        _B32_REF[train] = _oracle_step(cfg, sd, fix, masks)
+    ref_loss, ref_grads, ref_gn = _B32_REF[train]
     assert rel(loss, ref_loss) < 1e-2, (float(loss), float(ref_loss))
     gn = float(opt.total_norm())
     assert abs(gn - ref_gn) / ref_gn < 2e-2, (gn, ref_gn)
-    n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)), 5e-2,
+    n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)),
                               'B=32 train=%s' % train)
     assert n > 500
 

@@ -1976,11 +1976,26 @@ extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const flo
 //   part_out [B][T][Cout][2] = per-tile (sum du, sum du*x), T = idf_conv_dgrad_chain_tiles(...): feed both to
 //   idf_gn_bwd_apply, or to the next call of this function as (dy, in_part).
 // bf16, Cin % 32 == 0, Cout % 64 == 0, W a power of two in [4, 128].
+namespace {
+// pixel tile of a chain launch: the forward kernels' plan, or a smaller tile when asked for (IDF_CHAIN_BM = 128 / 64: two or
+// three 256-thread blocks share a CU and one block's epilogue arithmetic overlaps its neighbours' MFMA phases)
+bool chain_plan(int B, int H, int W, int Cout, int taps, int* BM, int* R) {
+  if (!(taps == 9 ? plan3(B, H, W, Cout, 0, BM, R) : plan1(B, H, W, Cout, BM, R))) return false;
+  static const int force = getenv("IDF_CHAIN_BM") ? atoi(getenv("IDF_CHAIN_BM")) : 0;
+  if ((force == 128 || force == 64) && force < *BM && H * W >= force) {
+    int r = force / W;
+    if (r < 1) r = 1;
+    while (H % r) --r;
+    *BM = force; *R = r;
+  }
+  return true;
+}
+}  // namespace
+
 extern "C" int idf_conv_dgrad_chain_tiles(int B, int H, int W, int Cin, int Cout, int taps) {
   int BM, R;
   if ((taps != 9 && taps != 1) || (Cout % 64) || (Cin % CK)) return -1;
-  if (taps == 9) { if (!shape3_ok(H, W, Cin, Cout, 0) || !plan3(B, H, W, Cout, 0, &BM, &R)) return -1; }
-  else { if (!shape1_ok(W, Cin, Cout) || !plan1(B, H, W, Cout, &BM, &R)) return -1; }
+  if (!(taps == 9 ? shape3_ok(H, W, Cin, Cout, 0) : shape1_ok(W, Cin, Cout)) || !chain_plan(B, H, W, Cout, taps, &BM, &R)) return -1;
   return H / R;
 }
 
@@ -2010,6 +2025,13 @@ extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const
   int BM;
   if (int e = fill_common(p, B, H, W, Cin, Cout, 0, taps == 9 ? 3 : 1, &BM))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv_dgrad_chain_bf16: tile too large (H%d W%d)" : "conv_dgrad_chain_bf16: tensor too large for 32-bit offsets", H, W);
+  {
+    int R;
+    chain_plan(B, H, W, Cout, taps, &BM, &R);
+    const int halo = taps == 9 ? 2 : 0;
+    p.R = R; p.tiles_per_img = H / R; p.wh_magic = wh_magic(W + halo, (R + halo) * (W + halo));
+    if (!p.wh_magic) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_chain_bf16: tile not addressable (H%d W%d)", H, W);
+  }
   p.n_tiles = Cout / 64;
   if (in_x) {
     p.dyp_x = (const bf16_t*)in_x; p.dyp_out = (bf16_t*)dy_out;

@@ -556,7 +556,8 @@ def test_bf16_train_step_celeba(a_dim):
             gn = float(opt.total_norm())
             assert abs(gn - ref_gn) / ref_gn < 2e-2, (k, gn, ref_gn)
             clip = min(1.0, 1.0 / (gn + 1e-6))
-            _check_named_grads(named, ref_grads, clip, 'step %d (%s)' % (k, 'replay' if k == 3 else 'eager'))
+            if k != 2:      # (the capturing call clears the arena after its warm-up pass: that step's gradients are gone)
+                _check_named_grads(named, ref_grads, clip, 'step %d (%s)' % (k, 'replay' if k == 3 else 'eager'))
     if a_dim == 32:
         with torch.no_grad():
             e17 = model(g['samp_x'].to(DEV), 17, g['samp_a'].to(DEV))

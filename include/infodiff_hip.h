@@ -286,8 +286,15 @@ int idf_silu_bwd(const float* x, const float* dy, float* dx, long n, void* strea
 /* models.py:640-646: res[0] = mean((out-eps)^2); res[1] = mean((c0*(x-c1*out)-x)^2)/T */
 int idf_loss_fwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T, float* res,
                  float* workspace, long n, int dtype, void* stream);
+/* dout from the upstream gradients g[0] (denoise term) and g[g_stride] (recon term); g_stride 0: one scalar for both */
 int idf_loss_bwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T,
-                 const float* g, void* dout, long n, int dtype, void* stream);
+                 const float* g, int g_stride, void* dout, long n, int dtype, void* stream);
+/* models.py:640-646 + 674-678 (the --mmd_weight branch) as one objective: res[4] = {denoise, recon, mmd(prior, lat),
+ * (denoise + recon) + w_mmd * mmd}; prior [n,D], lat [m,D] fp32; workspace 2048 + 2n + m floats.  Backward: idf_loss_bwd
+ * with g_stride 0 and idf_mmd_bwd with gscale = w_mmd, both on the gradient of res[3]. */
+int idf_objective_fwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T,
+                      const float* prior, const float* lat, int n, int m, int D, float w_mmd, float* res,
+                      float* workspace, long numel, int dtype, void* stream);
 /* sampling.py:29-37 (mode 0 DDPM), 52-59 (1 DDIM as written, eta 0.01), 71-72 (2 reverse DDIM).
  * coef: [T][8] per-step scalars {c0,c1,c2,c3,d0,d1,sigma,-} built on the host with the reference's
  * fp32 expressions; *idx selects the row.  x/xo fp32 state, eps (and optional xo_t copy) in dtype. */
@@ -295,7 +302,8 @@ int idf_sampler_step(const float* x, const void* eps, const float* noise, float*
                      const long* idx, const float* coef, int mode, long n, int dtype, void* stream);
 /* utils.py:74-90 RBF-kernel MMD (bandwidth dim^2); workspace 2n+m floats */
 int idf_mmd_fwd(const float* x, const float* y, int n, int m, int D, float* out, float* workspace, void* stream);
-int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, const float* g, float* dy, void* stream);
+int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, const float* g, float gscale, float* dy,
+                void* stream);      /* dy = g[0] * gscale * d mmd / d y */
 /* out[N] = sum over R rows; workspace idf_colsum_blocks(R)*N floats */
 int idf_colsum_blocks(long R);
 int idf_colsum(const void* in, float* out, float* workspace, long R, int N, int in_dtype, void* stream);

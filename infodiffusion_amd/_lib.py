@@ -60,10 +60,11 @@ SIGNATURES = {
     'idf_silu_fwd': ([_p, _p, _l, _p], C.c_int),
     'idf_silu_bwd': ([_p, _p, _p, _l, _p], C.c_int),
     'idf_loss_fwd': ([_p, _p, _p, _f, _f, _f, _p, _p, _l, _i, _p], C.c_int),
-    'idf_loss_bwd': ([_p, _p, _p, _f, _f, _f, _p, _p, _l, _i, _p], C.c_int),
+    'idf_loss_bwd': ([_p, _p, _p, _f, _f, _f, _p, _i, _p, _l, _i, _p], C.c_int),
+    'idf_objective_fwd': ([_p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _f, _p, _p, _l, _i, _p], C.c_int),
     'idf_sampler_step': ([_p] * 7 + [_i, _l, _i, _p], C.c_int),
     'idf_mmd_fwd': ([_p, _p, _i, _i, _i, _p, _p, _p], C.c_int),
-    'idf_mmd_bwd': ([_p, _p, _i, _i, _i, _p, _p, _p], C.c_int),
+    'idf_mmd_bwd': ([_p, _p, _i, _i, _i, _p, _f, _p, _p], C.c_int),
     'idf_colsum_blocks': ([_l], C.c_int),
     'idf_colsum': ([_p, _p, _p, _l, _i, _i, _p], C.c_int),
     'idf_pool2_sum': ([_p, _p, _i, _i, _i, _i, _i, _p], C.c_int),

@@ -100,12 +100,12 @@ __global__ void loss_final_kernel(const float2* __restrict__ part, int nb, float
   float fa = wave_sum((float)a), fr = wave_sum((float)r);
   if (threadIdx.x == 0) { res[0] = fa * inv_n; res[1] = fr * inv_n * inv_T; }
 }
-// dout = g0 * 2(out-eps)/n + g1 * 2(x0-x)*(-c0*c1)/(n*T)
+// dout = g0 * 2(out-eps)/n + g1 * 2(x0-x)*(-c0*c1)/(n*T);  g0 = g[0], g1 = g[gs] (gs = 0: one upstream scalar for both terms)
 template <typename T>
 __global__ void loss_bwd_kernel(const T* __restrict__ out, const float* __restrict__ eps, const float* __restrict__ x,
-                                float c0, float c1, const float* __restrict__ g, float inv_n, float inv_T,
+                                float c0, float c1, const float* __restrict__ g, int gs, float inv_n, float inv_T,
                                 T* __restrict__ dout, long n) {
-  float g0 = g[0] * 2.f * inv_n, g1 = g[1] * 2.f * inv_n * inv_T * (-c0 * c1);
+  float g0 = g[0] * 2.f * inv_n, g1 = g[gs] * 2.f * inv_n * inv_T * (-c0 * c1);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float o = Elem<T>::ld(out + i);
     float x0 = c0 * (x[i] - c1 * o);
@@ -179,9 +179,28 @@ __global__ void mmd_final_kernel(const float* __restrict__ rows, int n, int m, f
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
   if (threadIdx.x == 0) out[0] = a / ((float)n * n) + b / ((float)m * m) - 2.f * c / ((float)n * m);
 }
+// The whole objective's tail in one block: the two loss terms from their partials (loss_final_kernel), the MMD from its
+// row sums (mmd_final_kernel), and total = denoise + recon + w_mmd * mmd (models.py:640-646, 674-678 as ONE scalar).
+// res = {denoise, recon, mmd, total}
+__global__ void objective_final_kernel(const float2* __restrict__ part, int nb, float inv_n, float inv_T,
+                                       const float* __restrict__ rows, int n, int m, float w_mmd, float* __restrict__ res) {
+  double a = 0.0, r = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) { a += part[i].x; r += part[i].y; }
+  const float fa = wave_sum((float)a), fr = wave_sum((float)r);
+  float ka = 0.f, kb = 0.f, kc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) { ka += rows[i]; kc += rows[n + m + i]; }
+  for (int i = threadIdx.x; i < m; i += 64) kb += rows[n + i];
+  ka = wave_sum(ka); kb = wave_sum(kb); kc = wave_sum(kc);
+  if (threadIdx.x == 0) {
+    const float d = fa * inv_n, rc = fr * inv_n * inv_T;
+    const float mmd = ka / ((float)n * n) + kb / ((float)m * m) - 2.f * kc / ((float)n * m);
+    res[0] = d; res[1] = rc; res[2] = mmd;
+    res[3] = (d + rc) + w_mmd * mmd;          // the reference's order: (denoise + recon) + alpha * mmd
+  }
+}
 // dy_j = g * [ (2/m^2) sum_i kyy_ij * (-2/D^2)(y_j - y_i) - (2/(nm)) sum_i kxy_ij * (-2/D^2)(y_j - x_i) ]
 __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                      int n, int m, int D, const float* __restrict__ g,
+                                                      int n, int m, int D, const float* __restrict__ g, float gscale,
                                                       float* __restrict__ dy) {
   extern __shared__ float acc[];   // [4][D]
   const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256)
-    dy[(size_t)j * D + d] = g[0] * (acc[d] + acc[D + d] + acc[2 * D + d] + acc[3 * D + d]);
+    dy[(size_t)j * D + d] = (g[0] * gscale) * (acc[d] + acc[D + d] + acc[2 * D + d] + acc[3 * D + d]);
 }
 
 // ---------------------------------------------------------------- colsum
@@ -406,13 +425,38 @@ extern "C" int idf_loss_fwd(const void* out, const float* eps, const float* x, f
   return IDF_OK;
 }
 extern "C" int idf_loss_bwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T,
-                            const float* g, void* dout, long n, int dtype, void* stream) {
+                            const float* g, int g_stride, void* dout, long n, int dtype, void* stream) {
+  if (g_stride != 0 && g_stride != 1) IDF_FAIL(IDF_ERR_BADARG, "loss_bwd: g_stride must be 0 or 1");
   if (dtype == IDF_F32)
     hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, ST, (const float*)out, eps, x, c0, c1,
-                       g, 1.0f / (float)n, inv_T, (float*)dout, n);
+                       g, g_stride, 1.0f / (float)n, inv_T, (float*)dout, n);
   else
     hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, ST, (const bf16_t*)out, eps, x, c0,
-                       c1, g, 1.0f / (float)n, inv_T, (bf16_t*)dout, n);
+                       c1, g, g_stride, 1.0f / (float)n, inv_T, (bf16_t*)dout, n);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// res[4] = {denoise, recon, mmd, denoise + recon + w_mmd * mmd}: idf_loss_fwd + idf_mmd_fwd + the weighted sum in three
+// launches (loss partials, MMD row sums, one tail block).  workspace: 2048 + 2n + m floats.
+extern "C" int idf_objective_fwd(const void* out, const float* eps, const float* x, float c0, float c1, float inv_T,
+                                 const float* prior, const float* lat, int n, int m, int D, float w_mmd, float* res,
+                                 float* workspace, long numel, int dtype, void* stream) {
+  if (n <= 0 || m <= 0) IDF_FAIL(IDF_ERR_BADARG, "objective: empty latent batch");
+  int nb = ew_blocks(numel, 1024);
+  if (nb > 1024) nb = 1024;
+  if (dtype == IDF_F32)
+    hipLaunchKernelGGL(loss_partial_kernel<float>, dim3(nb), dim3(256), 0, ST, (const float*)out, eps, x, c0, c1,
+                       (float2*)workspace, numel);
+  else
+    hipLaunchKernelGGL(loss_partial_kernel<bf16_t>, dim3(nb), dim3(256), 0, ST, (const bf16_t*)out, eps, x, c0, c1,
+                       (float2*)workspace, numel);
+  IDF_CHECK_LAUNCH();
+  float* rows = workspace + 2048;
+  hipLaunchKernelGGL(mmd_rows_kernel, dim3(2 * n + m), dim3(256), 0, ST, prior, lat, n, m, D, rows);
+  IDF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(objective_final_kernel, dim3(1), dim3(64), 0, ST, (const float2*)workspace, nb, 1.0f / (float)numel, inv_T,
+                     rows, n, m, w_mmd, res);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -441,9 +485,9 @@ extern "C" int idf_mmd_fwd(const float* x, const float* y, int n, int m, int D, 
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
-extern "C" int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, const float* g, float* dy,
+extern "C" int idf_mmd_bwd(const float* x, const float* y, int n, int m, int D, const float* g, float gscale, float* dy,
                            void* stream) {
-  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(m), dim3(256), 4 * D * sizeof(float), ST, x, y, n, m, D, g, dy);
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(m), dim3(256), 4 * D * sizeof(float), ST, x, y, n, m, D, g, gscale, dy);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

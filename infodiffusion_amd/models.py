@@ -355,6 +355,16 @@ class InfoDiff(nn.Module):
         if x.is_cuda and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)     # once: q_sample, the encoder and the loss all read NHWC
         output, epsilon, a, mu, log_var = self.forward(x, idx=idx, get_target=True)
+        if (self.mmd_weight != 0 and self.kld_weight == 0 and args.prior == 'regular' and output.is_cuda
+                and args.mmd_weight == self.mmd_weight):
+            # the benchmarked objective: both loss terms, the MMD against prior draws and the weighted sum as one op
+            # (ops._Objective: 3 launches forward, one backward node) -- same arithmetic as the general path below
+            loss, terms = ops.objective_mmd(output, epsilon, x, torch.randn_like(a, device=self.device), a, self._rec_c0,
+                                            self._rec_c1, 1.0 / args.diffusion_steps, args.mmd_weight)
+            if self.verbose:
+                print('denoising loss:', terms[0])
+                print('recon loss:', terms[1])
+            return loss
         terms = ops.diff_loss(output, epsilon, x, self._rec_c0, self._rec_c1, 1.0 / args.diffusion_steps)
         loss = terms[0] + terms[1]
         if self.verbose:

@@ -413,7 +413,7 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
 
 # ------------------------------------------------------------ backward chain at the big maps
 _BWD_CHAIN = os.environ.get('IDF_BWD_CHAIN', '1') != '0'     # du epilogue + streaming apply instead of the one-launch GroupNorm backward
-# ... and the apply pass folded into the NEXT data-gradient conv's prologue (LazyGrad).  Built, oracle-tested, measured, and
+# ... and the apply pass folded into the NEXT data-gradient conv's prologue (LazyGrad).  Built, tested against fp32 autograd, measured, and
 # OFF by default: the prologue (in-block coefficient fold + two tensors staged per vector + the side write of dy) costs the
 # conv +25 us at 64->64 @64^2, B = 32, against the 12 us streaming pass it removes -- 10.89 vs 10.43 ms per step on one box
 # (profiles/r03_c_ab_chain_lazy.txt, r03_d_step_inventory_chain_lazy.txt)
@@ -1261,7 +1261,7 @@ class _DiffLoss(torch.autograd.Function):
         out, eps, x = ctx.saved_tensors
         c0, c1, inv_T = ctx.k
         dout = torch.empty_like(out, memory_format=CL)
-        call('idf_loss_bwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(_f32c(g)), _p(dout), out.numel(),
+        call('idf_loss_bwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(_f32c(g)), 1, _p(dout), out.numel(),
              _dt(out), _st())
         return dout, None, None, None, None, None
 
@@ -1290,12 +1290,55 @@ class _MMD(torch.autograd.Function):
         n, D = x.shape
         m = y.shape[0]
         dy = torch.empty_like(y)
-        call('idf_mmd_bwd', _p(x), _p(y), n, m, D, _p(_f32c(g).reshape(1)), _p(dy), _st())
+        call('idf_mmd_bwd', _p(x), _p(y), n, m, D, _p(_f32c(g).reshape(1)), 1.0, _p(dy), _st())
         return None, dy
 
 
 def mmd(x, y):
     return _MMD.apply(x, y)
+
+
+class _Objective(torch.autograd.Function):
+    """InfoDiff's --mmd_weight objective as ONE scalar (models.py:640-646, 674-678):
+        total = (mean((out-eps)^2) + mean((x0-x)^2)/T) + w * MMD(prior, lat)
+    -- loss partials, MMD row sums and one tail block forward (3 launches instead of the 7 of diff_loss + the scalar adds +
+    compute_mmd + the weighted add); backward one node: d out (idf_loss_bwd) and d lat (idf_mmd_bwd) from the upstream scalar.
+    Outputs: total, terms [3] = (denoise, recon, mmd) (not differentiable: for --verbose_loss)."""
+
+    @staticmethod
+    def forward(ctx, out, eps, x, prior, lat, c0, c1, inv_T, w):
+        out, eps, x = _nhwc(out), _nhwc(eps), _nhwc(x)
+        prior, lat = _f32c(prior), _f32c(lat)
+        n, D = prior.shape
+        m = lat.shape[0]
+        res = torch.empty((4,), dtype=torch.float32, device=out.device)
+        ws = torch.empty((2048 + 2 * n + m,), dtype=torch.float32, device=out.device)
+        call('idf_objective_fwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(prior), _p(lat), n, m, D, w, _p(res), _p(ws),
+             out.numel(), _dt(out), _st())
+        ctx.k = (c0, c1, inv_T, w)
+        ctx.save_for_backward(out, eps, x, prior, lat)
+        terms = res[:3]
+        ctx.mark_non_differentiable(terms)
+        return res[3], terms
+
+    @staticmethod
+    def backward(ctx, g, _):
+        out, eps, x, prior, lat = ctx.saved_tensors
+        c0, c1, inv_T, w = ctx.k
+        g = _f32c(g).reshape(1)
+        dout = dlat = None
+        if ctx.needs_input_grad[0]:
+            dout = torch.empty_like(out, memory_format=CL)
+            call('idf_loss_bwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(g), 0, _p(dout), out.numel(), _dt(out), _st())
+        if ctx.needs_input_grad[4]:
+            n, D = prior.shape
+            dlat = torch.empty_like(lat)
+            call('idf_mmd_bwd', _p(prior), _p(lat), n, lat.shape[0], D, _p(g), w, _p(dlat), _st())
+        return dout, None, None, None, dlat, None, None, None, None
+
+
+def objective_mmd(out, eps, x, prior, lat, c0, c1, inv_T, w):
+    return _Objective.apply(out, eps, x, prior, lat, float(c0), float(c1), float(inv_T), float(w))
 
 
 # ------------------------------------------------------------------- sampler

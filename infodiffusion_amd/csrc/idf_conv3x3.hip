@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
 #ifndef IDF_HALO_PRO_G
 #define IDF_HALO_PRO_G 8
 #endif
+
 template <int G = 8>
 __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8], const float (&shv)[8], int act, bool drop,
                                          uint64_t seedv, uint32_t salt, uint32_t thr, float dscale, uint32_t vec) {
@@ -799,6 +800,34 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 __device__ uint4 g_zero16;      // zero page: out-of-image halo pixels and padding rows load from here
 __device__ uint4 g_trash[16];   // where the persistent kernel's epilogue sends the stores of out-of-range elements (branch-free)
 
+// Diagnostic build only (tools/build_variant.sh NAME idf_conv3x3.hip -DIDF_DLDS_STAMP; never in the shipped library): per-phase
+// cycle sums of conv_dlds_bf16 -- wave 0 of every block stamps s_memtime at the phase boundaries and adds the differences
+// here: [0] prologue (plan + coefficients), [1] load wait, [2] GroupNorm transform, [3] MFMA, [4] epilogue, [5] blocks.
+#ifdef IDF_DLDS_STAMP
+__device__ unsigned long long g_dlds_stamps[64 * 8];     // 64 shards (block id mod 64): no same-address atomic pile-up
+__device__ __forceinline__ unsigned long long dlds_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define DLDS_STAMP(var) const unsigned long long var = dlds_now()
+#define DLDS_DECL unsigned long long dlds_sum[6] = {0, 0, 0, 0, 0, 1}
+#define DLDS_ADD(i, a, b) dlds_sum[i] += (b) - (a)
+#define DLDS_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_dlds_stamps[(blockIdx.x & 63) * 8 + i_], dlds_sum[i_]); } while (0)
+extern "C" int idf_debug_dlds_stamps(unsigned long long* out8, int reset) {
+  static unsigned long long h[64 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dlds_stamps), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; ++i) { out8[i] = 0; for (int s = 0; s < 64; ++s) out8[i] += h[s * 8 + i]; }
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_dlds_stamps), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#else
+#define DLDS_STAMP(var)
+#define DLDS_DECL
+#define DLDS_ADD(i, a, b)
+#define DLDS_FLUSH
+#endif
+
 // PRO: the GroupNorm prologue as an in-LDS pass -- once the chunk has landed every thread reads its own vectors
 // back, applies act(x * sc + sh) and writes them in place (one more barrier per chunk); with two blocks per CU the
 // other block's MFMA phase runs beside this VALU phase.
@@ -823,6 +852,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
   const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
   const int fr = lane & 15, fq = lane >> 4;
+  DLDS_DECL;
+  DLDS_STAMP(t_begin);
 
   int hbase[TM];
 #pragma unroll
@@ -878,9 +909,12 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
     pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   }
   const bool keep_a = PRO && p.a_out && n0 == 0;
+  DLDS_STAMP(t_pro);
+  DLDS_ADD(0, t_begin, t_pro);
 
   const int nchunks = p.Cin / CK;
   for (int ck = 0; ck < nchunks; ++ck) {
+    DLDS_STAMP(t0);
     const int c0 = ck * CK;
     const bf16_t* dbase = p.x;      // DUAL: the tensor this chunk lies in, advanced to the chunk's first channel
     int dpitch = p.Cin;
@@ -913,6 +947,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
     }
     __builtin_amdgcn_s_waitcnt(0);                   // the direct loads are counted by vmcnt
     __syncthreads();
+    DLDS_STAMP(t1);
+    DLDS_ADD(1, t0, t1);
     if (PRO) {
       const int cb = c0 + (tid & 3) * 8;
       float scv[8], shv[8];
@@ -941,6 +977,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
       }
       __syncthreads();
     }
+    DLDS_STAMP(t2);
+    DLDS_ADD(2, t1, t2);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = (tap / KS) * WH + (tap % KS);
@@ -959,10 +997,16 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
           acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
     }
     __syncthreads();
+    DLDS_STAMP(t3);
+    DLDS_ADD(3, t2, t3);
   }
 
   // epilogue through LDS (Cout % 8 == 0 is a launch condition)
+  DLDS_STAMP(t4);
   lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+  DLDS_STAMP(t5);
+  DLDS_ADD(4, t4, t5);
+  DLDS_FLUSH;
 }
 
 // ---------------------------------------------------------------- persistent, wave-specialised form

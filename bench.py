@@ -57,7 +57,10 @@ def make_args(a):
                            is_latent=False, act_dtype=a.dtype, dataset='celeba')
 
 
-CPU_THREADS = 32      # the oracle's convs stop scaling (and oversubscribe badly) far below the box's 256 cores
+# the oracle's convs stop scaling (and oversubscribe) far below the box's 256 cores: measured on the MI355X host at B = 32,
+# s per train step -- 32 threads 4.6, 64 threads 4.4, 128 threads 5.9 (profiles/r03_cpu_baseline_threads.txt); IDF_CPU_THREADS
+# overrides for such a sweep
+CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '32'))
 CPU_BATCH = 32        # the benchmarked batch, 1 warm-up + 3 timed steps; then 3 backbone evaluations
 
 
@@ -140,9 +143,9 @@ def cpu_baseline(margs, budget_s=240):
     t = sum(timed) / len(timed)
     res = {'value': round(CPU_BATCH / t, 3), 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
            'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
-                     '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores): %d timed '
-                     'step(s) after 1 warm-up, %.2f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0,
-                                                                len(timed), t)}
+                     '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores; ATen convs do not scale '
+                     'past a few dozen threads: profiles/r03_cpu_baseline_threads.txt): %d timed step(s) after 1 warm-up, '
+                     '%.2f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0, len(timed), t)}
     if len(evals) > 1:
         te = sum(evals[1:]) / len(evals[1:])
         res['sampling'] = {'value': round(CPU_BATCH / (100 * te), 4), 'unit': 'images/s',
@@ -151,11 +154,11 @@ def cpu_baseline(margs, budget_s=240):
     return res
 
 
-def pmc_traffic_r02(names):
+def pmc_traffic_file(names):
     """Average HBM bytes per launch over the kernels whose name contains one of `names`, from the committed rocprofv3
-    PMC passes of this round (profiles/r02_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    PMC passes of this round (profiles/r03_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
             d = json.load(f)
         ks = [v for k, v in d.items() if any(n in k for n in names)]
         n = sum(v['launches'] for v in ks)
@@ -207,6 +210,31 @@ class LaunchRecorder:
             bufs = [(0, px * Cin * 2), (2, px * Cout * 2), (5, px * Cout * 2)]
             bufs += [(i, px * Cout * 2) for i in (3, 4) if a[i]]
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_dgrad_chain_bf16':    # big maps: data-gradient conv with the du epilogue (and / or the dy prologue)
+            B, H, W, Cin, Cout, taps = a[31:37]
+            if taps != 9:
+                return None
+            px = B * H * W
+            bufs = [(0, px * Cin * 2), (29, px * Cout * 2)]
+            if a[1]:
+                bufs.append((1, px * Cin * 2))
+            if a[18]:
+                bufs.append((18, px * Cin * 2))
+            if a[20]:
+                C1 = a[22] if a[21] else Cout
+                bufs.append((20, px * C1 * 2))
+                if a[21]:
+                    bufs.append((21, px * (Cout - C1) * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_gn_bwd_apply':
+            C1 = a[5]
+            B, HW, C = a[24:27]
+            c1 = C1 if a[4] else C
+            bufs = [(0, B * HW * C * 2), (3, B * HW * c1 * 2), (8, B * HW * c1 * 2)]
+            if a[4]:
+                bufs += [(4, B * HW * (C - c1) * 2), (9, B * HW * (C - c1) * 2)]
+            bufs += [(i, B * HW * C * 2) for i in (6, 7) if a[i]]
+            return 'gn_bwd', bufs, float(sum(n for _, n in bufs))
         if name == 'idf_gn_fused_bwd':
             C1 = a[3]
             B, HW, C, dt = a[27:31]
@@ -273,6 +301,16 @@ class LaunchRecorder:
                     t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
                     keep.append(t)
                     al[18], al[19], al[20] = t.data_ptr(), None, None
+                if name == 'idf_gn_bwd_apply':       # not into the live gradient arena: per-sample sums to scratch
+                    B_, C_ = al[24], al[26]
+                    t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
+                    keep.append(t)
+                    al[21], al[22], al[23] = t.data_ptr(), None, None
+                if name == 'idf_conv_dgrad_chain_bf16' and al[1]:
+                    B_, C_ = al[31], al[34]
+                    t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
+                    keep.append(t)
+                    al[15], al[16], al[17] = t.data_ptr(), None, None
                 al[-1] = None
                 sets.append((al, keep))
             reps = max(1, -(-reps_min // K))
@@ -464,10 +502,11 @@ def main():
             n, ms, fl, by = fam['conv3x3']
             ach = fl / (ms * 1e-3) / 1e12
             out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16: forward incl. '
-                                         'GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the GroupNorm backward)',
+                                         'GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
+                                         'GroupNorm backward (small maps) or its du / partial-sum half (big maps))',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
-                               'traffic': pmc_traffic_r02(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16']),
+                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16']),
                                'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                'timing': 'cold: each replayed launch on its own buffer set, sets > 256 MB together',
                                'algorithmic_gflop_per_step': round(fl / 1e9, 1),
@@ -476,19 +515,20 @@ def main():
         if 'gn_bwd' in fam:
             n, ms, _, by = fam['gn_bwd']
             gbs = by / (ms * 1e-3) / 1e9
-            out['roofline_hbm'] = {'kernel': 'gn_small_bwd (GroupNorm + FiLM + SiLU + dropout backward, the ResBlock '
-                                             'elementwise pass that remains stand-alone)', 'bound': 'hbm',
+            out['roofline_hbm'] = {'kernel': 'gn_bwd_apply (the streaming half of the GroupNorm + FiLM + SiLU + dropout backward: '
+                                             'the ResBlock elementwise pass that remains a kernel of its own; + the two tail '
+                                             'GroupNorms still in gn_small_bwd)', 'bound': 'hbm',
                                    'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                                   'traffic': pmc_traffic_r02(['gn_small_bwd']), 'launches_per_step': n,
+                                   'traffic': pmc_traffic_file(['gn_bwd_apply', 'gn_small_bwd']), 'launches_per_step': n,
                                    'avg_launch_us': round(ms * 1e3 / n, 2),
                                    'algorithmic_bytes_per_launch': round(by / n),
-                                   'note': 'bytes = dA + x (+ branch gradients) read, dx written, once each'}
+                                   'note': 'bytes = du + x (+ branch gradients) read, dx written, once each'}
         if 'attn' in fam:
             n, ms, fl, by = fam['attn']
             ach = fl / (ms * 1e-3) / 1e12
             out['roofline_attn'] = {'kernel': 'attn_fwd_kernel (N = 256 tokens at 16x16, N = 64 at the 8x8 middle block; d = 128: QK^T, softmax, PV in one launch)',
                                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic_r02(['attn_fwd_kernel']),
+                                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic_file(['attn_fwd_kernel']),
                                     'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                     'note': '4 N^2 d FLOP per image; launch-bound at B = 32 (32 x 4 workgroups)'}
     if world > 1:

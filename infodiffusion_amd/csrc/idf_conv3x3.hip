@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
 #ifndef IDF_HALO_PRO_G
 #define IDF_HALO_PRO_G 8
 #endif
+#ifndef IDF_SMALL_PFD
+#define IDF_SMALL_PFD 1        // chunks in flight in the 64-pixel-tile launches: 2 was built and measured -- 128->128 @8x8 8.5 -> 8.9 us,
+                               // DDIM-100 at B = 256 297 -> 287 img/s (registers: 143 -> 214): the per-chunk 1.2 us is not load latency
+#endif
 
 template <int G = 8>
 __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8], const float (&shv)[8], int act, bool drop,
@@ -606,7 +610,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  uint4 hreg[HV], wreg[WV];
+  // staging registers of one chunk in flight (PFD = 2: two, for the small-tile launches -- see IDF_SMALL_PFD)
+  struct Stage { uint4 h[HV]; uint4 w[WV]; };
+  constexpr int PFD = (MODE == 0 && !DYP && TM == 2 && NWM == 2 && BN == 64) ? IDF_SMALL_PFD : 1;
+  Stage st0, st1;
   uint4 xreg[DYP ? HV : 1];    // DYP: the GroupNorm input xg beside du
   const int nchunks = p.Cin / CK;
 
@@ -646,7 +653,9 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     }
   }
 
-  auto load_chunk = [&](int ck) {
+  auto load_chunk = [&](int ck, Stage& S) {
+    uint4 (&hreg)[HV] = S.h;
+    uint4 (&wreg)[WV] = S.w;
     const int c0 = ck * CK;
     if (DUAL) {
       const bool first = c0 < p.C1;
@@ -673,7 +682,9 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   uint64_t seedv = 0;
   bool drop = false;
   if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
-  auto store_chunk = [&](int ck) {
+  auto store_chunk = [&](int ck, Stage& S) {
+    uint4 (&hreg)[HV] = S.h;
+    uint4 (&wreg)[WV] = S.w;
     if constexpr (DYP) {
       const int cb = ck * CK + (tid & 3) * 8;         // this thread's 8 channels of the chunk (idx & 3 == tid & 3)
       float av[8], k1v[8], k0v[8];
@@ -722,15 +733,16 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
       if (wlds[k] >= 0) *reinterpret_cast<uint4*>(Ws + wlds[k]) = wreg[k];
   };
 
-  load_chunk(0);
+  load_chunk(0, st0);
+  if (PFD == 2 && nchunks > 1) load_chunk(1, st1);
   GnbPre<GNB ? BM * (BN / 8) / NT : 1> gpre;
   if constexpr (GNB) gnb_prefetch<BM, BN, NT>(p, b, n0, KT, tid, gpre);
   if (PRO) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   if constexpr (DYP) gn_bwd_fold<NT>(p.dyp_f, b, oy0 == 0 && n0 == 0, cof, cof + 4 * p.Cin, tid);
-  for (int ck = 0; ck < nchunks; ++ck) {
-    store_chunk(ck);
+  auto step = [&](int ck, Stage& S) {
+    store_chunk(ck, S);
     __syncthreads();
-    if (ck + 1 < nchunks) load_chunk(ck + 1);
+    if (ck + PFD < nchunks) load_chunk(ck + PFD, S);     // the stage's registers are free again: next chunk of this slot
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = (tap / KS) * WH + (tap % KS);
@@ -749,6 +761,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
           acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
     }
     __syncthreads();
+  };
+  for (int ck = 0; ck < nchunks; ck += PFD) {
+    step(ck, st0);
+    if (PFD == 2 && ck + 1 < nchunks) step(ck + 1, st1);
   }
   if constexpr (DUE) {
     due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);

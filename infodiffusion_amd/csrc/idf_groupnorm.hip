@@ -661,15 +661,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_loop(const bf16_t* __restric
   extern __shared__ __attribute__((aligned(16))) float sm[];   // cof [C][4] | pc [C][2]
   const int C = f.C, HW = f.HW, tid = threadIdx.x, b = blockIdx.y;
   float* cof = sm;
-  gn_bwd_fold<256>(f, b, blockIdx.x == 0, cof, sm + 4 * C, tid);
   const int vpp = C / 8, lanes = 256 / vpp, v = tid % vpp, pl = tid / vpp;
-  if (pl >= lanes) return;
-  float av[8], k1v[8], k0v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float4 t4 = *reinterpret_cast<const float4*>(cof + 4 * (v * 8 + e));
-    av[e] = t4.x; k1v[e] = t4.y; k0v[e] = t4.z;
-  }
+  const bool live = pl < lanes;
   const bf16_t* src = x;
   bf16_t* dst = dx;
   int spitch = C, sc0 = v * 8;
@@ -678,24 +671,49 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_loop(const bf16_t* __restric
     else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
   }
   const int pend = min(HW, (int)(blockIdx.x + 1) * chunk);
-  for (int p = blockIdx.x * chunk + pl; p < pend; p += lanes) {
+  // the first pixel's operands are on their way before the fold starts (they do not depend on it): the stream's first
+  // round trip runs beside the fold's instead of behind it
+  int p = blockIdx.x * chunk + pl;
+  uint4 xr = make_uint4(0, 0, 0, 0), dr = xr, rr = xr, r2 = xr;
+  if (live && p < pend) {
     const size_t e0 = ((size_t)b * HW + p) * C + v * 8, es = ((size_t)b * HW + p) * spitch + sc0;
-    float xv[8], dv[8], o[8];
-    Vec16<bf16_t>::load(src + es, xv);
-    Vec16<bf16_t>::load(du + e0, dv);
+    xr = *reinterpret_cast<const uint4*>(src + es);
+    dr = *reinterpret_cast<const uint4*>(du + e0);
+    if (dres) rr = *reinterpret_cast<const uint4*>(dres + e0);
+    if (dres2) r2 = *reinterpret_cast<const uint4*>(dres2 + e0);
+  }
+  gn_bwd_fold<256>(f, b, blockIdx.x == 0, cof, sm + 4 * C, tid);
+  if (!live) return;
+  float av[8], k1v[8], k0v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float4 t4 = *reinterpret_cast<const float4*>(cof + 4 * (v * 8 + e));
+    av[e] = t4.x; k1v[e] = t4.y; k0v[e] = t4.z;
+  }
+  for (; p < pend; p += lanes) {
+    const size_t es = ((size_t)b * HW + p) * spitch + sc0;
+    float xv[8], dv[8], o[8], rv[8];
+    unpack16<bf16_t>(xr, xv);
+    unpack16<bf16_t>(dr, dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = av[e] * dv[e] + k1v[e] * xv[e] + k0v[e];
     if (dres) {
-      float rv[8];
-      Vec16<bf16_t>::load(dres + e0, rv);
+      unpack16<bf16_t>(rr, rv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rv[e];
     }
     if (dres2) {
-      float rv[8];
-      Vec16<bf16_t>::load(dres2 + e0, rv);
+      unpack16<bf16_t>(r2, rv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rv[e];
+    }
+    const int pn = p + lanes;                 // next pixel's operands before this pixel's store
+    if (pn < pend) {
+      const size_t e0 = ((size_t)b * HW + pn) * C + v * 8, en = ((size_t)b * HW + pn) * spitch + sc0;
+      xr = *reinterpret_cast<const uint4*>(src + en);
+      dr = *reinterpret_cast<const uint4*>(du + e0);
+      if (dres) rr = *reinterpret_cast<const uint4*>(dres + e0);
+      if (dres2) r2 = *reinterpret_cast<const uint4*>(dres2 + e0);
     }
     Vec16<bf16_t>::store(dst + es, o);
   }

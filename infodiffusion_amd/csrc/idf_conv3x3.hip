@@ -120,15 +120,8 @@ __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool write
     const float* st = p.st1;
     int T = p.T1, Cs = p.C1, cl = c;
     if (c >= p.C1) { st = p.st2; T = p.T2; Cs = C - p.C1; cl = c - p.C1; }
-    const float2* src = reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    int t = 0;
-    for (; t + 2 <= T; t += 2) {
-      float2 v0 = src[(size_t)t * Cs], v1 = src[(size_t)(t + 1) * Cs];
-      s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
-    }
-    if (t < T) { float2 v = src[(size_t)t * Cs]; s0 += v.x; q0 += v.y; }
-    chs[2 * c] = s0 + s1; chs[2 * c + 1] = q0 + q1;
+    const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl, T, (size_t)Cs);
+    chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
   }
   __syncthreads();
   const double n = (double)p.H * p.W * cpg;
@@ -1110,15 +1103,8 @@ __device__ __forceinline__ void ps_coefficients(const C3P& p, int b, bool writer
     const float* st = p.st1;
     int T = p.T1, Cs = p.C1, cl = c;
     if (c >= p.C1) { st = p.st2; T = p.T2; Cs = C - p.C1; cl = c - p.C1; }
-    const float2* src = reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    int t = 0;
-    for (; t + 2 <= T; t += 2) {
-      float2 v0 = src[(size_t)t * Cs], v1 = src[(size_t)(t + 1) * Cs];
-      s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
-    }
-    if (t < T) { float2 v = src[(size_t)t * Cs]; s0 += v.x; q0 += v.y; }
-    chs[2 * c] = s0 + s1; chs[2 * c + 1] = q0 + q1;
+    const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl, T, (size_t)Cs);
+    chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its own LDS writes are visible to its lanes
   const double n = (double)p.H * p.W * cpg;

@@ -13,6 +13,22 @@
 #pragma once
 #include "idf_common.h"
 
+// Sum of T per-tile partials (float2, `stride` float2s apart), all loads of a batch of 16 in flight before the first add.
+// (A plain `for t` loop makes hipcc wait for each pair of loads before it issues the next: T / 2 dependent L2 round trips
+// -- 4 us in front of every block at T = 16, the 64x64 maps.)  Two interleaved chains, even / odd t, in a fixed order:
+// every block that folds the same partials gets the same bits.
+__device__ __forceinline__ float2 idf_sum_partials(const float2* __restrict__ src, int T, size_t stride) {
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 16) {
+    float2 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (t0 + j < T) ? src[(size_t)(t0 + j) * stride] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) { s0 += v[j].x; q0 += v[j].y; s1 += v[j + 1].x; q1 += v[j + 1].y; }
+  }
+  return make_float2(s0 + s1, q0 + q1);
+}
+
 struct GnFoldP {
   const float* part; int T;              // [B][T][C][2]
   const float* mean; const float* rstd;  // [B][32]
@@ -31,15 +47,8 @@ template <int NT>
 __device__ __forceinline__ void gn_bwd_fold(const GnFoldP& f, int b, bool writer, float* cof, float* pc, int tid) {
   const int C = f.C, cpg = C >> 5;
   for (int c = tid; c < C; c += NT) {
-    const float2* src = reinterpret_cast<const float2*>(f.part) + (size_t)b * f.T * C + c;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    int t = 0;
-    for (; t + 2 <= f.T; t += 2) {
-      const float2 v0 = src[(size_t)t * C], v1 = src[(size_t)(t + 1) * C];
-      s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
-    }
-    if (t < f.T) { const float2 v = src[(size_t)t * C]; s0 += v.x; q0 += v.y; }
-    const float S1 = s0 + s1, S2 = q0 + q1;
+    const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(f.part) + (size_t)b * f.T * C + c, f.T, (size_t)C);
+    const float S1 = S.x, S2 = S.y;
     const int g = c / cpg;
     const float mu = f.mean[b * 32 + g], r = f.rstd[b * 32 + g];
     const float ga = f.gamma ? f.gamma[c] : 1.f, be = f.beta ? f.beta[c] : 0.f;

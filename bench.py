@@ -576,11 +576,19 @@ def main():
                                  'note': 'fp32 activations / weights (1e-4 parity path), B=%d, graph replay' % a.batch}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(margs)
-    if rank == 0:
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the LAST line of stdout: RCCL printf()s its version banner into the C library's stdout buffer, which would
+        # otherwise be flushed at exit, after this line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -35,6 +35,8 @@ struct WgP {
   int tiles_per_blk;
   int c_tiles, n_tiles;
   int Cw, Nw;         // dW is [Nw][taps][Cw] (Cw <= Cin, Nw <= Cout): channels the operands were zero-padded by get no gradient
+  int wshift;         // log2(W) (W is a power of two)
+  unsigned wh_magic;  // (pix * wh_magic) >> 16 == pix / WH over the staged tile's pixels (checked on the host)
 };
 
 #ifndef IDF_WGRAD_BLOCKS
@@ -57,20 +59,28 @@ __device__ __forceinline__ bf16x8_t mkfrag(s16x4_t lo, s16x4_t hi) {
 // KW = taps per block along x (3 for a 3x3 kernel row, 1 for 1x1).
 // MODE 0: stride 1; 1: stride 2 (DownSample); 2: nearest-x2-upsampled input (UpSample):
 // only the staging differs -- the LDS tile always holds the pixels the taps address.
-template <int KW, int MODE>
+// ROWS = 1: the block owns ONE kernel row (256 threads; the three rows of a (pixel range, cout tile, cin tile) are three
+//   blocks, each staging its own a / dy tiles: every operand byte crosses the fabric three times).
+// ROWS = 3 (KW 3, MODE 0): the three kernel rows are three 4-wave groups of ONE 768-thread block that share one staged
+//   (R + 2)-row input tile and one dy tile -- a is fetched (R + 2) / R times instead of three, dy once; each group keeps
+//   its own kernel row's accumulators (48 registers per thread, as before).
+template <int KW, int MODE, int ROWS = 1>
 __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) {
+  static_assert(ROWS == 1 || (ROWS == 3 && KW == 3 && MODE == 0), "the shared-tile form is the stride-1 3x3 one");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALO = KW / 2;
   constexpr int SX = (MODE == 1) ? 2 : 1;
+  constexpr int NT = 256 * ROWS;
   const int W = p.W, R = p.R, WH = SX * W + 2 * HALO;
-  const int npix_h = R * WH;              // staged input pixels
+  const int npix_h = (R + (ROWS == 3 ? 2 : 0)) * WH;   // staged input pixels (ROWS 3: one halo row above and below)
   const int KT = R * W;                   // contraction length per tile
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Ds = Xs + (size_t)npix_h * PITCH;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ky = (KW == 3) ? bx % 3 : 0;
-  if (KW == 3) bx /= 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3;        // wave inside its 4-wave group
+  const int ky = (ROWS == 3) ? (tid >> 8) : ((KW == 3) ? bx % 3 : 0);
+  if (KW == 3 && ROWS == 1) bx /= 3;
   const int c0 = (bx % p.c_tiles) * 64, n0 = (bx / p.c_tiles) * 64;
   const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
   const int tiles_per_img = p.H / R;
@@ -89,15 +99,16 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   float dbs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
-  const bool do_db = p.db != nullptr && c0 == 0 && ky == HALO;
+  const bool do_db = p.db != nullptr && c0 == 0 && (ROWS == 3 || ky == HALO);     // ROWS 3: dy is staged once, by every thread
   const bool cvalid = (c0 + v8 * 8) < p.Cin, nvalid = (n0 + v8 * 8) < p.Cout;
 
   // transposed-read lane geometry
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 
   // register double-buffering: tile t+1 is fetched while tile t is in the MFMAs
-  constexpr int XV = 5, DV = 4;           // 16-byte vectors per thread (input rows / dy)
-  uint4 xreg[XV], dreg[DV];
+  constexpr int XV = ROWS == 3 ? 3 : 5, DV = ROWS == 3 ? 2 : 4;   // 16-byte vectors per thread (input rows / dy)
+  struct TileRegs { uint4 x[XV], d[DV]; };
+  TileRegs rg0, rg1;       // ROWS 3 (one block per CU: nobody else covers a tile's flight): TWO tiles in flight
   // input tile source: a cin tile lies entirely in `a` or in `a2`
   const bf16_t* asrc = p.a + c0;
   int apitch = p.Cin;
@@ -105,16 +116,18 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     if (c0 < p.C1) apitch = p.C1;
     else { asrc = p.a2 + (c0 - p.C1); apitch = p.Cin - p.C1; }
   }
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, TileRegs& rg) {
+    uint4 (&xreg)[XV] = rg.x;
+    uint4 (&dreg)[DV] = rg.d;
     const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
-      int idx = tid + k * 256;
+      int idx = tid + k * NT;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (idx < npix_h * 8) {
         int pix = idx >> 3;
-        int hy = pix / WH, hx = pix - hy * WH;
-        int iy = SX * (oy0 + hy) + ky - HALO, ix = hx - HALO;
+        int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WH;      // no integer division in the tile loop
+        int iy = (ROWS == 3) ? (oy0 + hy - 1) : (SX * (oy0 + hy) + ky - HALO), ix = hx - HALO;
         if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
           if (MODE == 2) { iy >>= 1; ix >>= 1; }
           val = *reinterpret_cast<const uint4*>(asrc + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * apitch + v8 * 8);
@@ -124,22 +137,24 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     }
 #pragma unroll
     for (int k = 0; k < DV; ++k) {
-      int idx = tid + k * 256;
+      int idx = tid + k * NT;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (idx < KT * 8 && nvalid)
         val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + (idx >> 3)) * p.Cout + n0 + v8 * 8);
       dreg[k] = val;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](TileRegs& rg) {
+    uint4 (&xreg)[XV] = rg.x;
+    uint4 (&dreg)[DV] = rg.d;
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
-      int idx = tid + k * 256;
+      int idx = tid + k * NT;
       if (idx < npix_h * 8) *reinterpret_cast<uint4*>(Xs + (size_t)(idx >> 3) * PITCH + v8 * 8) = xreg[k];
     }
 #pragma unroll
     for (int k = 0; k < DV; ++k) {
-      int idx = tid + k * 256;
+      int idx = tid + k * NT;
       if (idx < KT * 8) {
         *reinterpret_cast<uint4*>(Ds + (size_t)(idx >> 3) * PITCH + v8 * 8) = dreg[k];
         if (do_db) {
@@ -154,11 +169,11 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     }
   };
 
-  if (t_beg < t_end) load_tile(t_beg);
-  for (int t = t_beg; t < t_end; ++t) {
-    store_tile();
+  constexpr int PFT = ROWS == 3 ? 2 : 1;      // tiles in flight
+  auto step = [&](int t, TileRegs& rg) {
+    store_tile(rg);
     __syncthreads();
-    if (t + 1 < t_end) load_tile(t + 1);
+    if (t + PFT < t_end) load_tile(t + PFT, rg);
     // ---- MFMA over the tile's pixels, 32 per step.  Logical k slot (g, j) maps to
     // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
     for (int ks = 0; ks < KT; ks += 32) {
@@ -170,9 +185,10 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
         for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
       }
-      int oyA = pixA / W, oxA = pixA - oyA * W, oyB = pixB / W, oxB = pixB - oyB * W;
-      const bf16_t* x0 = Xs + (size_t)(oyA * WH + SX * oxA) * PITCH + wc0 + 4 * pp;
-      const bf16_t* x1 = Xs + (size_t)(oyB * WH + SX * oxB) * PITCH + wc0 + 4 * pp;
+      int oyA = pixA >> p.wshift, oxA = pixA & (W - 1), oyB = pixB >> p.wshift, oxB = pixB & (W - 1);
+      const int yo = (ROWS == 3) ? ky : 0;        // the group's kernel row selects the staged row
+      const bf16_t* x0 = Xs + (size_t)((oyA + yo) * WH + SX * oxA) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x1 = Xs + (size_t)((oyB + yo) * WH + SX * oxB) * PITCH + wc0 + 4 * pp;
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) {
         bf16x8_t cf[2];
@@ -186,6 +202,12 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
       }
     }
     __syncthreads();
+  };
+  if (t_beg < t_end) load_tile(t_beg, rg0);
+  if (PFT == 2 && t_beg + 1 < t_end) load_tile(t_beg + 1, rg1);
+  for (int t = t_beg; t < t_end; t += PFT) {
+    step(t, rg0);
+    if (PFT == 2 && t + 1 < t_end) step(t + 1, rg1);
   }
 
   // D: row = n (4 per lane), col = c (lane & 15)
@@ -206,21 +228,21 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     }
 
   if (do_db) {
-    // reduce the 32 threads that share v8, then one atomic per cout
-    float* red = reinterpret_cast<float*>(smem);   // [32][64]
+    // reduce the NT / 8 threads that share v8, then one atomic per cout
+    float* red = reinterpret_cast<float*>(smem);   // [NT / 8][64]
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
     __syncthreads();
     if (tid < 64 && n0 + tid < p.Nw) {
       float s = 0.f;
-      for (int k = 0; k < 32; ++k) s += red[k * 64 + tid];
+      for (int k = 0; k < NT / 8; ++k) s += red[k * 64 + tid];
       atomicAdd(p.db + n0 + tid, s);
     }
   }
 }
 
 template <int KW, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16(const WgP p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16(const WgP p) {
   wgrad_block<KW, MODE>(p, blockIdx.x, blockIdx.y);
 }
 
@@ -234,7 +256,7 @@ struct WgDesc {
 };
 
 template <int KW, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDesc* __restrict__ tab, int n) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16_batched(const WgDesc* __restrict__ tab, int n) {
   const int bid = blockIdx.x;
   int lo = 0, hi = n;
   while (hi - lo > 1) {
@@ -258,10 +280,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_bf16_batched(const WgDes
   }
 }
 
+// the shared-tile form of the stride-1 3x3 class (768 threads, one block per CU)
+__global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDesc* __restrict__ tab, int n) {
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (tab[mid].blk0 <= bid) lo = mid; else hi = mid;
+  }
+  const WgDesc* d = tab + lo;
+  const WgP p = d->p;
+  const int local = bid - d->blk0, gx = d->gx;
+  if (d->xcd) {
+    const int x = local & 7, j = local >> 3;
+    const int by = x + 8 * (j / gx);
+    if (by >= d->gy) return;
+    wgrad_block<3, 0, 3>(p, j % gx, by);
+  } else {
+    if (local >= gx * d->gy) return;      // alignment padding
+    wgrad_block<3, 0, 3>(p, local % gx, local / gx);
+  }
+}
+
+// IDF_WGRAD_KR3 (default 1): the batched stride-1 3x3 class runs in the shared-tile form
+const int g_kr3 = getenv("IDF_WGRAD_KR3") ? atoi(getenv("IDF_WGRAD_KR3")) : 1;
+
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
             int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
-            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0) {
+            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0, bool kr3 = false) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -281,10 +328,20 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
   p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
   p.tiles = B * (H / R);
+  {
+    int ws = 0;
+    while ((1 << ws) < W) ++ws;
+    p.wshift = ws;
+    const int WHh = (mode == 1 ? 2 : 1) * W + 2 * (taps == 9 ? 1 : 0), np = (R + (kr3 ? 2 : 0)) * WHh;
+    unsigned m = 65536u / (unsigned)WHh + 1u;
+    for (int i = 0; i < np; ++i)
+      if ((((unsigned)i * m) >> 16) != (unsigned)(i / WHh)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: tile of %d pixels not addressable", np);
+    p.wh_magic = m;
+  }
   p.c_tiles = idf_cdiv(Cin, 64);
   p.n_tiles = idf_cdiv(Cout, 64);
   const int kh = taps == 9 ? 3 : 1;
-  gx = p.c_tiles * p.n_tiles * kh;
+  gx = p.c_tiles * p.n_tiles * (kr3 ? 1 : kh);
   if (target_blocks <= 0) {
     // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
     // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
@@ -309,8 +366,9 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.tiles_per_blk = idf_cdiv(p.tiles > 0 ? p.tiles : 1, split);
   gy = idf_cdiv(p.tiles, p.tiles_per_blk);
   const int sx = mode == 1 ? 2 : 1;
-  lds = ((size_t)R * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
-  if (lds < 32 * 64 * sizeof(float)) lds = 32 * 64 * sizeof(float);
+  lds = ((size_t)(R + (kr3 ? 2 : 0)) * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
+  const size_t red = (size_t)(kr3 ? 96 : 32) * 64 * sizeof(float);
+  if (lds < red) lds = red;
   return IDF_OK;
 }
 
@@ -364,8 +422,11 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   if (forced > 0) target_blocks = forced;
   static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 48;
   static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 48;
+  static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 64;
+  static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
+  const bool kr3 = g_kr3 && taps == 9 && mode == 0;
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
-                   a2, C1, target_blocks > 0 ? 0 : tpb, minb, Cin_w, Cout_w);
+                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : tpb), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;
@@ -386,6 +447,14 @@ extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int tot
   const WgDesc* tab = (const WgDesc*)dev_table;
   dim3 g(total_blocks);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n);
+  else if (mode == 0 && g_kr3) {
+    static bool raised = false;
+    if (!raised && lds_bytes > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_bf16_batched_kr3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raised = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_tr_bf16_batched_kr3, g, dim3(768), lds_bytes, st, tab, n);
+  }
   else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n);
   else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 1>), g, dim3(256), lds_bytes, st, tab, n);
   else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n);

@@ -45,6 +45,18 @@ struct WgP {
 constexpr int PITCH = 80;                 // elements per LDS pixel row
 constexpr int PITCHB = PITCH * 2;         // bytes
 
+// Loads / atomics through pointers that came out of a descriptor TABLE are flat instructions to hipcc (address space unknown),
+// and a flat load counts on lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of the MFMAs' LDS operands then
+// also waits for the NEXT tile's prefetch.  Going through the global address space explicitly keeps the two queues apart.
+typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4_t;
+__device__ __forceinline__ uint4 gload16(const bf16_t* p) {      // (the cast goes through an integer: a pointer-to-pointer cast stays generic)
+  const wg_u32x4_t v = *(const __attribute__((address_space(1))) wg_u32x4_t*)(unsigned long long)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gatomic_add(float* p, float v) {
+  __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ s16x4_t tr_read(const bf16_t* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4_t*)(lds_ptr));
@@ -75,7 +87,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   const int npix_h = (R + (ROWS == 3 ? 2 : 0)) * WH;   // staged input pixels (ROWS 3: one halo row above and below)
   const int KT = R * W;                   // contraction length per tile
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Ds = Xs + (size_t)npix_h * PITCH;
+  bf16_t* Ds = Xs + npix_h * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3;        // wave inside its 4-wave group
@@ -130,7 +142,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
         int iy = (ROWS == 3) ? (oy0 + hy - 1) : (SX * (oy0 + hy) + ky - HALO), ix = hx - HALO;
         if (cvalid && (unsigned)iy < (unsigned)(SX * p.H) && (unsigned)ix < (unsigned)(SX * W)) {
           if (MODE == 2) { iy >>= 1; ix >>= 1; }
-          val = *reinterpret_cast<const uint4*>(asrc + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * apitch + v8 * 8);
+          val = gload16(asrc + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * apitch + v8 * 8);
         }
       }
       xreg[k] = val;
@@ -140,7 +152,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
       int idx = tid + k * NT;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (idx < KT * 8 && nvalid)
-        val = *reinterpret_cast<const uint4*>(p.dy + ((size_t)(b * p.H + oy0) * W + (idx >> 3)) * p.Cout + n0 + v8 * 8);
+        val = gload16(p.dy + ((size_t)(b * p.H + oy0) * W + (idx >> 3)) * p.Cout + n0 + v8 * 8);
       dreg[k] = val;
     }
   };
@@ -150,13 +162,13 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
       int idx = tid + k * NT;
-      if (idx < npix_h * 8) *reinterpret_cast<uint4*>(Xs + (size_t)(idx >> 3) * PITCH + v8 * 8) = xreg[k];
+      if (idx < npix_h * 8) *reinterpret_cast<uint4*>(Xs + (idx >> 3) * PITCH + v8 * 8) = xreg[k];
     }
 #pragma unroll
     for (int k = 0; k < DV; ++k) {
       int idx = tid + k * NT;
       if (idx < KT * 8) {
-        *reinterpret_cast<uint4*>(Ds + (size_t)(idx >> 3) * PITCH + v8 * 8) = dreg[k];
+        *reinterpret_cast<uint4*>(Ds + (idx >> 3) * PITCH + v8 * 8) = dreg[k];
         if (do_db) {
           uint32_t w4[4] = {dreg[k].x, dreg[k].y, dreg[k].z, dreg[k].w};
 #pragma unroll
@@ -178,17 +190,17 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
     for (int ks = 0; ks < KT; ks += 32) {
       bf16x8_t nf[2];
-      int pixA = ks + 4 * g + q, pixB = pixA + 16;
+      const int pixA = ks + 4 * g + q, pixB = pixA + 16;
       {
-        const bf16_t* d0 = Ds + (size_t)pixA * PITCH + wn0 + 4 * pp;
-        const bf16_t* d1 = Ds + (size_t)pixB * PITCH + wn0 + 4 * pp;
+        const bf16_t* d0 = Ds + pixA * PITCH + wn0 + 4 * pp;
+        const bf16_t* d1 = Ds + pixB * PITCH + wn0 + 4 * pp;
 #pragma unroll
         for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
       }
-      int oyA = pixA >> p.wshift, oxA = pixA & (W - 1), oyB = pixB >> p.wshift, oxB = pixB & (W - 1);
+      const int oyA = pixA >> p.wshift, oxA = pixA & (W - 1), oyB = pixB >> p.wshift, oxB = pixB & (W - 1);
       const int yo = (ROWS == 3) ? ky : 0;        // the group's kernel row selects the staged row
-      const bf16_t* x0 = Xs + (size_t)((oyA + yo) * WH + SX * oxA) * PITCH + wc0 + 4 * pp;
-      const bf16_t* x1 = Xs + (size_t)((oyB + yo) * WH + SX * oxB) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x0 = Xs + ((oyA + yo) * WH + SX * oxA) * PITCH + wc0 + 4 * pp;
+      const bf16_t* x1 = Xs + ((oyB + yo) * WH + SX * oxB) * PITCH + wc0 + 4 * pp;
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) {
         bf16x8_t cf[2];
@@ -222,7 +234,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
-          if (n < p.Nw) atomicAdd(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cw + c, acc[kx][i][j][r]);
+          if (n < p.Nw) gatomic_add(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cw + c, acc[kx][i][j][r]);
         }
       }
     }
@@ -236,7 +248,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     if (tid < 64 && n0 + tid < p.Nw) {
       float s = 0.f;
       for (int k = 0; k < NT / 8; ++k) s += red[k * 64 + tid];
-      atomicAdd(p.db + n0 + tid, s);
+      gatomic_add(p.db + n0 + tid, s);
     }
   }
 }

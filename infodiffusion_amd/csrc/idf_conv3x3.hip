@@ -823,12 +823,9 @@ __device__ __forceinline__ unsigned long long dlds_now() {
 #define DLDS_DECL unsigned long long dlds_sum[6] = {0, 0, 0, 0, 0, 1}
 #define DLDS_ADD(i, a, b) dlds_sum[i] += (b) - (a)
 #define DLDS_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_dlds_stamps[(blockIdx.x & 63) * 8 + i_], dlds_sum[i_]); } while (0)
-extern "C" int idf_debug_dlds_stamps(unsigned long long* out8, int reset) {
-  static unsigned long long h[64 * 8];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dlds_stamps), sizeof(h)) != hipSuccess) return 1;
-  for (int i = 0; i < 8; ++i) { out8[i] = 0; for (int s = 0; s < 64; ++s) out8[i] += h[s * 8 + i]; }
-  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_dlds_stamps), h, sizeof(h)) != hipSuccess) return 1; }
-  return 0;
+// the diagnostic build's tool (tools/dlds_stamps.py) reads and clears the 64 x 8 counters through this device address
+extern "C" int idf_debug_dlds_stamps(void** dev_addr) {
+  return hipGetSymbolAddress(dev_addr, HIP_SYMBOL(g_dlds_stamps)) == hipSuccess ? 0 : 1;
 }
 #else
 #define DLDS_STAMP(var)

@@ -82,7 +82,7 @@ class GradSync:
         self._early_done = False
 
     @torch.no_grad()
-    def reduce_early(self):
+    def reduce_early(self, after=None):
         """All-reduce the early slice of the arena on the side stream (everything enqueued so far on the current
         stream has produced it); the rest of backward keeps running on the current stream.  `all_reduce_grads` joins
         the side stream again -- so this must not run inside a stream capture that ends before that call
@@ -98,6 +98,8 @@ class GradSync:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(cur)
+            if after is not None:                # a stream that is still producing part of the slice (deferred wgrad)
+                self._side.wait_stream(after)
             with torch.cuda.stream(self._side):
                 self._reduce_mean(flat[:self._cut])
         self._early_done = True

@@ -413,8 +413,8 @@ class InfoDiff(nn.Module):
             # ended -- launch the backbone's deferred weight gradients and put its slice of the gradient arena on
             # the wire while the encoder's backward pass runs (dist.GradSync.attach)
             def _early(grad, sync=sync):
-                ops.WgradBatch.flush()
-                sync.reduce_early()
+                ops.WgradBatch.flush_async()
+                sync.reduce_early(after=ops.WgradBatch.side_stream())
                 return None
             lat = lat.view_as(lat)
             lat.register_hook(_early)

@@ -509,9 +509,11 @@ def test_gn_one_launch_small(C, H, dtype):
     assert rel(dx2, xr.grad + dres.float()) < btol
 
 
-def test_wgrad_bf16_batched_matches_single_launches():
+@pytest.mark.parametrize('split', [0, 5])
+def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
     """All weight gradients of a backward pass from ONE table-driven launch per (taps, mode) class
-    (idf_conv_wgrad_bf16_batched, accumulating into gradient-arena slots) == the per-conv launches."""
+    (idf_conv_wgrad_bf16_batched, accumulating into gradient-arena slots) == the per-conv launches.  `split`: the first
+    `split` convs are flushed mid-backward on the side stream (WgradBatch.flush_async), the rest at the end, which joins."""
     from infodiffusion_amd.grad_arena import GradArena, slot_of
     cases = [(4, 32, 32, 32, 32, 9, ops.S1), (4, 64, 16, 16, 128, 9, ops.S1), (2, 128, 8, 8, 128, 1, ops.S1),
              (4, 32, 32, 32, 64, 9, ops.S1), (4, 128, 8, 8, 128, 9, ops.S1), (2, 64, 16, 16, 64, 9, ops.S2),
@@ -530,15 +532,19 @@ def test_wgrad_bf16_batched_matches_single_launches():
         refs.append(ops.conv_wgrad_bias_raw(a, dy, mode, taps, True))
     arena = GradArena(ws + bs)
     assert ops.WgradBatch.enabled and not ops.WgradBatch.pending
-    ops.WgradBatch.pending.append(None)              # hold the queue open as a running backward pass would
+    ops.WgradBatch._cb_queued = True                 # hold the queue open as a running backward pass would
     outs = []
-    for (a, dy), w, b, c in zip(data, ws, bs, cases):
+    for i, ((a, dy), w, b, c) in enumerate(zip(data, ws, bs, cases)):
         outs.append(ops.conv_wgrad_bias_raw(a, dy, c[6], c[5], True, slot_of(w), slot_of(b), True))
-    ops.WgradBatch.pending.pop(0)
-    assert len(ops.WgradBatch.pending) == len(cases)
-    assert all(float(o[0].abs().max()) == 0.0 for o in outs)      # nothing launched yet
+        if split and i + 1 == split:
+            assert all(float(o[0].abs().max()) == 0.0 for o in outs)      # nothing launched yet
+            monkeypatch.setattr(ops.WgradBatch, 'side_enabled', True)
+            ops.WgradBatch.flush_async()
+            assert not ops.WgradBatch.pending and ops.WgradBatch.side_stream() is not None
+    assert len(ops.WgradBatch.pending) == len(cases) - split
+    assert all(float(o[0].abs().max()) == 0.0 for o in outs[split:])      # nothing launched yet
     ops.WgradBatch.flush()
-    assert not ops.WgradBatch.pending
+    assert not ops.WgradBatch.pending and ops.WgradBatch.side_stream() is None
     for (rW, rb), (oW, ob) in zip(refs, outs):
         assert arena.holds(oW) and arena.holds(ob)
         assert rel(oW.cpu(), rW.cpu()) < 1e-5 and rel(ob.cpu(), rb.cpu()) < 1e-5
@@ -582,9 +588,8 @@ def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     wp = torch.nn.Parameter(torch.zeros(Cout, C, 1, 1, device=DEV))
     bp = torch.nn.Parameter(torch.zeros(Cout, device=DEV))
     arena = GradArena([wp, bp])
-    ops.WgradBatch.pending.append(None)
+    ops.WgradBatch._cb_queued = True
     got = ops._defer_or_launch_wgrad(x1, dy, slot_of(wp), slot_of(bp), 1, a2=x2)
-    ops.WgradBatch.pending.pop(0)
     assert got is not None
     ops.WgradBatch.flush()
     assert rel(got[0], ref_dW) < 1e-5 and rel(got[1], ref_db) < 1e-5

@@ -15,7 +15,7 @@ from infodiffusion_amd import _lib, ops
 B, Cin, Cout, H, pro = [int(v) for v in sys.argv[1:6]]
 DEV, CL = 'cuda', torch.channels_last
 lib = _lib.load()
-lib.idf_debug_dlds_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.idf_debug_dlds_stamps.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
 w = torch.randn(Cout, Cin, 3, 3, device=DEV) / (9 * Cin) ** 0.5
 wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
 g, bt = torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV)
@@ -34,8 +34,24 @@ def run(i):
 for i in range(4):
     run(i)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 8)()
-lib.idf_debug_dlds_stamps(buf, 1)
+_addr = ctypes.c_void_p()
+assert lib.idf_debug_dlds_stamps(ctypes.byref(_addr)) == 0
+_hip = ctypes.CDLL('libamdhip64.so')
+_hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+_raw = (ctypes.c_ulonglong * 512)()
+
+
+def stamps(reset):
+    """Sum of the 64 shards; optionally clear them."""
+    assert _hip.hipMemcpy(_raw, _addr, 4096, 2) == 0                  # device to host
+    out = [sum(_raw[s * 8 + i] for s in range(64)) for i in range(8)]
+    if reset:
+        zero = (ctypes.c_ulonglong * 512)()
+        assert _hip.hipMemcpy(_addr, zero, 4096, 1) == 0              # host to device
+    return out
+
+
+stamps(1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 N = 20
@@ -43,7 +59,7 @@ for i in range(N):
     run(i)
 e1.record()
 torch.cuda.synchronize()
-lib.idf_debug_dlds_stamps(buf, 0)
+buf = stamps(0)
 nb = max(1, buf[5])
 names = ['prologue', 'load wait', 'transform', 'mfma', 'epilogue']
 tot = sum(buf[i] for i in range(5))

@@ -255,6 +255,29 @@ int idf_bgemm(const void* A, const void* B, void* C, const float* bias, const vo
               long sB, long sC,
               int lda, int ldb, int ldc, int M, int N, int K, int ta, int tb, float alpha, int out_f32,
               int splitk, int dtype, void* stream);
+/* The conditioning path of a UNet as one entry point per direction (three launches forward, four backward: products
+ * of the same depth in the chain share a launch): TimeEmbedding (modules.py:9-38: table lookup -> Linear -> SiLU -> Linear), the latent embedding fc_a
+ * (models.py:298-301; fc_silu = 1 for the Bottleneck's Sequential(SiLU, Linear), models.py:371), and every block's
+ * FiLM projections Linear(SiLU(emb)) (modules.py:269-276) over the concatenated weights Wt [Nt][dim], Wa [Na][dim].
+ * All fp32.  t [B] int64, table [T][d_model], W1 [dim][d_model], W2 [dim][dim], a [B][a_dim] or NULL (no latent
+ * branch), Wfc [dim][a_dim].  Kept for the backward ([B][dim] each): h1, s1 = SiLU(h1), temb, st = SiLU(temb), aemb,
+ * sa = SiLU(aemb).  Outputs film_t [B][Nt], film_a [B][Na]. */
+int idf_temb_film_fwd(const long long* t, const float* table, int d_model, const float* W1, const float* b1,
+                      const float* W2, const float* b2, int dim, const float* a, int a_dim, const float* Wfc,
+                      const float* bfc, int fc_silu, const float* Wt, const float* bt, int Nt, const float* Wa,
+                      const float* ba, int Na, float* h1, float* s1, float* temb, float* st, float* aemb, float* sa,
+                      float* film_t, float* film_a, int B, void* stream);
+/* Its backward: every gradient pointer is optional (NULL = not wanted).  Scratch: dS, (idf_temb_film_parts(Nt) +
+ * idf_temb_film_parts(Na)) * B * dim floats -- the K slices of dfilm * W, summed in slice order (no atomics: the
+ * latent's gradient is bit-reproducible) -- and g1 [B][dim]; B * dim % 4 == 0.  Gradients are written (not
+ * accumulated) in the parameters' own layouts. */
+int idf_temb_film_parts(int N);
+int idf_temb_film_bwd(const float* dfilm_t, const float* dfilm_a, const long long* t, const float* table, int d_model,
+                      const float* W2, int dim, const float* a, int a_dim, const float* Wfc, int fc_silu, const float* Wt,
+                      int Nt, const float* Wa, int Na, const float* h1, const float* s1, const float* temb, const float* st,
+                      const float* aemb, const float* sa, float* dS, float* g1, float* dWt, float* dbt, float* dWa,
+                      float* dba, float* dW2, float* db2, float* dW1, float* db1, float* dWfc, float* dbfc, float* da, int B,
+                      void* stream);
 int idf_softmax_fwd(void* s, long R, int N, int dtype, void* stream);            /* modules.py:156 */
 int idf_softmax_bwd(const void* P, void* dP, long R, int N, int dtype, void* stream);
 

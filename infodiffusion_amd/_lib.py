@@ -49,6 +49,11 @@ SIGNATURES = {
     'idf_conv_wgrad_bf16_batched': ([_p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 12 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
+    'idf_temb_film_fwd': ([_p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i] + [_p] * 8 + [_i, _p],
+                          C.c_int),
+    'idf_temb_film_parts': ([_i], C.c_int),
+    'idf_temb_film_bwd': ([_p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i] + [_p] * 6 + [_p] * 13 + [_i, _p],
+                          C.c_int),
     'idf_softmax_fwd': ([_p, _l, _i, _i, _p], C.c_int),
     'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),
     'idf_attn_fused_ok': ([_i, _i, _i], C.c_int),

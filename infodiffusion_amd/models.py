@@ -11,7 +11,7 @@ from torch.nn import init
 
 from . import ops
 from .modules import (AuxResBlock, DownSample, ResBlock, ResBlock_encoder, RunCtx, TimeEmbedding, UpSample,
-                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, film_groups)
+                      ShadowSet, _Shadows, _cfg, _ACT_NONE, _ACT_SILU, batched_film, bind_context, film_groups, fused_film)
 from .utils import compute_mmd, gaussian_mixture, swiss_roll
 
 _DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
@@ -142,8 +142,12 @@ class UNet(_UNetSkeleton):
 
     def forward(self, x, t):
         x = self._prep(x)
-        temb = self.time_embedding(t)
-        batched_film(self._res_blocks(), temb, 't')
+        blocks = self._res_blocks()
+        if fused_film(self.time_embedding, t, blocks):
+            temb = None
+        else:
+            temb = self.time_embedding(t)
+            batched_film(blocks, temb, 't')
         return self._run(x, lambda blk, h, **kw: blk(h, temb, **kw))
 
 
@@ -170,11 +174,14 @@ class AuxiliaryUNet(_UNetSkeleton):
 
     def forward(self, x, t, a):
         x = self._prep(x)
-        aemb = ops.linear(a, self.fc_a.weight, self.fc_a.bias)
-        temb = self.time_embedding(t)
         blocks = self._res_blocks()
-        batched_film(blocks, temb, 't')
-        batched_film(blocks, aemb, 'a')
+        if fused_film(self.time_embedding, t, blocks, a, self.fc_a, False, blocks):
+            temb = aemb = None          # every block finds its FiLM pairs in `_film`
+        else:
+            aemb = ops.linear(a, self.fc_a.weight, self.fc_a.bias)
+            temb = self.time_embedding(t)
+            batched_film(blocks, temb, 't')
+            batched_film(blocks, aemb, 'a')
         return self._run(x, lambda blk, h, **kw: blk(h, temb, aemb, **kw))
 
 
@@ -202,12 +209,15 @@ class BottleneckAuxUNet(_UNetSkeleton):
 
     def forward(self, x, t, a):
         x = self._prep(x)
-        aemb = ops.linear(a, self.fc_a[1].weight, self.fc_a[1].bias, silu_in=True)
-        temb = self.time_embedding(t)
         blocks = self._res_blocks()
-        batched_film(blocks, temb, 't')
         mids = [m for m in blocks if isinstance(m, AuxResBlock)]
-        batched_film(mids, aemb, 'a')
+        if fused_film(self.time_embedding, t, blocks, a, self.fc_a[1], True, mids):
+            temb = aemb = None
+        else:
+            aemb = ops.linear(a, self.fc_a[1].weight, self.fc_a[1].bias, silu_in=True)
+            temb = self.time_embedding(t)
+            batched_film(blocks, temb, 't')
+            batched_film(mids, aemb, 'a')
         return self._run(x, lambda blk, h, **kw: (blk(h, temb, aemb, **kw) if isinstance(blk, AuxResBlock)
                                                   else blk(h, temb, **kw)))
 

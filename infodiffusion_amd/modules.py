@@ -465,3 +465,29 @@ def batched_film(blocks, emb, which):
     out = ops.linear(emb, ops.cat_params(groups[0]), ops.cat_params(groups[1]), silu_in=True)
     for blk, chunk in zip(blocks, out.split([l.weight.shape[0] for l in lins], dim=1)):
         blk._film[which] = chunk
+
+
+def fused_film(time_embedding, t, blocks_t, a=None, fc=None, fc_silu=False, blocks_a=None):
+    """The whole conditioning path in one call (ops.temb_film): TimeEmbedding(t), fc_a(a) and every block's FiLM
+    projections; each block finds its [B, 2C] column slices in `_film` as after `batched_film`.  False when the fused
+    entry does not apply (the caller then takes the per-product path)."""
+    tab, l1, _, l2 = time_embedding.timembedding
+    if not torch.is_tensor(t) or t.dtype != torch.long:
+        return False
+    if not ops.temb_film_ok(tab.weight, l1.weight, a, fc.weight if fc is not None else None):
+        return False
+    gt = film_groups(blocks_t, 't')
+    film_t = (ops.cat_params(gt[0]), ops.cat_params(gt[1]))
+    film_a = None
+    if a is not None and blocks_a:
+        ga = film_groups(blocks_a, 'a')
+        film_a = (ops.cat_params(ga[0]), ops.cat_params(ga[1]))
+    out_t, out_a = ops.temb_film(t, tab.weight, l1, l2, film_t, a if film_a is not None else None,
+                                 fc if film_a is not None else None, fc_silu, film_a)
+    for blk, chunk in zip(blocks_t, out_t.split([b.temb_proj[1].weight.shape[0] for b in blocks_t], dim=1)):
+        blk._film['t'] = chunk
+    if film_a is not None:
+        for blk, chunk in zip(blocks_a, out_a.split([b.aemb_proj[1].weight.shape[0] for b in blocks_a], dim=1)):
+            blk._film['a'] = chunk
+    return True
+

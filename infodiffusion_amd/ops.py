@@ -1241,6 +1241,92 @@ def linear(x, weight, bias=None, silu_in=False):
     return _Linear.apply(x, weight, bias, silu_in, slots)
 
 
+# ------------------------------------------------- conditioning path (time / latent embedding -> FiLM)
+_TEMB_FUSED = os.environ.get('IDF_TEMB_FUSED', '1') != '0'
+
+
+def _grad_dst(slot, like):
+    """Where a parameter gradient is written: the parameter's gradient-arena slot when it is free, else a new tensor."""
+    if slot is not None and slot.available() and tuple(slot.view.shape) == tuple(like.shape) and slot.view.is_contiguous():
+        return slot.take()
+    return torch.empty(like.shape, dtype=torch.float32, device=like.device)
+
+
+class _TembFilm(torch.autograd.Function):
+    """film_t = Linear_t(SiLU(temb)), film_a = Linear_a(SiLU(aemb)) with temb = TimeEmbedding(t) (modules.py:9-38) and
+    aemb = fc_a(a) (models.py:298-301) -- the whole conditioning path through idf_temb_film_fwd / _bwd (three launches
+    forward, four backward, instead of one per product, SiLU, bias gradient and split-K reduction)."""
+
+    @staticmethod
+    def forward(ctx, t, a, table, W1, b1, W2, b2, Wfc, bfc, Wt, bt, Wa, ba, fc_silu, slots):
+        B = t.shape[0]
+        dev = table.device
+        t = t.contiguous()
+        has_a = a is not None
+        par = [_f32c(v) if v is not None else None for v in (table, W1, b1, W2, b2, Wfc, bfc, Wt, bt, Wa, ba)]
+        table, W1, b1, W2, b2, Wfc, bfc, Wt, bt, Wa, ba = par
+        a = _f32c(a) if has_a else None
+        dim, d_model = W1.shape
+        Nt = Wt.shape[0]
+        Na = Wa.shape[0] if (has_a and Wa is not None) else 0
+        a_dim = a.shape[1] if has_a else 0
+        keep = torch.empty((6, B, dim), dtype=torch.float32, device=dev)        # h1, s1, temb, st, aemb, sa
+        film_t = torch.empty((B, Nt), dtype=torch.float32, device=dev)
+        film_a = torch.empty((B, Na), dtype=torch.float32, device=dev) if Na else None
+        call('idf_temb_film_fwd', _p(t), _p(table), d_model, _p(W1), _p(b1), _p(W2), _p(b2), dim, _p(a), a_dim, _p(Wfc),
+             _p(bfc), int(bool(fc_silu)), _p(Wt), _p(bt), Nt, _p(Wa), _p(ba), Na, _p(keep[0]), _p(keep[1]), _p(keep[2]),
+             _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(film_t), _p(film_a), B, _st())
+        ctx.fc_silu, ctx.slots, ctx.has_a, ctx.Na = bool(fc_silu), slots or (None,) * 10, has_a, Na
+        ctx.save_for_backward(t, a, table, W1, W2, Wfc, Wt, Wa, keep)
+        return film_t, film_a
+
+    @staticmethod
+    def backward(ctx, dft, dfa):
+        t, a, table, W1, W2, Wfc, Wt, Wa, keep = ctx.saved_tensors
+        need = ctx.needs_input_grad         # t, a, table, W1, b1, W2, b2, Wfc, bfc, Wt, bt, Wa, ba, fc_silu, slots
+        B, dev = t.shape[0], table.device
+        dim, d_model = W1.shape
+        Nt = Wt.shape[0]
+        has_a = ctx.has_a and ctx.Na > 0
+        dft = _f32c(dft) if dft is not None else torch.zeros((B, Nt), dtype=torch.float32, device=dev)
+        if has_a:
+            dfa = _f32c(dfa) if dfa is not None else torch.zeros((B, ctx.Na), dtype=torch.float32, device=dev)
+        sl = ctx.slots            # W1, b1, W2, b2, Wfc, bfc, Wt, bt, Wa, ba
+        shapes = (W1, W1[:, 0], W2, W2[:, 0], Wfc, Wfc[:, 0] if Wfc is not None else None, Wt, Wt[:, 0], Wa,
+                  Wa[:, 0] if Wa is not None else None)
+        g = [None] * 10
+        for i in range(10):
+            live = i < 4 or (i in (6, 7)) or has_a
+            if need[3 + i] and live and shapes[i] is not None:
+                g[i] = _grad_dst(sl[i], shapes[i])
+        da = torch.empty_like(a) if (has_a and need[1]) else None
+        lib = _lib.load()
+        parts = lib.idf_temb_film_parts(Nt) + (lib.idf_temb_film_parts(ctx.Na) if has_a else 0)
+        scratch = torch.empty((parts + 1, B, dim), dtype=torch.float32, device=dev)      # K slices of dS | dh1s
+        dS, dh1s = scratch[:parts], scratch[parts]
+        call('idf_temb_film_bwd', _p(dft), _p(dfa) if has_a else None, _p(t), _p(table), d_model, _p(W2), dim, _p(a),
+             a.shape[1] if a is not None else 0, _p(Wfc), int(ctx.fc_silu), _p(Wt), Nt, _p(Wa), ctx.Na, _p(keep[0]),
+             _p(keep[1]), _p(keep[2]), _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(dS), _p(dh1s), _p(g[6]), _p(g[7]), _p(g[8]),
+             _p(g[9]), _p(g[2]), _p(g[3]), _p(g[0]), _p(g[1]), _p(g[4]), _p(g[5]), _p(da), B, _st())
+        if ctx.has_a and not has_a and need[1]:
+            da = torch.zeros_like(a)
+        return (None, da, None, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], None, None)
+
+
+def temb_film_ok(table, *tensors):
+    return _TEMB_FUSED and table.is_cuda and all(v is None or v.dtype == torch.float32 for v in tensors)
+
+
+def temb_film(t, table, l1, l2, film_t, a=None, fc=None, fc_silu=False, film_a=None):
+    """(film_t [B, Nt], film_a [B, Na] or None).  l1, l2, fc: nn.Linear modules; film_t / film_a: (weight, bias) of the
+    concatenated FiLM projections (cat_params views of the blocks' ParamGroups)."""
+    ps = [l1.weight, l1.bias, l2.weight, l2.bias, fc.weight if fc is not None else None,
+          fc.bias if fc is not None else None, film_t[0], film_t[1], film_a[0] if film_a is not None else None,
+          film_a[1] if film_a is not None else None]
+    slots = tuple(slot_of(v) for v in ps) if torch.is_grad_enabled() else None
+    return _TembFilm.apply(t, a, table, *ps, fc_silu, slots)
+
+
 # ------------------------------------------------------------ input pipeline
 def prep_u8(img_u8, flip=None):
     """uint8 NHWC image batch [B, H, W, C] on the GPU -> fp32 activations (x / 255 - 0.5) / 0.5, logical

@@ -716,3 +716,55 @@ def test_groupnorm_prologue_conv_one_launch(case):
         y2 = ops.conv_gn_raw(xp, None, ops.gn_partials_raw(xp), None, gam, bet, ft, fa, seed, 7, p_drop, act, wf, bias, res,
                              Cout, taps)[0]
         assert rel(y1, y2) < 1e-2
+
+
+@pytest.mark.parametrize('B,with_a,fc_silu', [(2, True, False), (32, True, False), (5, False, False), (32, True, True),
+                                               (70, True, False)])
+def test_conditioning_path_one_entry_matches_pytorch(B, with_a, fc_silu):
+    """idf_temb_film_fwd / _bwd (TimeEmbedding + fc_a + every block's FiLM projections; three launches forward, four backward:
+    modules.py:9-38, 269-276; models.py:298-301, 371) against fp32 PyTorch autograd of the same chain: both outputs and
+    every parameter gradient + the latent's.  Ragged widths (not multiples of the 64-wide tile) on purpose."""
+    import torch.nn.functional as F
+    T, d_model, dim, a_dim, Nt, Na = 50, 64, 256, 32, 2 * (64 + 100), 200
+    g = torch.Generator(device='cpu')
+    g.manual_seed(B)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    table = mk(T, d_model)
+    t = torch.randint(0, T, (B,), generator=g).to(DEV)
+    P = dict(W1=mk(dim, d_model, sc=d_model ** -0.5), b1=mk(dim, sc=0.1), W2=mk(dim, dim, sc=dim ** -0.5), b2=mk(dim, sc=0.1),
+             Wfc=mk(dim, a_dim, sc=a_dim ** -0.5), bfc=mk(dim, sc=0.1), Wt=mk(Nt, dim, sc=dim ** -0.5), bt=mk(Nt, sc=0.1),
+             Wa=mk(Na, dim, sc=dim ** -0.5), ba=mk(Na, sc=0.1))
+    a = mk(B, a_dim)
+    gt, ga = mk(B, Nt), mk(B, Na)
+
+    def leaves():
+        return {k: v.clone().requires_grad_(True) for k, v in P.items()}, a.clone().requires_grad_(True)
+
+    R, ar = leaves()
+    temb = F.linear(F.silu(F.linear(table[t], R['W1'], R['b1'])), R['W2'], R['b2'])
+    ft_ref = F.linear(F.silu(temb), R['Wt'], R['bt'])
+    loss = (ft_ref * gt).sum()
+    if with_a:
+        aemb = F.linear(F.silu(ar) if fc_silu else ar, R['Wfc'], R['bfc'])
+        fa_ref = F.linear(F.silu(aemb), R['Wa'], R['ba'])
+        loss = loss + (fa_ref * ga).sum()
+    loss.backward()
+
+    O_, ao = leaves()
+    n = lambda k: O_[k] if with_a else None
+    ft, fa = ops._TembFilm.apply(t, ao if with_a else None, table, O_['W1'], O_['b1'], O_['W2'], O_['b2'], n('Wfc'), n('bfc'),
+                                 O_['Wt'], O_['bt'], n('Wa'), n('ba'), fc_silu, None)
+    assert rel(ft, ft_ref) < 1e-5
+    lo = (ft * gt).sum()
+    if with_a:
+        assert rel(fa, fa_ref) < 1e-5
+        lo = lo + (fa * ga).sum()
+    else:
+        assert fa is None
+    lo.backward()
+    for k in P:
+        if not with_a and k in ('Wfc', 'bfc', 'Wa', 'ba'):
+            continue
+        assert rel(O_[k].grad, R[k].grad) < 2e-5, k
+    if with_a:
+        assert rel(ao.grad, ar.grad) < 2e-5

@@ -881,18 +881,22 @@ def test_graphed_train_step_replays_and_follows_lr_changes():
     assert np.isfinite(float(step(short, 0)))
 
 
-def test_data_parallel_path_one_rank_rccl_matches_no_exchange():
-    """The whole data-parallel step on the real (fmnist) model over RCCL with one rank: gradients averaged over a
-    world of 1 are unchanged, so loss and gradient norm must equal the run without an exchange at every step -- with
-    the backbone slice of the arena all-reduced from the hook on the latent while the encoder's backward pass runs,
-    the encoder slice + stand-alone gradients after it, and exchange + optimizer captured inside the hipGraph."""
+@pytest.mark.parametrize('tag,dtype', [('fmnist', 'fp32'), ('celeba', 'bf16')])
+def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
+    """The whole data-parallel step on the real model over RCCL with one rank: gradients averaged over a world of 1 are
+    unchanged, so loss and gradient norm must equal the run without an exchange -- with the backbone slice of the arena
+    all-reduced from the hook on the latent while the encoder's backward pass runs, the encoder slice + stand-alone
+    gradients after it, and exchange + optimizer captured inside the hipGraph.  fp32 (fmnist): every step to 1e-3 / 1e-2.
+    bf16 (the benchmarked CelebA model): the first two steps (one eager warm-up, one more) to 1e-3 on the loss and
+    1e-2 / 3e-2 on the norm; after that two runs of the SAME configuration drift apart (fp32 atomic order in the weight
+    gradients feeding bf16 training), so the later steps only have to keep training."""
     import os
     import torch.distributed as dist
     from infodiffusion_amd.dist import GradSync
     from infodiffusion_amd.optim import FusedClipAdamW
     from infodiffusion_amd.trainer import GraphedTrainStep
-    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
-    g = gold('model_fmnist')
+    cfg = O.dataset_cfg(tag, a_dim=32, mmd_weight=0.1)
+    g = gold('model_' + tag)
     x = g['x'].to(DEV)
     own_group = not dist.is_initialized()
     if own_group:
@@ -901,7 +905,7 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV, 0))
     try:
         def run(with_sync):
-            model, args, sd = make_infodiff(cfg, DEV, 'bf16', 'manifest_fmnist')
+            model, args, sd = make_infodiff(cfg, DEV, dtype, 'manifest_' + tag)
             model.eval()                        # no dropout: the two runs draw the same noise from the same seeds
             opt = FusedClipAdamW(model.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
             sync = GradSync(model, 1, force=True, arena=opt.arena) if with_sync else None
@@ -917,9 +921,8 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange():
         ref, _ = run(False)
         got, st = run(True)
         assert st.graph is not None and st.sync_in_graph
-        # the first step must agree closely; later steps drift apart like two runs of the SAME configuration do (fp32
-        # atomic order in the weight gradients feeding bf16 training: 0.3 % on the loss, a few % on the norm by step 5)
-        for k, (tl, tn) in enumerate([(1e-4, 1e-3), (5e-3, 3e-2), (2e-2, 0.15), (3e-2, 0.25), (4e-2, 0.4)]):
+        tols = [(1e-3, 1e-2)] * 5 if dtype == 'fp32' else [(1e-3, 1e-2), (1e-3, 3e-2)]
+        for k, (tl, tn) in enumerate(tols):
             (l0, n0), (l1, n1) = ref[k], got[k]
             assert abs(l0 - l1) <= tl * abs(l0) and abs(n0 - n1) <= tn * abs(n0), (k, ref, got)
         assert ref[-1][0] < ref[0][0] and got[-1][0] < got[0][0]           # both train

@@ -566,7 +566,8 @@ class WgradBatch:
     _LRU = 6
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
-    # Flushes issued DURING backward (`flush_async`: the data-parallel latent hook of InfoDiff.forward) can run on a side stream next to the data-gradient chain; the end-of-backward flush joins it again.
+    # Flushes issued DURING backward (`flush_async`: the data-parallel latent hook of InfoDiff.forward) can run on a side
+    # stream next to the data-gradient chain; the end-of-backward flush joins it again.
     # Off by default: measured on one GPU the chain slows down by more than the weight gradients hide (10.11 -> 10.25 ms
     # with one early flush, 11.2 ms with a flush every 8 queued convs: profiles/r03_v_ab_wgrad_side.txt).
     side_enabled = os.environ.get('IDF_WGRAD_SIDE', '0') != '0'
@@ -682,7 +683,8 @@ class WgradBatch:
                 buf[4] = torch.cuda.Event()
                 buf[4].record()
         base = buf[1].data_ptr()
-        for off, n, blk, lds, taps, mode in buf[3]:
+        plan = buf[3]
+        for off, n, blk, lds, taps, mode in plan:
             call('idf_conv_wgrad_bf16_batched', base + off * nb, n, blk, lds, taps, mode, _st())
 
 

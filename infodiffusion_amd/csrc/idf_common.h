@@ -31,6 +31,23 @@ void idf_set_error(const char* fmt, ...);
     }                                                             \
   } while (0)
 
+// Dynamic LDS beyond 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel -- a per-DEVICE attribute.  One
+// `granted` array per kernel (a static of the launching function / template instantiation) remembers what each device
+// already has, so the attribute is raised once per (kernel, device, larger request), not per launch.  A failure is
+// returned: the launch that follows would run without the opt-in.  (A racing duplicate call is harmless.)
+#include <atomic>
+struct IdfLdsGrant { std::atomic<size_t> granted[32]; };
+inline hipError_t idf_ensure_lds(const void* kern, size_t bytes, IdfLdsGrant& g) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 32 && g.granted[dev].load(std::memory_order_relaxed) >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && dev >= 0 && dev < 32) g.granted[dev].store(bytes, std::memory_order_relaxed);
+  return e;
+}
+
 typedef uint16_t bf16_t;  // raw storage
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -1536,15 +1536,12 @@ inline size_t aux_bytes(const C3P& p, bool pro, int nwaves, int BN) {
   return a > s ? a : s;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is raised once per kernel (per larger request), not on every launch:
-// `have` is a static of the calling launch<...> instantiation, i.e. one per kernel.  (A racing duplicate call is harmless.)
-#define IDF_ENSURE_LDS(kern, bytes)                                                                            \
-  do {                                                                                                         \
-    static std::atomic<size_t> have{64 * 1024};                                                                \
-    if ((size_t)(bytes) > have.load(std::memory_order_relaxed)) {                                             \
-      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-      have.store((size_t)(bytes), std::memory_order_relaxed);                                                  \
-    }                                                                                                          \
+// idf_ensure_lds with one grant record per kernel (a static of the calling launch<...> instantiation).  Should the opt-in
+// fail, the launch is skipped and the error left for the caller's IDF_CHECK_LAUNCH.
+#define IDF_ENSURE_LDS(kern, bytes)                                                              \
+  do {                                                                                           \
+    static IdfLdsGrant grant_;                                                                   \
+    if (idf_ensure_lds((const void*)(kern), (size_t)(bytes), grant_) != hipSuccess) return;      \
   } while (0)
 
 template <int KS, bool PRO = false, bool DUAL = false>

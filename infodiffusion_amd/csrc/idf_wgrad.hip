@@ -156,7 +156,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
       dreg[k] = val;
     }
   };
-  auto store_tile = [&](TileRegs& rg) {
+  auto store_tile = [&](TileRegs& rg, bf16_t* Xs, bf16_t* Ds) {
     uint4 (&xreg)[XV] = rg.x;
     uint4 (&dreg)[DV] = rg.d;
 #pragma unroll
@@ -181,11 +181,8 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     }
   };
 
-  constexpr int PFT = ROWS == 3 ? 2 : 1;      // tiles in flight
-  auto step = [&](int t, TileRegs& rg) {
-    store_tile(rg);
-    __syncthreads();
-    if (t + PFT < t_end) load_tile(t + PFT, rg);
+  // ---- MFMA over the tile's pixels, 32 per step
+  auto compute = [&](const bf16_t* Xs, const bf16_t* Ds) {
     // ---- MFMA over the tile's pixels, 32 per step.  Logical k slot (g, j) maps to
     // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
     for (int ks = 0; ks < KT; ks += 32) {
@@ -213,13 +210,44 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
             acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf[j], acc[kx][i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
   };
-  if (t_beg < t_end) load_tile(t_beg, rg0);
-  if (PFT == 2 && t_beg + 1 < t_end) load_tile(t_beg + 1, rg1);
-  for (int t = t_beg; t < t_end; t += PFT) {
-    step(t, rg0);
-    if (PFT == 2 && t + 1 < t_end) step(t + 1, rg1);
+  if constexpr (ROWS == 3) {
+    // one block per CU: nobody else covers a tile's staging, so the tile lives in LDS twice.  Tile t is contracted from
+    // one buffer while the waves that are done with it already write tile t + 1 (in registers since two tiles ago) into
+    // the other: ONE barrier per tile, and the MFMA pipe no longer idles through every LDS write phase.
+    bf16_t* X1 = Xs + (npix_h + KT) * PITCH;
+    bf16_t* D1 = X1 + npix_h * PITCH;
+    if (t_beg < t_end) load_tile(t_beg, rg0);
+    if (t_beg + 1 < t_end) load_tile(t_beg + 1, rg1);
+    if (t_beg < t_end) {
+      store_tile(rg0, Xs, Ds);
+      if (t_beg + 2 < t_end) load_tile(t_beg + 2, rg0);
+    }
+    __syncthreads();
+    for (int t = t_beg; t < t_end; t += 2) {
+      compute(Xs, Ds);                                  // tile t; rg1 = tile t + 1, rg0 = tile t + 2 (in flight)
+      if (t + 1 < t_end) {
+        store_tile(rg1, X1, D1);
+        if (t + 3 < t_end) load_tile(t + 3, rg1);
+      }
+      __syncthreads();
+      if (t + 1 >= t_end) break;
+      compute(X1, D1);                                  // tile t + 1; rg0 = tile t + 2, rg1 = tile t + 3 (in flight)
+      if (t + 2 < t_end) {
+        store_tile(rg0, Xs, Ds);
+        if (t + 4 < t_end) load_tile(t + 4, rg0);
+      }
+      __syncthreads();
+    }
+  } else {
+    if (t_beg < t_end) load_tile(t_beg, rg0);
+    for (int t = t_beg; t < t_end; ++t) {
+      store_tile(rg0, Xs, Ds);
+      __syncthreads();
+      if (t + 1 < t_end) load_tile(t + 1, rg0);        // tile t + 1 is fetched while tile t is in the MFMAs
+      compute(Xs, Ds);
+      __syncthreads();
+    }
   }
 
   // D: row = n (4 per lane), col = c (lane & 15)
@@ -378,7 +406,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.tiles_per_blk = idf_cdiv(p.tiles > 0 ? p.tiles : 1, split);
   gy = idf_cdiv(p.tiles, p.tiles_per_blk);
   const int sx = mode == 1 ? 2 : 1;
-  lds = ((size_t)(R + (kr3 ? 2 : 0)) * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB;
+  lds = ((size_t)(R + (kr3 ? 2 : 0)) * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB * (kr3 ? 2 : 1);     // kr3: two LDS tiles
   const size_t red = (size_t)(kr3 ? 96 : 32) * 64 * sizeof(float);
   if (lds < red) lds = red;
   return IDF_OK;
@@ -460,11 +488,9 @@ extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int tot
   dim3 g(total_blocks);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n);
   else if (mode == 0 && g_kr3) {
-    static bool raised = false;
-    if (!raised && lds_bytes > 64 * 1024) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_bf16_batched_kr3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      raised = true;
-    }
+    static IdfLdsGrant grant;
+    if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_tr_bf16_batched_kr3, (size_t)lds_bytes, grant); e != hipSuccess)
+      IDF_FAIL((int)e, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
     hipLaunchKernelGGL(conv_wgrad_tr_bf16_batched_kr3, g, dim3(768), lds_bytes, st, tab, n);
   }
   else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n);

@@ -460,8 +460,8 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   size_t lds;
   static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
   if (forced > 0) target_blocks = forced;
-  static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 48;
-  static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 48;
+  static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 16;      // re-swept for the 1x1 / stride-2 / up-sampling classes: profiles/r03_wgrad_tpb_sweep.txt
+  static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 96;
   static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 64;
   static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
   const bool kr3 = g_kr3 && taps == 9 && mode == 0;

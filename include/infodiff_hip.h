@@ -145,6 +145,24 @@ int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_
                               const float* sc, const float* sh, const uint64_t* seed, uint32_t salt, float p_drop,
                               int act, void* out, float* part_out, int B, int H, int W, int Cin, int Cout, int taps,
                               void* stream);
+/* ResBlock shortcuts riding in their neighbours' launches (round 3).  A block whose channel count changes computes
+ * `self.shortcut(x)` (a 1x1 conv, modules.py:228, 248, 281) beside `self.block1(x)`: idf_conv_gn_sc_bf16 is idf_conv_gn_bf16
+ * (3x3, Cout > 32) whose launch carries extra blocks computing  sc_y [B,H,W,sc_Cout] = conv1x1(x | x2, sc_w [sc_Cout][Cin]) +
+ * sc_bias  over the RAW input (same pixel tiles; no prologue; centre tap only).  In backward the shortcut's data gradient
+ * rides with the first conv's: idf_conv_dgrad_chain_sc_bf16 is idf_conv_dgrad_chain_bf16 (3x3, du epilogue, no dy
+ * prologue) + extra blocks computing  sc_dx [B,H,W,Cout] = conv1x1(sc_dy [B,H,W,sc_Cin], sc_w [Cout][sc_Cin])  with sc_w
+ * the shortcut's data-gradient weights (idf_pack_conv_weight); sc_dx then joins idf_gn_bwd_apply as `dres`.
+ * sc_Cout % 8 == 0, sc_Cin % 32 == 0.  Two launches fewer per such block and step. */
+int idf_conv_gn_sc_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                        const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
+                        float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop, const void* w, const float* bias,
+                        const void* res, void* y, void* a_out, float* mean, float* rstd, float* sc, float* sh, float* st_out,
+                        float* coef_ws, int B, int H, int W, int Cin, int Cout, int taps, void* stream, const void* sc_w,
+                        const float* sc_bias, void* sc_y, int sc_Cout);
+int idf_conv_dgrad_chain_sc_bf16(const void* dy, const void* w, const void* x, const void* x2, int C1, const float* sc,
+                                 const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, void* out,
+                                 float* part_out, int B, int H, int W, int Cin, int Cout, void* stream, const void* sc_dy,
+                                 const void* sc_w, void* sc_dx, int sc_Cin);
 /* dx = A*du + K1*x + K0 (+ dres + dres2) from the (du, part [B][T][C][2]) pair idf_conv_dgrad_chain_bf16 leaves behind: the
  * GroupNorm / FiLM backward of modules.py:312-318 without its reduction (one read of du, x and the branch gradients, one
  * write of dx; every block folds its image's partials first).  x may be the pair x [..,C1] | x2 (then dx2 is written too).

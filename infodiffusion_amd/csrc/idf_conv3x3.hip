@@ -69,6 +69,14 @@ struct C3P {
   // (gn_bwd_fold; block (row tile 0, cout tile 0) of an image stores that GroupNorm's parameter / FiLM gradients);
   // dyp_out: dy written once (interior vectors of cout tile 0), kept for the weight gradient of the conv that produced xg
   const bf16_t* dyp_x; bf16_t* dyp_out; GnFoldP dyp_f;
+  // ---- an auxiliary 1x1 job riding in the same launch (conv3x3_halo_bf16, MODE 0, KS 3, BN 64): blocks >= main_blocks run
+  // y_aux = conv1x1(x_aux | x2_aux) + bias_aux over the same pixel tiles -- the ResBlock shortcut (modules.py:228, 248) beside
+  // the block's first conv (forward: both read the block input) or its data gradient beside the first conv's (backward):
+  // the input is staged raw (no prologue), only the centre tap is contracted, the epilogue is the plain one.
+  int main_blocks, aux_blocks;
+  const bf16_t* aux_x; const bf16_t* aux_x2; int aux_C1, aux_Cin;
+  const bf16_t* aux_w;          // [aux_Cout][aux_Cin]
+  const float* aux_bias; bf16_t* aux_y; int aux_Cout, aux_n_tiles;
   // ---- persistent wave-specialised form (conv_ps_bf16): a pixel tile = NI images x R rows x W columns = 256 pixels
   int ps_NI, ps_rwshift;        // images per tile, log2(R * W)
   int ps_npi;                   // halo pixels per image, (R + 2 halo)(W + 2 halo)
@@ -558,8 +566,21 @@ __device__ __forceinline__ void due_epilogue(const C3P& p, const f32x4_t (&acc)[
 // BWD: the backward chain at the big maps (MODE 0, BN 64, Cout % 64 == 0) -- bit 0: dy prologue (the staged input is
 // A * du + K1 * xg + K0, two tensors per vector), bit 1: du epilogue (due_epilogue).
 template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool PRO = false, bool GNB = false, int BWD = 0>
-__global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
+__global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
   constexpr bool DYP = (BWD & 1) != 0, DUE = (BWD & 2) != 0;
+  constexpr bool AUX_OK = MODE == 0 && KS == 3 && BN == 64 && !GNB && !DYP;     // instantiations that may carry an auxiliary job
+  C3P p = p_in;
+  int bid = blockIdx.x;
+  bool aux = false;
+  if constexpr (AUX_OK) {
+    if (p_in.aux_blocks > 0 && bid >= p_in.main_blocks) {       // block-uniform
+      aux = true;
+      bid -= p_in.main_blocks;
+      p.x = p_in.aux_x; p.x2 = p_in.aux_x2; p.C1 = p_in.aux_C1; p.Cin = p_in.aux_Cin; p.w = p_in.aux_w; p.bias = p_in.aux_bias;
+      p.res = nullptr; p.y = p_in.aux_y; p.Cout = p_in.aux_Cout; p.n_tiles = p_in.aux_n_tiles; p.st_out = nullptr;
+      p.a_out = nullptr;
+    }
+  }
   constexpr int NT = NWM * 128;               // threads (NWM x 2 waves)
   constexpr int TN = BN / 32;                 // cout 16-tiles per wave
   constexpr int TAPS = KS * KS, HALO = KS / 2;
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   unsigned char* Ws = smem + (size_t)npix_h * 64;   // [TAPS][BN][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int tile = bid / p.n_tiles, n0 = (bid % p.n_tiles) * BN;
   const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
   const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
   const int fr = lane & 15, fq = lane >> 4;
@@ -643,6 +664,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     if (idx < BN * TAPS * 4) {
       if (n0 + n < p.Cout) woff[k] = ((n0 + n) * TAPS + tap) * p.Cin + ch * 8;
       wlds[k] = (tap * BN + n) * 64 + swz(n, ch) * 16;
+      if (AUX_OK && aux) {                     // 1x1 weights [Cout][Cin]: the centre tap's slot only
+        woff[k] = (tap == TAPS / 2 && n0 + n < p.Cout) ? (n0 + n) * p.Cin + ch * 8 : -1;
+        if (tap != TAPS / 2) wlds[k] = -1;
+      }
     }
   }
 
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   float* cof = reinterpret_cast<float*>(smem + p.aux_off);      // PRO: [Cin][2] (sc, sh)
   uint64_t seedv = 0;
   bool drop = false;
-  if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
+  if (PRO && !aux) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
   auto store_chunk = [&](int ck, Stage& S) {
     uint4 (&hreg)[HV] = S.h;
     uint4 (&wreg)[WV] = S.w;
@@ -701,7 +726,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
           if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.dyp_out + (unsigned)(hoff[k] + ck * CK)) = hreg[k];
         }
     }
-    if (PRO) {
+    if (PRO && !aux) {
       const int cb = ck * CK + (tid & 3) * 8;         // this thread's 8 channels of the chunk (idx & 3 == tid & 3)
       float scv[8], shv[8];
 #pragma unroll
@@ -730,7 +755,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
   if (PFD == 2 && nchunks > 1) load_chunk(1, st1);
   GnbPre<GNB ? BM * (BN / 8) / NT : 1> gpre;
   if constexpr (GNB) gnb_prefetch<BM, BN, NT>(p, b, n0, KT, tid, gpre);
-  if (PRO) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
+  if (PRO && !aux) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   if constexpr (DYP) gn_bwd_fold<NT>(p.dyp_f, b, oy0 == 0 && n0 == 0, cof, cof + 4 * p.Cin, tid);
   auto step = [&](int ck, Stage& S) {
     store_chunk(ck, S);
@@ -738,6 +763,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     if (ck + PFD < nchunks) load_chunk(ck + PFD, S);     // the stage's registers are free again: next chunk of this slot
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
+      if (AUX_OK && aux && tap != TAPS / 2) continue;       // (block-uniform)
       const int toff = (tap / KS) * WH + (tap % KS);
       bf16x8_t wf[TN], xf[TM];
 #pragma unroll
@@ -760,8 +786,10 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p) {
     if (PFD == 2 && ck + 1 < nchunks) step(ck + 1, st1);
   }
   if constexpr (DUE) {
-    due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
-    return;
+    if (!aux) {
+      due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+      return;
+    }
   }
 
   // epilogue.  A lane holds couts n..n+3 of one pixel, i.e. 8-byte pieces scattered over 16 pixel
@@ -1568,7 +1596,9 @@ void launch(C3P& p, hipStream_t st) {
   lds += aux_bytes(p, PRO, NWM * 2, BN);
   auto kern = conv3x3_halo_bf16<MODE, TM, BN, NWM, KS, DUAL, PRO>;
   IDF_ENSURE_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
+  p.main_blocks = p.B * p.tiles_per_img * p.n_tiles;
+  if (!(MODE == 0 && KS == 3 && BN == 64)) p.aux_blocks = 0;           // (callers attach an auxiliary job only to these)
+  hipLaunchKernelGGL(kern, dim3(p.main_blocks + p.aux_blocks), dim3(NWM * 128), lds, st, p);
 }
 
 template <int TM, int NWM, int KS>
@@ -1595,7 +1625,9 @@ void launch_bwd_chain(C3P& p, hipStream_t st) {
   lds += a > s ? a : s;
   auto kern = conv3x3_halo_bf16<0, TM, BN, NWM, KS, false, false, false, BWD>;
   IDF_ENSURE_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(NWM * 128), lds, st, p);
+  p.main_blocks = p.B * p.tiles_per_img * p.n_tiles;
+  if (!(KS == 3 && !(BWD & 1))) p.aux_blocks = 0;
+  hipLaunchKernelGGL(kern, dim3(p.main_blocks + p.aux_blocks), dim3(NWM * 128), lds, st, p);
 }
 
 void clear_pro(C3P& p) {
@@ -1608,6 +1640,8 @@ void clear_pro(C3P& p) {
   p.gnb_dfilm_t = p.gnb_dfilm_a = p.gnb_dgb = p.gnb_dgam = p.gnb_dbet = nullptr;
   p.due_x = p.due_x2 = nullptr; p.due_C1 = 0; p.due_sc = p.due_sh = nullptr;
   p.dyp_x = nullptr; p.dyp_out = nullptr; memset(&p.dyp_f, 0, sizeof(p.dyp_f));
+  p.main_blocks = p.aux_blocks = 0; p.aux_x = p.aux_x2 = p.aux_w = nullptr; p.aux_C1 = p.aux_Cin = 0; p.aux_bias = nullptr;
+  p.aux_y = nullptr; p.aux_Cout = p.aux_n_tiles = 0;
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
 #ifdef IDF_PS_DBG
   static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
@@ -1954,13 +1988,15 @@ extern "C" int idf_conv_gn_advice(int B, int H, int W, int Cin, int Cout, int ta
 // mean / rstd [B,32] and sc / sh [B,Cin] (for idf_gn_fused_bwd / idf_gn_coef_bwd); st_out as above.
 // coef_ws (optional): B * Cin * 2 floats of scratch -- launches that cut an image into many tiles fold the coefficients
 // once per image into it with a small launch of their own instead of once per block.
-extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
-                                const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
-                                int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
-                                const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
-                                float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
-                                int Cout, int taps, void* stream) {
+static int conv_gn_impl(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                        const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                        int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
+                        const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                        float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
+                        int Cout, int taps, void* stream, const void* sc_w, const float* sc_bias, void* sc_y, int sc_Cout) {
   if (!x2) { C1 = Cin; st2 = nullptr; T2 = 0; }
+  if (sc_w && (taps != 9 || Cout <= 32 || !sc_y || sc_Cout <= 0 || (sc_Cout & 7)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_sc_bf16: the shortcut rides with 3x3 convs of > 32 couts (taps %d Cout %d sc_Cout %d)", taps, Cout, sc_Cout);
   const bool ok = taps == 9 ? shape3_ok(H, W, Cin, Cout, 0) : (taps == 1 && shape1_ok(W, Cin, Cout));
   if (!ok || (Cin % 32) || (x2 && (C1 <= 0 || C1 >= Cin || (C1 % CK))))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: B%d H%d W%d Cin%d (C1 %d) Cout%d taps%d not covered", B, H, W, Cin, C1, Cout, taps);
@@ -1994,10 +2030,51 @@ extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const flo
     p.cof_in = coef_ws;
     p.mean_out = p.rstd_out = p.sc_out = p.sh_out = nullptr;      // written by the coefficient launch
   }
+  if (sc_w) {
+    // the block's 1x1 shortcut over the same (raw) input as extra blocks of this launch: the register-staged kernel only
+    p.aux_x = p.x; p.aux_x2 = p.x2; p.aux_C1 = p.C1; p.aux_Cin = Cin; p.aux_w = (const bf16_t*)sc_w; p.aux_bias = sc_bias;
+    p.aux_y = (bf16_t*)sc_y; p.aux_Cout = sc_Cout; p.aux_n_tiles = idf_cdiv(sc_Cout, 64);
+    p.n_tiles = idf_cdiv(Cout, 64);
+    p.aux_blocks = B * p.tiles_per_img * p.aux_n_tiles;
+    if (x2) {
+      if (BM == 256) launch<0, 4, 64, 4, 3, true, true>(p, st); else if (BM == 128) launch<0, 4, 64, 2, 3, true, true>(p, st); else launch<0, 2, 64, 2, 3, true, true>(p, st);
+    } else {
+      if (BM == 256) launch<0, 4, 64, 4, 3, false, true>(p, st); else if (BM == 128) launch<0, 4, 64, 2, 3, false, true>(p, st); else launch<0, 2, 64, 2, 3, false, true>(p, st);
+    }
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+  }
   if (taps == 9) { if (x2) dispatch3<true, true>(p, 0, BM, st); else dispatch3<false, true>(p, 0, BM, st); }
   else { if (x2) dispatch1<true, true>(p, BM, st); else dispatch1<false, true>(p, BM, st); }
   IDF_CHECK_LAUNCH();
   return IDF_OK;
+}
+
+extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                                const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                                int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
+                                const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                                float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W, int Cin,
+                                int Cout, int taps, void* stream) {
+  return conv_gn_impl(x, x2, C1, st1, T1, st2, T2, gamma, beta, film_t, film_a, ld_t, ld_a, eps, act, seed, salt, p_drop, w, bias,
+                      res, y, a_out, mean, rstd, sc, sh, st_out, coef_ws, B, H, W, Cin, Cout, taps, stream, nullptr, nullptr,
+                      nullptr, 0);
+}
+
+// The same launch also runs the block's 1x1 shortcut  sc_y = conv1x1(x | x2, sc_w [sc_Cout][Cin]) + sc_bias  over the RAW
+// input (modules.py:228, 248, 281: `self.shortcut(x)` beside `self.block1(x)`): extra blocks of the 3x3 launch, one launch
+// fewer per ResBlock whose channel count changes.  3x3 convs of more than 32 couts, sc_Cout % 8 == 0.
+extern "C" int idf_conv_gn_sc_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                                   const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                                   int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,
+                                   const void* w, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                                   float* rstd, float* sc, float* sh, float* st_out, float* coef_ws, int B, int H, int W,
+                                   int Cin, int Cout, int taps, void* stream, const void* sc_w, const float* sc_bias, void* sc_y,
+                                   int sc_Cout) {
+  if (!sc_w) IDF_FAIL(IDF_ERR_BADARG, "conv_gn_sc_bf16: shortcut weights missing");
+  return conv_gn_impl(x, x2, C1, st1, T1, st2, T2, gamma, beta, film_t, film_a, ld_t, ld_a, eps, act, seed, salt, p_drop, w, bias,
+                      res, y, a_out, mean, rstd, sc, sh, st_out, coef_ws, B, H, W, Cin, Cout, taps, stream, sc_w, sc_bias, sc_y,
+                      sc_Cout);
 }
 
 // ---- the backward chain at the big maps (64x64 / 32x32: a tile is a slice of an image, so the GroupNorm backward's
@@ -2039,15 +2116,17 @@ extern "C" int idf_conv_dgrad_chain_tiles(int B, int H, int W, int Cin, int Cout
   return H / R;
 }
 
-extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T,
-                                         const float* in_mean, const float* in_rstd, const float* in_sc,
-                                         const float* in_gamma, const float* in_beta, const float* in_film_t,
-                                         const float* in_film_a, int in_ld_t, int in_ld_a, float* in_dfilm_t,
-                                         float* in_dfilm_a, float* in_dgb, float* in_dgamma_acc, float* in_dbeta_acc,
-                                         void* dy_out, const void* w, const void* x, const void* x2, int C1,
-                                         const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
-                                         float p_drop, int act, void* out, float* part_out, int B, int H, int W, int Cin,
-                                         int Cout, int taps, void* stream) {
+static int dgrad_chain_impl(const void* dy, const void* in_x, const float* in_part, int in_T,
+                            const float* in_mean, const float* in_rstd, const float* in_sc,
+                            const float* in_gamma, const float* in_beta, const float* in_film_t,
+                            const float* in_film_a, int in_ld_t, int in_ld_a, float* in_dfilm_t,
+                            float* in_dfilm_a, float* in_dgb, float* in_dgamma_acc, float* in_dbeta_acc,
+                            void* dy_out, const void* w, const void* x, const void* x2, int C1,
+                            const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
+                            float p_drop, int act, void* out, float* part_out, int B, int H, int W, int Cin,
+                            int Cout, int taps, void* stream, const void* sc_dy, const void* sc_w, void* sc_dx, int sc_Cin) {
+  if (sc_dy && (taps != 9 || in_x || !sc_w || !sc_dx || sc_Cin <= 0 || (sc_Cin % 32)))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_chain_sc_bf16: the shortcut's data gradient rides with 3x3 launches without a dy prologue (taps %d sc_Cin %d)", taps, sc_Cin);
   if (idf_conv_dgrad_chain_tiles(B, H, W, Cin, Cout, taps) < 0)
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_dgrad_chain_bf16: B%d H%d W%d Cin%d Cout%d taps%d not covered", B, H, W, Cin, Cout, taps);
   if (!dy || !w || !out) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_bf16: null argument");
@@ -2088,6 +2167,12 @@ extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const
     p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
     p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
   }
+  if (sc_dy) {
+    // sc_dx [B,H,W,Cout] = conv1x1(sc_dy [B,H,W,sc_Cin], sc_w [Cout][sc_Cin]): the shortcut's data gradient, extra blocks
+    p.aux_x = (const bf16_t*)sc_dy; p.aux_x2 = nullptr; p.aux_C1 = sc_Cin; p.aux_Cin = sc_Cin; p.aux_w = (const bf16_t*)sc_w;
+    p.aux_bias = nullptr; p.aux_y = (bf16_t*)sc_dx; p.aux_Cout = Cout; p.aux_n_tiles = Cout / 64;
+    p.aux_blocks = B * p.tiles_per_img * p.aux_n_tiles;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int bwd = (in_x ? 1 : 0) | (x ? 2 : 0);
 #define IDF_CHAIN(KS)                                                                                     \
@@ -2100,4 +2185,31 @@ extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const
 #undef IDF_CHAIN
   IDF_CHECK_LAUNCH();
   return IDF_OK;
+}
+
+extern "C" int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T,
+                                         const float* in_mean, const float* in_rstd, const float* in_sc,
+                                         const float* in_gamma, const float* in_beta, const float* in_film_t,
+                                         const float* in_film_a, int in_ld_t, int in_ld_a, float* in_dfilm_t,
+                                         float* in_dfilm_a, float* in_dgb, float* in_dgamma_acc, float* in_dbeta_acc,
+                                         void* dy_out, const void* w, const void* x, const void* x2, int C1,
+                                         const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
+                                         float p_drop, int act, void* out, float* part_out, int B, int H, int W, int Cin,
+                                         int Cout, int taps, void* stream) {
+  return dgrad_chain_impl(dy, in_x, in_part, in_T, in_mean, in_rstd, in_sc, in_gamma, in_beta, in_film_t, in_film_a, in_ld_t,
+                          in_ld_a, in_dfilm_t, in_dfilm_a, in_dgb, in_dgamma_acc, in_dbeta_acc, dy_out, w, x, x2, C1, sc, sh, seed,
+                          salt, p_drop, act, out, part_out, B, H, W, Cin, Cout, taps, stream, nullptr, nullptr, nullptr, 0);
+}
+
+// The same launch also runs the data gradient of the block's 1x1 shortcut,  sc_dx [B,H,W,Cout] = conv1x1(sc_dy [B,H,W,sc_Cin],
+// sc_w [Cout][sc_Cin])  (sc_w = the shortcut's data-gradient weights, idf_pack_conv_weight): both gradients of a block
+// entry in one launch; sc_dx then joins idf_gn_bwd_apply as `dres`.  3x3, du epilogue only (no dy prologue), sc_Cin % 32 == 0.
+extern "C" int idf_conv_dgrad_chain_sc_bf16(const void* dy, const void* w, const void* x, const void* x2, int C1, const float* sc,
+                                            const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act,
+                                            void* out, float* part_out, int B, int H, int W, int Cin, int Cout, void* stream,
+                                            const void* sc_dy, const void* sc_w, void* sc_dx, int sc_Cin) {
+  if (!sc_dy) IDF_FAIL(IDF_ERR_BADARG, "conv_dgrad_chain_sc_bf16: shortcut gradient missing");
+  return dgrad_chain_impl(dy, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, w, x, x2, C1, sc, sh, seed, salt, p_drop, act, out,
+                          part_out, B, H, W, Cin, Cout, 9, stream, sc_dy, sc_w, sc_dx, sc_Cin);
 }

@@ -210,9 +210,10 @@ def _gn_advice(B, H, W, Cin, Cout, taps):
 
 
 def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
-                keep_a=False, keep_coef=False, want_stats=False):
+                keep_a=False, keep_coef=False, want_stats=False, shortcut=None):
     """y = conv(act(GN/FiLM(x | x2))) + bias (+ residual) in one launch -> (y, a, mean, rstd, sc, sh, st_out);
-    a / the coefficients are None unless asked for (training)."""
+    a / the coefficients are None unless asked for (training).  shortcut = (w_sc [Cs][Cin] kernel layout, bias_sc, Cs): the
+    same launch also computes s = conv1x1(x | x2) + bias_sc (the block's shortcut over the raw input), returned last."""
     B, C1, H, W = x.shape
     Cin = C1 + (x2.shape[1] if x2 is not None else 0)
     dev = x.device
@@ -226,10 +227,16 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
         sh = torch.empty((B, Cin), dtype=torch.float32, device=dev)
     st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev, 1) if want_stats else None
     ws = torch.empty((B, Cin, 2), dtype=torch.float32, device=dev) if B * H * W >= (1 << 18) else None
-    call('idf_conv_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
-         _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, act, _p(seed), salt, float(p_drop),
-         _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), _p(ws), B, H, W, Cin,
-         Cout, taps, _st())
+    args = (_p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
+            _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, act, _p(seed), salt, float(p_drop),
+            _p(w_fwd), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), _p(ws), B, H, W, Cin,
+            Cout, taps, _st())
+    if shortcut is not None:
+        w_sc, b_sc, Cs = shortcut
+        s = empty_nhwc(B, Cs, H, W, x.dtype, dev)
+        call('idf_conv_gn_sc_bf16', *args, _p(w_sc), _p(b_sc), _p(s), Cs)
+        return y, a, mean, rstd, sc, sh, st, s
+    call('idf_conv_gn_bf16', *args)
     return y, a, mean, rstd, sc, sh, st
 
 
@@ -417,6 +424,8 @@ _BWD_CHAIN = os.environ.get('IDF_BWD_CHAIN', '1') != '0'     # du epilogue + str
 # OFF by default: the prologue (in-block coefficient fold + two tensors staged per vector + the side write of dy) costs the
 # conv +25 us at 64->64 @64^2, B = 32, against the 12 us streaming pass it removes -- 10.89 vs 10.43 ms per step on one box
 # (profiles/r03_c_ab_chain_lazy.txt, r03_d_step_inventory_chain_lazy.txt)
+_SC_FUSE = os.environ.get('IDF_SC_FUSE', '1') != '0'       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
+_SC_FUSE_MAXHW = int(os.environ.get('IDF_SC_FUSE_MAXHW', '256'))   # ... where those launches leave CUs idle (maps up to 16 x 16)
 _BWD_LAZY = os.environ.get('IDF_BWD_LAZY', '0') != '0'
 
 
@@ -464,16 +473,23 @@ def _lazy_check_consumed():
 
 
 def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=None, x2=None, sc=None, sh=None, seed=None,
-                         salt=0, p_drop=0.0, act=0):
+                         salt=0, p_drop=0.0, act=0, shortcut=None):
     """Stride-1 data-gradient conv of the backward chain -> (out, part, dy_mat).  lazy: `dy` is lazy.du and the real input
     gradient is formed in the prologue (written to dy_mat when want_dy); x (+ x2): du epilogue, out = du and part = its
-    per-tile partial sums -- else out = dA."""
+    per-tile partial sums -- else out = dA.  shortcut = (ds, w_sc_dgrad): the launch also computes the block shortcut's
+    data gradient dxs = conv1x1(ds) (3x3, du epilogue, no lazy input) -> (out, part, dxs)."""
     B, Cin, H, W = dy.shape
     out = empty_nhwc(B, Cout, H, W, dy.dtype, dy.device)
     part = None
     C1 = x.shape[1] if (x is not None and x2 is not None) else 0
     if x is not None:
         part = torch.empty((B, chain_tiles(B, H, W, Cin, Cout, taps), Cout, 2), dtype=torch.float32, device=dy.device)
+    if shortcut is not None:
+        ds, w_sc = shortcut
+        dxs = empty_nhwc(B, Cout, H, W, dy.dtype, dy.device)
+        call('idf_conv_dgrad_chain_sc_bf16', _p(dy), _p(w_dgrad), _p(x), _p(x2), C1, _p(sc), _p(sh), _p(seed), salt,
+             float(p_drop), act, _p(out), _p(part), B, H, W, Cin, Cout, _st(), _p(ds), _p(w_sc), _p(dxs), ds.shape[1])
+        return out, part, dxs
     dy_mat = torch.empty_like(dy, memory_format=CL) if (lazy is not None and want_dy) else None
     L = lazy
     acc = L.acc if L is not None else None
@@ -983,15 +999,21 @@ class _BlockEntryCat(torch.autograd.Function):
         st = None
         if st1 is not None and st2 is not None and conv_gn_ok(x1, x2, 9, w.shape[0]):
             # GroupNorm + SiLU applied while the conv stages the two sources; statistics from their producers
-            h, a, mean, rstd, sc, sh, st = conv_gn_raw(x1, x2, st1, st2, gn_w, gn_b, None, None, None, cfg['salt'], 0.0,
-                                                       cfg['act'], w_fwd, b, None, w.shape[0], 9, keep_a=need[2],
-                                                       keep_coef=any(need[i] for i in (0, 1, 4, 5)), want_stats=True)
+            # (the 1x1 shortcut over the same raw input rides in the launch: IDF_SC_FUSE)
+            ride = _SC_FUSE and H * W <= _SC_FUSE_MAXHW and w.shape[0] > 32 and sw.shape[0] % 8 == 0
+            out = conv_gn_raw(x1, x2, st1, st2, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], w_fwd, b, None,
+                              w.shape[0], 9, keep_a=need[2], keep_coef=any(need[i] for i in (0, 1, 4, 5)), want_stats=True,
+                              shortcut=(cfg_sc['shadows'](x1.dtype, train)[0], sb, sw.shape[0]) if ride else None)
+            h, a, mean, rstd, sc, sh, st = out[:7]
+            s = out[7] if ride else None
         else:
             a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
             h, st = conv_raw(a, w_fwd, b, None, None, None, None, 0, 0.0, S1, 9, 0, w.shape[0], want_stats=True)
-        s = empty_nhwc(B, sw.shape[0], H, W, x1.dtype, x1.device)
-        call('idf_conv1x1_bf16', _p(x1), _p(x2), C1, _p(cfg_sc['shadows'](x1.dtype, train)[0]), _p(sb), None, _p(s),
-             B, H, W, C, sw.shape[0], None, _st())
+            s = None
+        if s is None:
+            s = empty_nhwc(B, sw.shape[0], H, W, x1.dtype, x1.device)
+            call('idf_conv1x1_bf16', _p(x1), _p(x2), C1, _p(cfg_sc['shadows'](x1.dtype, train)[0]), _p(sb), None, _p(s),
+                 B, H, W, C, sw.shape[0], None, _st())
         ctx.cfg, ctx.cfg_sc, ctx.slots = cfg, cfg_sc, slots or (None,) * 6
         ctx.has_st = st is not None
         ctx.chain_ok = _BWD_CHAIN and C1 % 64 == 0 and chain_tiles(B, H, W, w.shape[0], C, 9) > 0     # see _FusedConv
@@ -1023,14 +1045,21 @@ class _BlockEntryCat(torch.autograd.Function):
             xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL)
             got = conv_wgrad_bias_raw(xc, ds, S1, 1, True)
         dsW, dsb = got
-        dxs = conv_dgrad_raw(ds, cfg_sc['shadows'](x1.dtype, True)[1], S1, 1, (B, C, H, W))
+        w_sc_dgrad = cfg_sc['shadows'](x1.dtype, True)[1]
         w_dgrad = cfg['shadows'](x1.dtype, True)[1]
+        ride = (ctx.chain_ok and _SC_FUSE and H * W <= _SC_FUSE_MAXHW and lazy_in is None and
+                ds.shape[1] % 32 == 0)                      # shortcut dgrad in the chain launch
+        dxs = None if ride else conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
         if ctx.chain_ok:
             # the conv's epilogue emits du and the per-tile sums over the two-source input; dx1 / dx2 by a streaming pass
-            du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc, sh=sh,
-                                                    act=cfg['act'])
-            if lazy_in is not None:
-                dh = dh_mat
+            if ride:
+                du, part, dxs = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'],
+                                                     shortcut=(ds, w_sc_dgrad))
+            else:
+                du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc,
+                                                        sh=sh, act=cfg['act'])
+                if lazy_in is not None:
+                    dh = dh_mat
             (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, (gws, gbs),
                                                            dres=dxs, x2=x2)
         else:

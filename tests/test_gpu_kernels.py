@@ -768,3 +768,51 @@ def test_conditioning_path_one_entry_matches_pytorch(B, with_a, fc_silu):
         assert rel(O_[k].grad, R[k].grad) < 2e-5, k
     if with_a:
         assert rel(ao.grad, ar.grad) < 2e-5
+
+
+@pytest.mark.parametrize('case', [
+    # (B, C1, C2, H, Cout, Cs)
+    (2, 128, 64, 16, 64, 64), (3, 128, 128, 8, 128, 128), (33, 128, 64, 64, 64, 64), (4, 128, 128, 32, 128, 128),
+    (2, 64, 0, 16, 128, 128), (5, 256, 128, 16, 128, 72),
+])
+def test_shortcut_rides_in_the_first_convs_launches(case):
+    """idf_conv_gn_sc_bf16 / idf_conv_dgrad_chain_sc_bf16: a ResBlock's 1x1 shortcut (modules.py:228, 248, 281) and its
+    data gradient as extra blocks of the block's first 3x3 launch and of that conv's data-gradient launch -- against fp32
+    PyTorch, and the main job's outputs unchanged (bitwise) by the rider."""
+    B, C1, C2, H, Cout, Cs = case
+    C = C1 + C2
+    x1 = (0.5 + 1.5 * rnd(1, B, C1, H, H)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    x2 = (rnd(2, B, C2, H, H) - 0.3).to(DEV).bfloat16().contiguous(memory_format=CL) if C2 else None
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL) if C2 else x1
+    gam, bet = (1 + 0.1 * rnd(3, C)).to(DEV), (0.1 * rnd(4, C)).to(DEV)
+    w = (rnd(7, Cout, C, 3, 3) / (C * 9) ** 0.5).to(DEV)
+    bias = rnd(8, Cout).to(DEV)
+    wsc = (rnd(11, Cs, C, 1, 1) / C ** 0.5).to(DEV)
+    bsc = rnd(12, Cs).to(DEV)
+    wf, wd = ops.pack_weight(w, torch.bfloat16, True, True)
+    wsf, wsd = ops.pack_weight(wsc, torch.bfloat16, True, True)
+    st1, st2 = ops.gn_partials_raw(x1), (ops.gn_partials_raw(x2) if C2 else None)
+    plain = ops.conv_gn_raw(x1, x2, st1, st2, gam, bet, None, None, None, 7, 0.0, 2, wf, bias, None, Cout, 9, keep_a=True,
+                            keep_coef=True, want_stats=True)
+    ride = ops.conv_gn_raw(x1, x2, st1, st2, gam, bet, None, None, None, 7, 0.0, 2, wf, bias, None, Cout, 9, keep_a=True,
+                           keep_coef=True, want_stats=True, shortcut=(wsf, bsc, Cs))
+    y, a, mean, rstd, sc, sh, st, s = ride
+    u = F.silu(F.group_norm(xc.float(), 32, gam, bet, eps=1e-5))
+    assert rel(y, F.conv2d(u, w, bias, padding=1)) < 2e-2
+    assert rel(s, F.conv2d(xc.float(), wsc, bsc)) < 1e-2
+    assert rel(a, u) < 1e-2 and rel(sc, plain[4]) < 1e-6 and rel(sh, plain[5]) < 1e-6
+    assert rel(y, plain[0]) < 1e-2          # (another kernel variant may have computed `plain`: not bitwise)
+    s1, s2 = _chan_sums(y)
+    assert float((st.double().sum(dim=1)[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+
+    # backward: du / partials of the main job + the shortcut's data gradient
+    if not ops.chain_tiles(B, H, H, Cout, C, 9) > 0 or Cs % 32:
+        return
+    dh = rnd(20, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    ds = rnd(21, B, Cs, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    du0, part0, _ = ops.conv_dgrad_chain_raw(dh, wd, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=2)
+    du, part, dxs = ops.conv_dgrad_chain_raw(dh, wd, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=2, shortcut=(ds, wsd))
+    assert torch.equal(du, du0) and torch.equal(part, part0)
+    xr = xc.float().clone().requires_grad_(True)
+    F.conv2d(xr, wsc, bsc).backward(ds.float())
+    assert rel(dxs, xr.grad) < 1e-2

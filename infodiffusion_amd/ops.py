@@ -425,7 +425,7 @@ _BWD_CHAIN = os.environ.get('IDF_BWD_CHAIN', '1') != '0'     # du epilogue + str
 # conv +25 us at 64->64 @64^2, B = 32, against the 12 us streaming pass it removes -- 10.89 vs 10.43 ms per step on one box
 # (profiles/r03_c_ab_chain_lazy.txt, r03_d_step_inventory_chain_lazy.txt)
 _SC_FUSE = os.environ.get('IDF_SC_FUSE', '1') != '0'       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
-_SC_FUSE_MAXHW = int(os.environ.get('IDF_SC_FUSE_MAXHW', '256'))   # ... where those launches leave CUs idle (maps up to 16 x 16)
+_SC_FUSE_MAXPIX = int(os.environ.get('IDF_SC_FUSE_MAXPIX', '8192'))   # ... where those launches leave CUs idle: B * H * W up to 32 x 16 x 16
 _BWD_LAZY = os.environ.get('IDF_BWD_LAZY', '0') != '0'
 
 
@@ -1000,7 +1000,7 @@ class _BlockEntryCat(torch.autograd.Function):
         if st1 is not None and st2 is not None and conv_gn_ok(x1, x2, 9, w.shape[0]):
             # GroupNorm + SiLU applied while the conv stages the two sources; statistics from their producers
             # (the 1x1 shortcut over the same raw input rides in the launch: IDF_SC_FUSE)
-            ride = _SC_FUSE and H * W <= _SC_FUSE_MAXHW and w.shape[0] > 32 and sw.shape[0] % 8 == 0
+            ride = _SC_FUSE and B * H * W <= _SC_FUSE_MAXPIX and w.shape[0] > 32 and sw.shape[0] % 8 == 0
             out = conv_gn_raw(x1, x2, st1, st2, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], w_fwd, b, None,
                               w.shape[0], 9, keep_a=need[2], keep_coef=any(need[i] for i in (0, 1, 4, 5)), want_stats=True,
                               shortcut=(cfg_sc['shadows'](x1.dtype, train)[0], sb, sw.shape[0]) if ride else None)
@@ -1047,7 +1047,7 @@ class _BlockEntryCat(torch.autograd.Function):
         dsW, dsb = got
         w_sc_dgrad = cfg_sc['shadows'](x1.dtype, True)[1]
         w_dgrad = cfg['shadows'](x1.dtype, True)[1]
-        ride = (ctx.chain_ok and _SC_FUSE and H * W <= _SC_FUSE_MAXHW and lazy_in is None and
+        ride = (ctx.chain_ok and _SC_FUSE and B * H * W <= _SC_FUSE_MAXPIX and lazy_in is None and
                 ds.shape[1] % 32 == 0)                      # shortcut dgrad in the chain launch
         dxs = None if ride else conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
         if ctx.chain_ok:

@@ -867,7 +867,7 @@ extern "C" int idf_debug_dlds_stamps(void** dev_addr) {
 // other block's MFMA phase runs beside this VALU phase.
 // DUAL: the input is the never-materialised concatenation x | x2 -- a chunk's per-lane source addresses point into
 // the tensor the chunk lies in.
-template <int KS, bool PRO = false, bool DUAL = false>
+template <int KS, bool PRO = false, bool DUAL = false, bool DUE = false>
 __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   constexpr int TM = 4, BN = 64, NWM = 4, NT = 512, TN = 2;
   constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 256;
@@ -1037,7 +1037,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
 
   // epilogue through LDS (Cout % 8 == 0 is a launch condition)
   DLDS_STAMP(t4);
-  lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+  if constexpr (DUE) due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);   // backward chain: du + partials
+  else lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
   DLDS_STAMP(t5);
   DLDS_ADD(4, t4, t5);
   DLDS_FLUSH;
@@ -1582,6 +1583,20 @@ void launch_dlds(C3P& p, hipStream_t st) {
   p.aux_off = (int)lds;
   lds += aux_bytes(p, PRO, 8, 64);
   auto kern = conv_dlds_bf16<KS, PRO, DUAL>;
+  IDF_ENSURE_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
+}
+
+// the du-epilogue data-gradient conv in the direct-to-LDS form (two 512-thread blocks per CU: one block's epilogue
+// arithmetic runs beside the other's loads and MFMAs)
+void launch_dlds_due(C3P& p, hipStream_t st) {
+  const int npix_h = (p.R + 2) * (p.W + 2);
+  size_t lds = ((size_t)((npix_h + 15) / 16) * 16 + 9 * 64) * 64;
+  size_t olds = (size_t)256 * (64 + 4) * sizeof(float);
+  if (olds > lds) lds = olds;
+  p.aux_off = (int)lds;
+  lds += (size_t)8 * 64 * 8;                                            // wave partials
+  auto kern = conv_dlds_bf16<3, false, false, true>;
   IDF_ENSURE_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
 }
@@ -2175,6 +2190,14 @@ static int dgrad_chain_impl(const void* dy, const void* in_x, const float* in_pa
   }
   hipStream_t st = (hipStream_t)stream;
   const int bwd = (in_x ? 1 : 0) | (x ? 2 : 0);
+  // IDF_CHAIN_DLDS: launches of at least this many blocks take the direct-to-LDS form (0 = never)
+  static const long chain_dlds = getenv("IDF_CHAIN_DLDS") ? atol(getenv("IDF_CHAIN_DLDS")) : 0;
+  if (chain_dlds > 0 && bwd == 2 && taps == 9 && BM == 256 && !sc_dy && (long)B * p.tiles_per_img * p.n_tiles >= chain_dlds &&
+      ((p.R + 2) * (p.W + 2) + 15) / 16 + 36 <= 72) {
+    launch_dlds_due(p, st);
+    IDF_CHECK_LAUNCH();
+    return IDF_OK;
+  }
 #define IDF_CHAIN(KS)                                                                                     \
   do {                                                                                                    \
     if (BM == 256) { if (bwd == 3) launch_bwd_chain<4, 4, KS, 3>(p, st); else if (bwd == 2) launch_bwd_chain<4, 4, KS, 2>(p, st); else launch_bwd_chain<4, 4, KS, 1>(p, st); } \

@@ -180,6 +180,13 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
 #ifndef IDF_HALO_PRO_G
 #define IDF_HALO_PRO_G 8
 #endif
+#ifndef IDF_RES_PF
+#define IDF_RES_PF 0          // plain epilogue: residual vectors issued under the last chunk's MFMA phase -- built, measured, OFF:
+                              // +25 registers in the plain kernels, 9.88 vs 9.83 ms per step (the du epilogue's x prefetch below pays: -0.05 ms)
+#endif
+#ifndef IDF_DUE_PF
+#define IDF_DUE_PF 1          // du epilogue: x vectors issued under the last chunk's MFMA phase
+#endif
 #ifndef IDF_SMALL_PFD
 #define IDF_SMALL_PFD 1        // chunks in flight in the 64-pixel-tile launches: 2 was built and measured -- 128->128 @8x8 8.5 -> 8.9 us,
                                // DDIM-100 at B = 256 297 -> 287 img/s (registers: 143 -> 214): the per-chunk 1.2 us is not load latency
@@ -206,9 +213,26 @@ __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8],
 // whole 16-byte chunks, consecutive lanes covering one pixel's contiguous couts: full-line HBM writes, coalesced
 // bias / residual reads.  With p.st_out the per-cout (sum, sum of squares) of the block's bf16-rounded outputs are
 // stored too: the GroupNorm that reads y needs no pass of its own over it.
+// the residual vectors of this thread's outputs (same (pixel, 8-cout) slots as lds_epilogue's loop): issued by the caller
+// under its last MFMA phase
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void res_fetch(const C3P& p, uint4 (&rr)[(BM * (BN / 8) + NT - 1) / NT], int b, int oy0, int n0, int KT,
+                                          int tid) {
+  constexpr int CPR = BN / 8, NI = (BM * CPR + NT - 1) / NT;
+  const int ncols = min(BN, p.Cout - n0);
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int idx = tid + k * NT, pl = idx / CPR, cc = (idx - pl * CPR) * 8;
+    rr[k] = make_uint4(0, 0, 0, 0);
+    if (idx < BM * CPR && pl < KT && cc < ncols)
+      rr[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)(b * p.H + oy0) * p.W + pl) * p.Cout + n0 + cc);
+  }
+}
+
 template <int TM, int TN, int BM, int BN, int NT>
 __device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,
-                                             int n0, int KT, int tid, int wm0, int wn0) {
+                                             int n0, int KT, int tid, int wm0, int wn0,
+                                             const uint4 (&rpre)[(BM * (BN / 8) + NT - 1) / NT], bool have_rpre) {   // res_fetch's registers
   const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int W = p.W, R = p.R;
   const int ncols = min(BN, p.Cout - n0);          // valid couts of this tile
@@ -228,7 +252,10 @@ __device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[
   float ssum[8], ssq[8];                           // statistics of this thread's 8 couts (cc is fixed per thread)
 #pragma unroll
   for (int k = 0; k < 8; ++k) ssum[k] = ssq[k] = 0.f;
-  for (int idx = tid; idx < BM * CPR; idx += NT) {
+#pragma unroll
+  for (int kk = 0; kk < (BM * CPR + NT - 1) / NT; ++kk) {
+    const int idx = tid + kk * NT;
+    if (idx >= BM * CPR) break;
     int pl = idx / CPR, cc = (idx - pl * CPR) * 8;
     if (pl >= KT || cc >= ncols) continue;
     float o[8];
@@ -243,7 +270,11 @@ __device__ __forceinline__ void lds_epilogue(const C3P& p, const f32x4_t (&acc)[
     }
     if (p.res) {
       float r[8];
-      Vec16<bf16_t>::load(p.res + e, r);
+      if (have_rpre) {
+        const uint32_t w4[4] = {rpre[kk].x, rpre[kk].y, rpre[kk].z, rpre[kk].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[2 * i] = __uint_as_float(w4[i] << 16); r[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+      } else Vec16<bf16_t>::load(p.res + e, r);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += r[k];
     }
@@ -460,29 +491,35 @@ __device__ __forceinline__ void gnb_epilogue(const C3P& p, const f32x4_t (&acc)[
 // in place of dA, together with the per-channel partial sums the GroupNorm backward needs (sum du, sum du * x) -- the
 // backward mirror of lds_epilogue's statistics.  x is fetched at the top (its latency hides behind the accumulators' trip
 // through LDS); the sums are of the bf16-rounded du, i.e. of what the consumer of du will read.
-template <int TM, int TN, int BM, int BN, int NT>
-__device__ __forceinline__ void due_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,
-                                             int n0, int KT, int tid, int wm0, int wn0) {
-  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int W = p.W, R = p.R, C = p.Cout;
-  constexpr int PF = BN + 4, CPR = BN / 8, NI = BM * CPR / NT;
-  static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "a thread keeps one channel slot");
-  float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]
-  const int cc = (tid % CPR) * 8;                  // this thread's 8 channels of the tile
-  // the GroupNorm's input: x [.., C1] | x2 [.., C - C1] (C1 % BN == 0: a cout tile lies in one of them)
+// this thread's vectors of the GroupNorm input x for the du epilogue (x [.., C1] | x2 [.., C - C1], C1 % BN == 0: a cout
+// tile lies in one of them): issued by the caller while its last MFMA phase still runs, consumed by due_epilogue
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void due_fetch_x(const C3P& p, uint4 (&xr)[BM * (BN / 8) / NT], int b, int oy0, int n0, int KT, int tid) {
+  constexpr int CPR = BN / 8, NI = BM * CPR / NT;
+  const int C = p.Cout, cc = (tid % CPR) * 8;
   const bf16_t* xs = p.due_x;
   int xpitch = C, xc = n0 + cc;
   if (p.due_x2) {
     if (n0 < p.due_C1) xpitch = p.due_C1;
     else { xs = p.due_x2; xpitch = C - p.due_C1; xc -= p.due_C1; }
   }
-  uint4 xr[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int pl = (tid + k * NT) / CPR;
     xr[k] = make_uint4(0, 0, 0, 0);
-    if (pl < KT) xr[k] = *reinterpret_cast<const uint4*>(xs + ((size_t)(b * p.H + oy0) * W + pl) * xpitch + xc);
+    if (pl < KT) xr[k] = *reinterpret_cast<const uint4*>(xs + ((size_t)(b * p.H + oy0) * p.W + pl) * xpitch + xc);
   }
+}
+
+template <int TM, int TN, int BM, int BN, int NT>
+__device__ __forceinline__ void due_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,
+                                             int n0, int KT, int tid, int wm0, int wn0, const uint4 (&xr)[BM * (BN / 8) / NT]) {
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int W = p.W, R = p.R, C = p.Cout;
+  constexpr int PF = BN + 4, CPR = BN / 8, NI = BM * CPR / NT;
+  static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "a thread keeps one channel slot");
+  float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]
+  const int cc = (tid % CPR) * 8;                  // this thread's 8 channels of the tile
   float scv[8], shv[8];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -757,10 +794,22 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
   if constexpr (GNB) gnb_prefetch<BM, BN, NT>(p, b, n0, KT, tid, gpre);
   if (PRO && !aux) pro_coefficients<NT>(p, b, oy0 == 0 && n0 == 0, cof, cof + 2 * p.Cin, tid);
   if constexpr (DYP) gn_bwd_fold<NT>(p.dyp_f, b, oy0 == 0 && n0 == 0, cof, cof + 4 * p.Cin, tid);
+  uint4 due_xr[DUE ? BM * (BN / 8) / NT : 1];
+  constexpr bool RES_PF = IDF_RES_PF && !DUE && !GNB && MODE == 0 && BN == 64;   // residual vectors fetched under the last MFMA phase
+  uint4 res_rr[RES_PF ? (BM * (BN / 8) + NT - 1) / NT : 1];
+  const bool res_pf = RES_PF && p.res != nullptr && (p.Cout & 7) == 0;
   auto step = [&](int ck, Stage& S) {
     store_chunk(ck, S);
     __syncthreads();
     if (ck + PFD < nchunks) load_chunk(ck + PFD, S);     // the stage's registers are free again: next chunk of this slot
+    if constexpr (DUE) {
+      // the du epilogue's x vectors fly during the last chunk's MFMAs (IDF_DUE_PF; issued earlier they sit in front of
+      // every chunk's vmcnt wait)
+      if (IDF_DUE_PF && ck == nchunks - 1 && !aux) due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, KT, tid);
+    }
+    if constexpr (RES_PF) {
+      if (res_pf && ck == nchunks - 1) res_fetch<BM, BN, NT>(p, res_rr, b, oy0, n0, KT, tid);
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       if (AUX_OK && aux && tap != TAPS / 2) continue;       // (block-uniform)
@@ -787,7 +836,8 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
   }
   if constexpr (DUE) {
     if (!aux) {
-      due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+      if (!IDF_DUE_PF) due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, KT, tid);
+      due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, due_xr);
       return;
     }
   }
@@ -802,7 +852,11 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
     return;
   }
   if ((p.Cout & 7) == 0) {
-    lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+    if constexpr (RES_PF) lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, res_rr, res_pf);
+    else {
+      uint4 none[(BM * (BN / 8) + NT - 1) / NT];
+      lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, none, false);
+    }
     return;
   }
   // ragged cout counts (epsilon / latent heads): direct per-lane stores
@@ -1037,8 +1091,15 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
 
   // epilogue through LDS (Cout % 8 == 0 is a launch condition)
   DLDS_STAMP(t4);
-  if constexpr (DUE) due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);   // backward chain: du + partials
-  else lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0);
+  if constexpr (DUE) {      // backward chain: du + partials
+    uint4 due_xr[BM * (BN / 8) / NT];
+    due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, KT, tid);
+    due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, due_xr);
+  }
+  else {
+    uint4 none[(BM * (BN / 8) + NT - 1) / NT];
+    lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, none, false);
+  }
   DLDS_STAMP(t5);
   DLDS_ADD(4, t4, t5);
   DLDS_FLUSH;

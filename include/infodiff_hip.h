@@ -145,6 +145,13 @@ int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_
                               const float* sc, const float* sh, const uint64_t* seed, uint32_t salt, float p_drop,
                               int act, void* out, float* part_out, int B, int H, int W, int Cin, int Cout, int taps,
                               void* stream);
+/* The fold of idf_conv_gn_bf16 as a launch of its own: mean / rstd [B][32] and (sc, sh) [B][C] of a GroupNorm stage
+ * (modules.py:264-268, 283-288) from the statistics partials its input carries (st1 [B][T1][C1][2], st2 for the second
+ * source of a skip pair).  With idf_gn_apply this is the streaming form of the GroupNorm pass for big tensors whose
+ * convolution stays a launch of its own (idf_conv_gn_advice = 0).  ws: [B][2C] floats of scratch. */
+int idf_gn_coef_from_stats(const float* st1, int T1, const float* st2, int T2, int C1, const float* gamma, const float* beta,
+                           const float* film_t, const float* film_a, int ld_t, int ld_a, float eps, float* mean, float* rstd,
+                           float* sc, float* sh, float* ws, int B, int HW, int C, void* stream);
 /* ResBlock shortcuts riding in their neighbours' launches (round 3).  A block whose channel count changes computes
  * `self.shortcut(x)` (a 1x1 conv, modules.py:228, 248, 281) beside `self.block1(x)`: idf_conv_gn_sc_bf16 is idf_conv_gn_bf16
  * (3x3, Cout > 32) whose launch carries extra blocks computing  sc_y [B,H,W,sc_Cout] = conv1x1(x | x2, sc_w [sc_Cout][Cin]) +

@@ -26,6 +26,7 @@ SIGNATURES = {
     'idf_conv_tiles': ([_i] * 8, C.c_int),
     'idf_conv_gn_advice': ([_i] * 6, C.c_int),
     'idf_conv_gn_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _u32, _f] + [_p] * 11 + [_i] * 6 + [_p], C.c_int),
+    'idf_gn_coef_from_stats': ([_p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p], C.c_int),
     'idf_conv_gn_sc_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _u32, _f] + [_p] * 11 + [_i] * 6 + [_p] +
                             [_p, _p, _p, _i], C.c_int),
     'idf_conv_dgrad_chain_sc_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i, _p, _p] + [_i] * 5 + [_p] + [_p, _p, _p, _i],

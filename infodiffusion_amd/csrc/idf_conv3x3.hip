@@ -2126,6 +2126,31 @@ static int conv_gn_impl(const void* x, const void* x2, int C1, const float* st1,
   return IDF_OK;
 }
 
+// mean / rstd / (sc, sh) of a GroupNorm stage from the statistics partials its input carries (the fold idf_conv_gn_bf16 does
+// in-block, as a launch of its own: grid B).  For the sites where the policy keeps GroupNorm and conv apart on big tensors
+// (idf_conv_gn_advice = 0): coefficients from the producer's partials + the streaming idf_gn_apply instead of the one-launch
+// GroupNorm, which re-reads nothing but runs its statistics -> apply phases serially per CU.  ws: [B][2C] floats scratch.
+extern "C" int idf_gn_coef_from_stats(const float* st1, int T1, const float* st2, int T2, int C1, const float* gamma,
+                                      const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a, float eps,
+                                      float* mean, float* rstd, float* sc, float* sh, float* ws, int B, int HW, int C,
+                                      void* stream) {
+  if (!st1 || T1 < 1 || !mean || !rstd || !sc || !sh || !ws || C <= 0 || (C % 32) || HW <= 0)
+    IDF_FAIL(IDF_ERR_BADARG, "gn_coef_from_stats: bad arguments (C %d HW %d T1 %d)", C, HW, T1);
+  if (!st2) { C1 = C; T2 = 0; }
+  if (st2 && (C1 <= 0 || C1 >= C || T2 < 1)) IDF_FAIL(IDF_ERR_BADARG, "gn_coef_from_stats: C1 %d of %d", C1, C);
+  if (B == 0) return IDF_OK;
+  C3P p;
+  clear_pro(p);
+  p.B = B; p.H = HW; p.W = 1; p.Cin = C; p.C1 = C1;
+  p.st1 = st1; p.T1 = T1; p.st2 = st2; p.T2 = T2;
+  p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * C; p.ld_a = ld_a ? ld_a : 2 * C; p.eps = eps;
+  p.mean_out = mean; p.rstd_out = rstd; p.sc_out = sc; p.sh_out = sh;
+  hipLaunchKernelGGL(pro_coef_kernel, dim3(B), dim3(256), (size_t)C * 16, (hipStream_t)stream, p, ws);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
 extern "C" int idf_conv_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
                                 const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
                                 int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt, float p_drop,

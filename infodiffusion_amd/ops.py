@@ -290,6 +290,22 @@ def gn_coef_fwd_raw(x, gamma, beta, film_t, film_a):
     return mean, rstd, sc, sh
 
 
+def gn_coef_from_stats_raw(st, C, HW, gamma, beta, film_t, film_a):
+    """(mean, rstd, sc, sh) of a GroupNorm stage from the statistics partials st [B][T][C][2] its input carries."""
+    B, dev = st.shape[0], st.device
+    mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    sc = torch.empty((B, C), dtype=torch.float32, device=dev)
+    sh = torch.empty((B, C), dtype=torch.float32, device=dev)
+    ws = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+    call('idf_gn_coef_from_stats', _p(st), st.shape[1], None, 0, C, _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
+         _ld(film_a), GN_EPS, _p(mean), _p(rstd), _p(sc), _p(sh), _p(ws), B, HW, C, _st())
+    return mean, rstd, sc, sh
+
+
+_GN_STREAM_MINPIX = int(os.environ.get('IDF_GN_STREAM_MINPIX', str(1 << 18)))     # B * H * W from which the unfused GroupNorm streams
+
+
 def _gn_acc(acc):
     """acc = (gamma slot, beta slot) of the gradient arena -> their views when both are free."""
     if acc is None or acc[0] is None or acc[1] is None or not (acc[0].available() and acc[1].available()):
@@ -785,7 +801,14 @@ class _FusedConv(torch.autograd.Function):
                 x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias, residual,
                 Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats)
         else:
-            if act and gn_small_ok(x):
+            ast = getattr(x, '_gn', None)
+            if (act and ast is not None and x.dtype == torch.bfloat16 and x.shape[1] % 32 == 0 and ast.shape[0] == x.shape[0]
+                    and ast.shape[2] == x.shape[1] and x.shape[0] * x.shape[2] * x.shape[3] >= _GN_STREAM_MINPIX):
+                # big tensor whose conv stays a launch of its own: coefficients from the producer's partials + the
+                # streaming apply (5.4 TB/s) instead of the one-launch GroupNorm (serial phases per CU, 3.8 TB/s)
+                mean, rstd, sc, sh = gn_coef_from_stats_raw(ast, x.shape[1], x.shape[2] * x.shape[3], gn_w, gn_b, film_t, film_a)
+                a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
+            elif act and gn_small_ok(x):
                 a, mean, rstd, sc, sh = gn_fused_fwd_raw(x, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act)
             elif act:
                 mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)

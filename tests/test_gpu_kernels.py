@@ -816,3 +816,30 @@ def test_shortcut_rides_in_the_first_convs_launches(case):
     xr = xc.float().clone().requires_grad_(True)
     F.conv2d(xr, wsc, bsc).backward(ds.float())
     assert rel(dxs, xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize('B,C,H,film', [(3, 128, 32, True), (2, 64, 64, False), (5, 256, 8, True)])
+def test_groupnorm_coefficients_from_producer_statistics(B, C, H, film):
+    """idf_gn_coef_from_stats (+ idf_gn_apply): the streaming form of the GroupNorm pass for big tensors whose conv stays a
+    launch of its own -- coefficients folded from the partials a producing conv left behind -- against fp32 PyTorch and the
+    one-launch GroupNorm."""
+    Cp = 64
+    xin = rnd(1, B, Cp, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    wp = (rnd(2, C, Cp, 3, 3) / (Cp * 9) ** 0.5).to(DEV)
+    wpf, _ = ops.pack_weight(wp, torch.bfloat16, True, False)
+    x, st = ops.conv_raw(xin, wpf, None, None, None, None, None, 0, 0.0, ops.S1, 9, 0, C, want_stats=True)
+    gam, bet = (1 + 0.1 * rnd(3, C)).to(DEV), (0.1 * rnd(4, C)).to(DEV)
+    ft = (0.2 * rnd(5, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    mean, rstd, sc, sh = ops.gn_coef_from_stats_raw(st, C, H * H, gam, bet, ft, fa)
+    a = ops.gn_apply_raw(x, sc, sh, None, 0, 0.0, 2)
+    u = F.group_norm(x.float(), 32, gam, bet, eps=1e-5)
+    if film:
+        u = u * (1 + ft[:, :C, None, None]) + ft[:, C:, None, None]
+        u = u * (1 + fa[:, :C, None, None]) + fa[:, C:, None, None]
+    assert rel(a, F.silu(u)) < 1e-2
+    mu = x.float().reshape(B, 32, -1).mean(dim=2)
+    var = x.float().reshape(B, 32, -1).var(dim=2, unbiased=False)
+    assert rel(mean, mu) < 1e-5 and rel(rstd, (var + 1e-5).rsqrt()) < 1e-5
+    a0, m0, r0, sc0, sh0 = ops.gn_fused_fwd_raw(x, gam, bet, ft, fa, None, 0, 0.0, 2)
+    assert rel(sc, sc0) < 1e-5 and rel(sh, sh0) < 1e-5

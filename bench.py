@@ -482,7 +482,8 @@ def main():
                    'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                    'parallelism': 'dp%d' % world, 'hipgraph': used_graph,
                    'exchange': None if sync is None else ('in graph, backbone slice overlapped with the encoder backward'
-                                                          if (used_graph and sync_in_graph) else 'eager after backward'),
+                                                          if (used_graph and sync_in_graph) else
+                                                          'all-reduce of the gradient arena + optimizer after each replayed forward + backward'),
                    'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW',
                    'last_grad_norm': None if gnorm is None else round(gnorm, 4)},
     }

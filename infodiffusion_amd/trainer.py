@@ -3,12 +3,13 @@
 
 Eagerly a CelebA step issues ~550 kernel launches from Python and is host-bound (~30 ms); replayed from a
 graph it runs at the GPU's pace (~10 ms).  The step is captured after two eager warm-up steps (they build
-the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) the
-all-reduces (RCCL on a side stream, event-joined) and the optimizer are captured too: the whole data-parallel
-step is one graph.  Should that capture fail on ANY rank, every rank drops it together and captures forward +
-backward only at its next step (exchange and optimizer then run eagerly after each replay, and the overlap of
-the backbone's slice with the encoder's backward pass is switched off: a collective forked inside a capture
-must be joined inside it).  A batch whose shape differs from the captured one (the last, short batch of an
+the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) forward +
+backward are captured and the all-reduce + optimizer run eagerly after each replay (the overlap of the
+backbone's slice with the encoder's backward pass is then off: a collective forked inside a capture must be
+joined inside it).  IDF_DP_INGRAPH=1 captures the all-reduces (RCCL on a side stream, event-joined) and the
+optimizer too -- the whole data-parallel step as one graph; it works but the process aborts intermittently
+while such a capture is open on this stack, so it is opt-in.  Should a capture fail on ANY rank, every rank
+drops it together and retries with less in the graph at its next step.  A batch whose shape differs from the captured one (the last, short batch of an
 epoch) runs eagerly, after which the step is captured afresh (the eager pass re-homes gradients the graph's
 kernels write).  Objectives whose draws are made on the host every step (--prior 10mix / roll: numpy samplers,
 models.py:654-657) are never captured; the KL capacity of --use_C lives in a device scalar refreshed per call,
@@ -30,7 +31,14 @@ class GraphedTrainStep:
         host_prior = getattr(args, 'prior', 'regular') != 'regular' and getattr(args, 'mmd_weight', 0) != 0
         if host_prior:
             self.use_graph = False
-        self.sync_in_graph = sync is not None      # RCCL collectives on a side stream are capturable on this stack
+        # The gradient exchange stays OUTSIDE the captured step by default: forward + backward replay from the graph, the
+        # all-reduce and the optimizer follow eagerly (five launches).  Capturing RCCL collectives works on this stack but the
+        # process aborts intermittently while such a capture is open (3 of 8 runs of the one-rank test, 1 of 8 with every
+        # collective issued from the main thread; none in 8 with the exchange outside) -- IDF_DP_INGRAPH=1 opts in.
+        import os
+        self.sync_in_graph = sync is not None and os.environ.get('IDF_DP_INGRAPH', '0') == '1'
+        if sync is not None and not self.sync_in_graph and self.use_graph:
+            sync.early_enabled = False             # a collective forked inside a capture must be joined inside it
         if sync is not None and hasattr(model, 'attach_grad_sync'):
             model.attach_grad_sync(sync)
 

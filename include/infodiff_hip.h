@@ -316,6 +316,11 @@ int idf_attn_fused_ok(int N, int D, int dtype);
 int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int D, float scale, int dtype, void* stream);
 int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int N, int D,
                  float scale, int dtype, void* stream);
+/* The same backward as ONE launch (round 3): given the forward's output o [B, N, D], the key-value half forms the row sums
+ * sum_j P dP as dO . o (the same number up to the bf16 rounding of o), so the two halves depend on nothing of each other
+ * and share a grid (query blocks | key-value blocks: 2 x 128 workgroups at B = 32). */
+int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse, const void* o, void* dqkv, int B, int N, int D,
+                   float scale, int dtype, void* stream);
 
 /* ---- elementwise / reductions */
 /* Input pipeline on the device (reference data.py:149-171, ToTensor -> RandomHorizontalFlip -> Normalize):

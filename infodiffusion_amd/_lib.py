@@ -64,6 +64,7 @@ SIGNATURES = {
     'idf_attn_fused_ok': ([_i, _i, _i], C.c_int),
     'idf_attn_fwd': ([_p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
     'idf_attn_bwd': ([_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
+    'idf_attn_bwd_o': ([_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
     'idf_prep_u8': ([_p, _p, _p, _i, _i, _i, _i, _p], C.c_int),
     'idf_qsample': ([_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p], C.c_int),
     'idf_gather_rows': ([_p, _p, _p, _i, _i, _p], C.c_int),

@@ -185,9 +185,9 @@ __global__ __launch_bounds__(ANT) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // ------------------------------------------------- backward A: dQ and the row sums  sum_j P dP
 template <int D, int AN>
-__global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
-                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dsum, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void attn_bwd_q_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                bf16_t* __restrict__ dqkv, float* __restrict__ dsum, float scale,
+                                                unsigned char* smem) {
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Vs = Ks + AN * ACfg<D>::PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,15 +230,25 @@ __global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restric
   f32x4_t out[ACfg<D>::CT];
   outprod<D, AN>(out, Ks, pk, lane);
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D, 3 * D, out, lane, scale);
-  if (lane < 16) dsum[(size_t)b * AN + r0 + lane] = dot;
+  if (dsum && lane < 16) dsum[(size_t)b * AN + r0 + lane] = dot;
+}
+
+template <int D, int AN>
+__global__ __launch_bounds__(ANT) void attn_bwd_q_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dsum, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn_bwd_q_body<D, AN>(qkv, dO, dqkv, dsum, scale, smem);
 }
 
 // ------------------------------------------------- backward B: dK and dV (rows = keys)
+// o != null: the row sums D_i = sum_j P_ij dP_ij are formed here as dO_i . O_i (O = P V, so the two are the same number up
+// to the bf16 rounding of O) instead of being read from the query launch -- the two halves of the backward then depend on
+// nothing of each other and run as ONE launch (attn_bwd_kernel)
 template <int D, int AN>
-__global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
-                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                          bf16_t* __restrict__ dqkv, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void attn_bwd_kv_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                 const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                 const bf16_t* __restrict__ o, bf16_t* __restrict__ dqkv, float scale,
+                                                 unsigned char* smem) {
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Gs = Qs + AN * ACfg<D>::PITCH;
   float* Ls = reinterpret_cast<float*>(Gs + AN * ACfg<D>::PITCH);   // [256] row logsumexp
@@ -250,7 +260,21 @@ __global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restri
   stage_rows<D, AN>(dO + (size_t)b * AN * D, D, Gs, tid);
   if (tid < AN) {
     Ls[tid] = lse[(size_t)b * AN + tid];
-    Ds[tid] = dsum[(size_t)b * AN + tid];
+    if (o) {
+      const uint4* orow = reinterpret_cast<const uint4*>(o + ((size_t)b * AN + tid) * D);
+      const uint4* grow = reinterpret_cast<const uint4*>(dO + ((size_t)b * AN + tid) * D);
+      float acc = 0.f;
+#pragma unroll 4
+      for (int v = 0; v < D / 8; ++v) {
+        const uint4 a = orow[v], g = grow[v];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc += __uint_as_float(aw[i] << 16) * __uint_as_float(gw[i] << 16) +
+                 __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(gw[i] & 0xffff0000u);
+      }
+      Ds[tid] = acc;
+    } else Ds[tid] = dsum[(size_t)b * AN + tid];
   }
   bf16x8_t kf[ACfg<D>::KS], vf[ACfg<D>::KS];
   load_rowfrag<D>(base + (size_t)r0 * 3 * D + D, 3 * D, lane, kf);
@@ -278,6 +302,24 @@ __global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restri
   store_out<D>(dqkv + ((size_t)b * AN + r0) * 3 * D + D, 3 * D, out, lane, scale);
 }
 
+template <int D, int AN>
+__global__ __launch_bounds__(ANT) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                          bf16_t* __restrict__ dqkv, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn_bwd_kv_body<D, AN>(qkv, dO, lse, dsum, nullptr, dqkv, scale, smem);
+}
+
+// both halves in one launch (grid.z = 2: query blocks | key-value blocks): at B = 32 each half is 128 workgroups on 256 CUs
+template <int D, int AN>
+__global__ __launch_bounds__(ANT) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                       const float* __restrict__ lse, const bf16_t* __restrict__ o,
+                                                       bf16_t* __restrict__ dqkv, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.z == 0) attn_bwd_q_body<D, AN>(qkv, dO, dqkv, nullptr, scale, smem);
+  else attn_bwd_kv_body<D, AN>(qkv, dO, lse, nullptr, o, dqkv, scale, smem);
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: raised once per (kernel set, device), not per
 // launch; a failure is reported to the caller (the launch would otherwise run without the LDS opt-in).
 template <int D, int AN>
@@ -291,6 +333,7 @@ hipError_t raise_lds_once() {
   e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_q_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<D, AN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess && dev < 32) done.fetch_or(1u << dev, std::memory_order_relaxed);
   return e;
 }
@@ -307,11 +350,16 @@ hipError_t launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, 
 }
 
 template <int D, int AN>
-hipError_t launch_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, float scale,
-                      hipStream_t st) {
+hipError_t launch_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, const void* o, void* dqkv, int B,
+                      float scale, hipStream_t st) {
   if (hipError_t e = raise_lds_once<D, AN>(); e != hipSuccess) return e;
   const dim3 g(AN / 64, B);
   const size_t lds = ACfg<D, AN>::LDS;
+  if (o) {
+    hipLaunchKernelGGL((attn_bwd_kernel<D, AN>), dim3(AN / 64, B, 2), dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       lse, (const bf16_t*)o, (bf16_t*)dqkv, scale);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((attn_bwd_q_kernel<D, AN>), g, dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
                      (bf16_t*)dqkv, dsum, scale);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;       // a failure here is the q launch's, not the kv launch's
@@ -338,14 +386,27 @@ extern "C" int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, 
   return IDF_OK;
 }
 
-extern "C" int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int N,
-                            int D, float scale, int dtype, void* stream) {
+static int attn_bwd_impl(const void* qkv, const void* dO, const float* lse, float* dsum, const void* o, void* dqkv, int B, int N,
+                         int D, float scale, int dtype, void* stream) {
   if (!idf_attn_fused_ok(N, D, dtype)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_bwd: N=%d D=%d dtype=%d not covered", N, D, dtype);
+  if (!o && !dsum) IDF_FAIL(IDF_ERR_BADARG, "attn_bwd: the row-sum scratch is missing");
   if (B == 0) return IDF_OK;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (N == 256) e = D == 128 ? launch_bwd<128, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st) : launch_bwd<64, 256>(qkv, dO, lse, dsum, dqkv, B, scale, st);
-  else e = D == 128 ? launch_bwd<128, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st) : launch_bwd<64, 64>(qkv, dO, lse, dsum, dqkv, B, scale, st);
+  if (N == 256) e = D == 128 ? launch_bwd<128, 256>(qkv, dO, lse, dsum, o, dqkv, B, scale, st) : launch_bwd<64, 256>(qkv, dO, lse, dsum, o, dqkv, B, scale, st);
+  else e = D == 128 ? launch_bwd<128, 64>(qkv, dO, lse, dsum, o, dqkv, B, scale, st) : launch_bwd<64, 64>(qkv, dO, lse, dsum, o, dqkv, B, scale, st);
   if (e != hipSuccess) IDF_FAIL((int)e, "attn_bwd: %s (query / key-value launch)", hipGetErrorString(e));
   return IDF_OK;
+}
+
+extern "C" int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum, void* dqkv, int B, int N,
+                            int D, float scale, int dtype, void* stream) {
+  return attn_bwd_impl(qkv, dO, lse, dsum, nullptr, dqkv, B, N, D, scale, dtype, stream);
+}
+
+// the backward as ONE launch: with the forward's output o [B, N, D] the key-value half forms the row sums itself
+extern "C" int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse, const void* o, void* dqkv, int B, int N,
+                              int D, float scale, int dtype, void* stream) {
+  if (!o) IDF_FAIL(IDF_ERR_BADARG, "attn_bwd_o: the forward output is missing");
+  return attn_bwd_impl(qkv, dO, lse, nullptr, o, dqkv, B, N, D, scale, dtype, stream);
 }

@@ -1128,6 +1128,9 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
 
 
 # ------------------------------------------------------------------ attention
+_ATTN_BWD_ONE = os.environ.get('IDF_ATTN_BWD_ONE', '1') != '0'      # query and key-value halves of the backward in one launch
+
+
 class _Attention(torch.autograd.Function):
     """qkv [B, 3C, H, W] (NHWC-dense: [B, N, 3C]) -> softmax(q k^T C^-1/2) v as [B, C, H, W]."""
 
@@ -1142,7 +1145,7 @@ class _Attention(torch.autograd.Function):
             o = empty_nhwc(B, C, H, W, dt, dev)
             lse = torch.empty((B, N), dtype=torch.float32, device=dev)
             call('idf_attn_fwd', _p(qkv), _p(o), _p(lse), B, N, C, float(int(C) ** (-0.5)), _dt(qkv), _st())
-            ctx.save_for_backward(qkv, lse)
+            ctx.save_for_backward(qkv, lse, o)          # o: lets the backward run as one launch (idf_attn_bwd_o)
             return o
         S = torch.empty((B, N, N), dtype=dt, device=dev)
         bgemm_raw(qkv, 0, qkv, C, S, 0, None, B, N * C3, N * C3, N * N, C3, C3, N, N, N, C, 0, 0,
@@ -1155,15 +1158,18 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
-        qkv, P = ctx.saved_tensors
+        qkv, P = ctx.saved_tensors[:2]
         B, C3, H, W = qkv.shape
         C, N = C3 // 3, H * W
         do = _nhwc(do.to(qkv.dtype))
         scale = float(int(C) ** (-0.5))
         dqkv = torch.empty_like(qkv, memory_format=CL)
-        if ctx.fused:
-            dsum = torch.empty_like(P)       # P is the saved row logsumexp here
-            call('idf_attn_bwd', _p(qkv), _p(do), _p(P), _p(dsum), _p(dqkv), B, N, C, scale, _dt(qkv), _st())
+        if ctx.fused:                        # P is the saved row logsumexp here
+            if _ATTN_BWD_ONE:
+                call('idf_attn_bwd_o', _p(qkv), _p(do), _p(P), _p(ctx.saved_tensors[2]), _p(dqkv), B, N, C, scale, _dt(qkv), _st())
+            else:
+                dsum = torch.empty_like(P)
+                call('idf_attn_bwd', _p(qkv), _p(do), _p(P), _p(dsum), _p(dqkv), B, N, C, scale, _dt(qkv), _st())
             return dqkv
         # dV = P^T dO
         bgemm_raw(P, 0, do, 0, dqkv, 2 * C, None, B, N * N, N * C, N * C3, N, C, C3, N, C, N, 1, 1)

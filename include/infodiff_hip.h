@@ -244,6 +244,10 @@ int idf_gn_partials(const void* x, float* part, int B, int HW, int C, int dtype,
  * SiLU + Dropout of modules.py:264-288, 312-319 as one read + one write */
 int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed, uint32_t salt,
                  float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
+/* idf_gn_apply over the never-materialised concatenation x [.., C1] | x2 [.., C - C1] of a skip pair (models.py:321);
+ * out is dense over all C channels. */
+int idf_gn_apply2(const void* x, const void* x2, int C1, void* out, const float* sc, const float* sh, const uint64_t* seed,
+                  uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream);
 /* Backward through act(GN/FiLM(x)) given dA (gradient w.r.t. the activated tensor):
  * dx (+ dres), dfilm_t/dfilm_a [B,2C], dgb [B][2][C] (per-sample dgamma, dbeta;
  * sum over B with idf_colsum) when non-NULL, and/or atomic accumulation of the batch sums

@@ -48,6 +48,7 @@ SIGNATURES = {
     'idf_gn_fused_fwd': ([_p, _p, _i] + [_p] * 5 + [_i, _i, _f] + [_p] * 5 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_fused_bwd': ([_p, _p, _p, _i, _p, _p, _p, _p] + [_p] * 4 + [_i, _i] + [_p] * 10 + [_u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_apply': ([_p, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
+    'idf_gn_apply2': ([_p, _p, _i, _p, _p, _p, _p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_conv_wgrad_bf16': ([_p, _p, _p, _p] + [_i] * 10 + [_p], C.c_int),
     'idf_wgrad_desc_bytes': ([], C.c_int),
     'idf_wgrad_desc_fill': ([_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 11 + [_p, _p], C.c_int),

@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const T* __restrict__ dA, co
 }
 
 // elementwise: a = dropout(SiLU(x*sc + sh))  (act 2)  or  x*sc + sh  (act 1); same geometry
+// x2 != null: the input is the channel concatenation x [.., C1] | x2 [.., C - C1] (a skip pair read in place, C1 % VE == 0);
+// `out` is dense over all C channels
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ out,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
+                                                       T* __restrict__ out,
                                                        const float* __restrict__ sc, const float* __restrict__ sh,
                                                        int HW, int C, int chunk, int act, const uint64_t* seed,
                                                        uint32_t salt, uint32_t thr, float dscale) {
@@ -330,6 +333,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const int vpp = C / VE, lanes = 256 / vpp, tid = threadIdx.x;
   const int b = blockIdx.y, v = tid % vpp, pl = tid / vpp;
   if (pl >= lanes) return;
+  const T* src = x;
+  int spitch = C, sc0 = v * VE;                    // this thread's vector inside its source tensor
+  if (x2) {
+    if (v * VE < C1) spitch = C1;
+    else { src = x2; spitch = C - C1; sc0 = v * VE - C1; }
+  }
   float scv[VE], shv[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   for (int p = blockIdx.x * chunk + pl; p < pend; p += lanes) {
     size_t e0 = ((size_t)b * HW + p) * C + v * VE;
     float xv[VE];
-    Vec16<T>::load(x + e0, xv);
+    Vec16<T>::load(src + ((size_t)b * HW + p) * spitch + sc0, xv);
     const uint32_t h = (act == 2 && seed) ? idf_vec_hash(*seed, salt, e0 >> 3) : 0u;
     const int l0 = (int)(e0 & 7);
     idf_act_vec<VE>(xv, scv, shv, act, seed != nullptr, h, l0, thr, dscale);
@@ -933,11 +942,13 @@ extern "C" int idf_gn_coef_bwd(const void* dA, const void* x, const void* dres, 
 }
 
 // a = act(x*sc+sh): the GroupNorm-apply + FiLM + SiLU + dropout pass (one read, one write)
-extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed,
-                            uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
+static int gn_apply_impl(const void* x, const void* x2, int C1, void* out, const float* sc, const float* sh, const uint64_t* seed,
+                         uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
   if (B == 0) return IDF_OK;
   int VE = dtype == IDF_F32 ? 4 : 8;
   if (C % VE) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_apply: C=%d unsupported", C);
+  if (x2 && (C1 <= 0 || C1 >= C || (C1 % VE))) IDF_FAIL(IDF_ERR_UNSUPPORTED, "gn_apply: C1=%d of %d unsupported", C1, C);
+  if (!x2) C1 = C;
   if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "gn_apply: act must be 1 or 2");
   hipStream_t st = (hipStream_t)stream;
   uint32_t thr = idf_drop_thresh(p_drop);
@@ -947,13 +958,26 @@ extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const flo
   int achunk = pick_chunk_ew(B, HW);
   dim3 ga(idf_cdiv(HW, achunk), B);
   if (dtype == IDF_F32)
-    hipLaunchKernelGGL(gn_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)x, (float*)out, sc, sh, HW, C,
+    hipLaunchKernelGGL(gn_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)x, (const float*)x2, C1, (float*)out, sc, sh, HW, C,
                        achunk, act, sd, salt, thr, dscale);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, sc, sh, HW, C,
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)out, sc, sh, HW, C,
                        achunk, act, sd, salt, thr, dscale);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
+}
+
+extern "C" int idf_gn_apply(const void* x, void* out, const float* sc, const float* sh, const uint64_t* seed,
+                            uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype, void* stream) {
+  return gn_apply_impl(x, nullptr, 0, out, sc, sh, seed, salt, p_drop, act, B, HW, C, dtype, stream);
+}
+
+// the same pass over the never-materialised concatenation x [.., C1] | x2 [.., C - C1] of a skip pair (models.py:321)
+extern "C" int idf_gn_apply2(const void* x, const void* x2, int C1, void* out, const float* sc, const float* sh,
+                             const uint64_t* seed, uint32_t salt, float p_drop, int act, int B, int HW, int C, int dtype,
+                             void* stream) {
+  if (!x2) IDF_FAIL(IDF_ERR_BADARG, "gn_apply2: second source missing");
+  return gn_apply_impl(x, x2, C1, out, sc, sh, seed, salt, p_drop, act, B, HW, C, dtype, stream);
 }
 
 // 1 when idf_gn_fused_fwd / idf_gn_fused_bwd cover this shape (the host picks the path with it).

@@ -290,17 +290,28 @@ def gn_coef_fwd_raw(x, gamma, beta, film_t, film_a):
     return mean, rstd, sc, sh
 
 
-def gn_coef_from_stats_raw(st, C, HW, gamma, beta, film_t, film_a):
-    """(mean, rstd, sc, sh) of a GroupNorm stage from the statistics partials st [B][T][C][2] its input carries."""
+def gn_coef_from_stats_raw(st, C, HW, gamma, beta, film_t, film_a, st2=None):
+    """(mean, rstd, sc, sh) of a GroupNorm stage from the statistics partials st [B][T][C][2] its input carries (st2: the
+    partials of the second source of a skip pair; st then covers the first st.shape[2] of the C channels)."""
     B, dev = st.shape[0], st.device
     mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
     sc = torch.empty((B, C), dtype=torch.float32, device=dev)
     sh = torch.empty((B, C), dtype=torch.float32, device=dev)
     ws = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
-    call('idf_gn_coef_from_stats', _p(st), st.shape[1], None, 0, C, _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
-         _ld(film_a), GN_EPS, _p(mean), _p(rstd), _p(sc), _p(sh), _p(ws), B, HW, C, _st())
+    call('idf_gn_coef_from_stats', _p(st), st.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
+         st.shape[2] if st2 is not None else C, _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS,
+         _p(mean), _p(rstd), _p(sc), _p(sh), _p(ws), B, HW, C, _st())
     return mean, rstd, sc, sh
+
+
+def gn_apply2_raw(x, x2, sc, sh, seed, salt, p_drop, act):
+    """a = act((x | x2) * sc + sh), dense over all channels: the streaming pass over a skip pair read in place."""
+    B, C1, H, W = x.shape
+    C = C1 + x2.shape[1]
+    a = empty_nhwc(B, C, H, W, x.dtype, x.device)
+    call('idf_gn_apply2', _p(x), _p(x2), C1, _p(a), _p(sc), _p(sh), _p(seed), salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
+    return a
 
 
 _GN_STREAM_MINPIX = int(os.environ.get('IDF_GN_STREAM_MINPIX', str(1 << 18)))     # B * H * W from which the unfused GroupNorm streams
@@ -1030,7 +1041,15 @@ class _BlockEntryCat(torch.autograd.Function):
             h, a, mean, rstd, sc, sh, st = out[:7]
             s = out[7] if ride else None
         else:
-            a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
+            a1, a2 = getattr(x1, '_gn', None), getattr(x2, '_gn', None)
+            if (a1 is not None and a2 is not None and x1.dtype == torch.bfloat16 and C % 32 == 0 and C1 % 8 == 0
+                    and a1.shape[0] == B and a2.shape[0] == B and a1.shape[2] == C1 and a2.shape[2] == C - C1
+                    and B * H * W >= _GN_STREAM_MINPIX):
+                # big pair whose conv stays a launch of its own: coefficients from the producers' partials + streaming apply
+                mean, rstd, sc, sh = gn_coef_from_stats_raw(a1, C, H * W, gn_w, gn_b, None, None, st2=a2)
+                a = gn_apply2_raw(x1, x2, sc, sh, None, cfg['salt'], 0.0, cfg['act'])
+            else:
+                a, mean, rstd, sc, sh = gn_fused_fwd_raw(x1, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], x2=x2)
             h, st = conv_raw(a, w_fwd, b, None, None, None, None, 0, 0.0, S1, 9, 0, w.shape[0], want_stats=True)
             s = None
         if s is None:

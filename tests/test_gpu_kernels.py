@@ -843,3 +843,12 @@ def test_groupnorm_coefficients_from_producer_statistics(B, C, H, film):
     assert rel(mean, mu) < 1e-5 and rel(rstd, (var + 1e-5).rsqrt()) < 1e-5
     a0, m0, r0, sc0, sh0 = ops.gn_fused_fwd_raw(x, gam, bet, ft, fa, None, 0, 0.0, 2)
     assert rel(sc, sc0) < 1e-5 and rel(sh, sh0) < 1e-5
+    # a skip pair (x | x2) read in place: partials of both producers, idf_gn_apply2
+    x2, st2 = ops.conv_raw(xin, wpf, None, None, None, None, None, 0, 0.0, ops.S1, 9, 0, C, want_stats=True)
+    x2 = (x2.float() * 0.5 + 0.25).bfloat16().contiguous(memory_format=CL)
+    st2 = ops.gn_partials_raw(x2)
+    g2, b2 = torch.cat([gam, gam * 0.5]), torch.cat([bet, bet + 0.1])
+    m2, r2, sc2, sh2 = ops.gn_coef_from_stats_raw(st, 2 * C, H * H, g2, b2, None, None, st2=st2)
+    a2 = ops.gn_apply2_raw(x, x2, sc2, sh2, None, 0, 0.0, 2)
+    ref2 = F.silu(F.group_norm(torch.cat([x, x2], dim=1).float(), 32, g2, b2, eps=1e-5))
+    assert rel(a2, ref2) < 1e-2

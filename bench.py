@@ -58,8 +58,8 @@ def make_args(a):
 
 
 # the oracle's convs stop scaling (and oversubscribe) far below the box's 256 cores: measured on the MI355X host at B = 32,
-# s per train step -- 32 threads 4.6, 64 threads 4.4, 128 threads 5.9 (profiles/r03_cpu_baseline_threads.txt); IDF_CPU_THREADS
-# overrides for such a sweep
+# s per train step -- 32 threads 3.9-5.1, 64 threads 8.7-10, 128 threads 18-25 (profiles/r03_cpu_baseline_threads.txt; 8 and
+# 16 threads: profiles/r04_cpu_baseline_threads.txt, tools/cpu_threads_sweep.sh); IDF_CPU_THREADS overrides for such a sweep
 CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '32'))
 CPU_BATCH = 32        # the benchmarked batch, 1 warm-up + 3 timed steps; then 3 backbone evaluations
 
@@ -188,7 +188,7 @@ class LaunchRecorder:
             yb = B * H * W * Cout * 2
             bufs = [(0, B * Hs * Ws * Cin * 2), (4, yb)] + ([(3, yb)] if a[3] else [])
             return 'conv3x3', bufs, 2.0 * B * H * W * Cout * 9 * Cin / (4 if mode == 3 else 1)
-        if name == 'idf_conv_gn_bf16':
+        if name in ('idf_conv_gn_bf16', 'idf_conv_gn_sc_bf16'):
             C1 = a[2]
             B, H, W, Cin, Cout, taps = a[29:35]
             if taps != 9:
@@ -201,7 +201,11 @@ class LaunchRecorder:
                 bufs.append((20, px * Cout * 2))
             if a[22]:
                 bufs.append((22, px * Cin * 2))
-            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+            work = 2.0 * px * Cout * 9 * Cin
+            if name == 'idf_conv_gn_sc_bf16':       # the block's 1x1 shortcut rides in the launch: its output and its FLOPs
+                bufs.append((38, px * a[39] * 2))
+                work += 2.0 * px * a[39] * Cin
+            return 'conv3x3', bufs, work
         if name == 'idf_conv_dgrad_gn_bf16':      # small maps: data-gradient conv + GroupNorm backward in one launch
             B, H, W, Cin, Cout, taps = a[25:31]
             if taps != 9:
@@ -226,6 +230,15 @@ class LaunchRecorder:
                 if a[21]:
                     bufs.append((21, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_dgrad_chain_sc_bf16':  # ... with the block shortcut's data gradient riding in the launch
+            B, H, W, Cin, Cout = a[13:18]
+            sc_Cin = a[22]
+            px = B * H * W
+            C1 = a[4] if a[3] else Cout
+            bufs = [(0, px * Cin * 2), (11, px * Cout * 2), (2, px * C1 * 2), (19, px * sc_Cin * 2), (21, px * Cout * 2)]
+            if a[3]:
+                bufs.append((3, px * (Cout - C1) * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin + 2.0 * px * Cout * sc_Cin
         if name == 'idf_gn_bwd_apply':
             C1 = a[5]
             B, HW, C = a[24:27]
@@ -253,6 +266,11 @@ class LaunchRecorder:
             return 'attn', [(0, B * N * 3 * C * 2), (1, B * N * C * 2)], 4.0 * B * N * N * C
         return None
 
+    @staticmethod
+    def _stream_idx(name, args):
+        """Index of the stream argument (the last one, except where a rider's arguments follow it)."""
+        return {'idf_conv_gn_sc_bf16': 35, 'idf_conv_dgrad_chain_sc_bf16': 18}.get(name, len(args) - 1)
+
     def install(self):
         from infodiffusion_amd import ops
         self.ops = ops
@@ -263,8 +281,9 @@ class LaunchRecorder:
             sp = rec._spec(name, args)
             if sp is not None:
                 ptr = {i for i, _ in sp[1]}
+                si = rec._stream_idx(name, args)
                 key = (name,) + tuple((v is not None) if (i in ptr or isinstance(v, int) and v > (1 << 32)) else v
-                                      for i, v in enumerate(args[:-1]))
+                                      for i, v in enumerate(args) if i != si)
                 if key in rec.calls:
                     rec.calls[key][0] += 1
                 else:
@@ -281,6 +300,7 @@ class LaunchRecorder:
         side = torch.cuda.Stream()
         for key, (count, (name, args)) in self.calls.items():
             family, bufs, work = self._spec(name, args)
+            si = self._stream_idx(name, args)
             per_set = sum(n for _, n in bufs)
             K = max(4, min(16, -(-(320 << 20) // per_set)))
             sets = []
@@ -311,14 +331,14 @@ class LaunchRecorder:
                     t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
                     keep.append(t)
                     al[15], al[16], al[17] = t.data_ptr(), None, None
-                al[-1] = None
+                al[si] = None
                 sets.append((al, keep))
             reps = max(1, -(-reps_min // K))
 
             def run_all(stream_ptr):
                 for _ in range(reps):
                     for al, _k in sets:
-                        al[-1] = stream_ptr
+                        al[si] = stream_ptr
                         self.orig(name, *al)
             run_all(torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
@@ -422,16 +442,11 @@ def main():
     pool = [(torch.rand(a.batch, 3, 64, 64, generator=g) * 2 - 1).to(dev).contiguous(memory_format=torch.channels_last)
             for _ in range(8)]
 
-    def fwd_bwd():
-        loss = model.loss_fn(margs, pool[0])
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        return loss
-
     # the product's own training step (run.py's): loss_fn -> zero_grad -> backward -> [exchange] -> clip + AdamW, two
-    # eager steps, then the whole step captured once and replayed (trainer.GraphedTrainStep; with a gradient exchange
-    # the all-reduces and the optimizer are inside the graph, and a capture that fails on any rank takes every rank
-    # down the same fallback)
+    # eager steps, then the step captured once and replayed (trainer.GraphedTrainStep: ONE graph on one GPU; with a
+    # gradient exchange THREE graphs -- forward + backbone backward | encoder backward | clip + AdamW -- with the two
+    # all-reduces issued eagerly between them, the first overlapping the encoder's backward pass; a capture that fails
+    # on any rank takes every rank to eager steps together)
     from infodiffusion_amd.trainer import GraphedTrainStep
     pre = None if a.fused_opt else (lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
     trainer = GraphedTrainStep(model, margs, opt, sync=sync, use_graph=bool(a.graph), pre_step=pre)
@@ -443,7 +458,6 @@ def main():
         step(i)
     torch.cuda.synchronize()
     used_graph = trainer.graph is not None
-    sync_in_graph = trainer.sync_in_graph
 
     for i in range(a.warmup):
         step(i)
@@ -481,9 +495,10 @@ def main():
                                'train step, random-pixel batches, random-init weights' % a.a_dim,
                    'per_gpu_batch': a.batch, 'global_batch': a.batch * world,
                    'parallelism': 'dp%d' % world, 'hipgraph': used_graph,
-                   'exchange': None if sync is None else ('in graph, backbone slice overlapped with the encoder backward'
-                                                          if (used_graph and sync_in_graph) else
-                                                          'all-reduce of the gradient arena + optimizer after each replayed forward + backward'),
+                   'exchange': None if sync is None else (
+                       'three graphs (forward + backbone backward | encoder backward | clip + AdamW), all-reduce of the backbone '
+                       'slice of the gradient arena eagerly between the first two (overlapping the encoder backward), the rest before the third'
+                       if (used_graph and trainer.split) else 'all-reduce of the gradient arena between backward and the optimizer'),
                    'optimizer': 'fused clip+AdamW' if a.fused_opt else 'clip_grad_norm_ + torch AdamW',
                    'last_grad_norm': None if gnorm is None else round(gnorm, 4)},
     }
@@ -492,9 +507,7 @@ def main():
         # dominant kernel family: the 3x3 convs (forward incl. the GroupNorm-prologue form, and data gradients)
         rec = LaunchRecorder()
         rec.install()
-        if sync is not None:
-            sync.early_enabled = False      # rank 0 alone runs this pass: no collective may be issued from its hooks
-        fwd_bwd()       # every launch of a step; no exchange / optimizer: the other ranks are not in this block
+        trainer.forward_backward(pool[0])       # every launch of a step; no exchange / optimizer: the other ranks are not in this block
         rec.remove()
         torch.cuda.synchronize()
         fam = rec.measure(dev)

@@ -14,9 +14,9 @@
  *  - Activations are dense NHWC.  `dtype` selects the activation/weight storage
  *    type: IDF_F32 (0) or IDF_BF16 (1); accumulation, statistics, FiLM
  *    coefficients, losses and weight gradients are always fp32.
- *  - Return 0 on success, a hipError_t value on a launch failure, or
+ *  - Return 0 on success, IDF_ERR_HIP when a HIP runtime call or launch failed, or
  *    IDF_ERR_UNSUPPORTED / IDF_ERR_BADARG; idf_last_error() (thread-local) holds
- *    the message.  Never aborts, never throws.
+ *    the message (for IDF_ERR_HIP: the hipError string).  Never aborts, never throws.
  *  - Re-entrant and stateless: safe to call from PyTorch's autograd thread.
  */
 #ifndef INFODIFF_HIP_H
@@ -31,6 +31,7 @@ extern "C" {
 #define IDF_BF16 1
 #define IDF_ERR_UNSUPPORTED 1001
 #define IDF_ERR_BADARG 1002
+#define IDF_ERR_HIP 1003
 
 /* conv gather modes */
 #define IDF_CONV_S1 0  /* stride 1, pad taps/2                                  */
@@ -206,7 +207,12 @@ int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int
  * always accumulating: dW / db pre-zeroed), chaining blk0 = sum of the previous blocks_out, copies
  * the table to device memory and launches it.  target_blocks = grid budget per problem (<= 0: blocks
  * are sized by work -- IDF_WGRAD_TPB pixel tiles per block, at least IDF_WGRAD_MINB blocks per problem --
- * because every problem shares the chip with the others); lds_bytes = max of the entries' lds_out. */
+ * because every problem shares the chip with the others); lds_bytes = max of the entries' lds_out.
+ * Stride-1 3x3 problems run in a shared-tile form (three kernel rows on one staged tile) when their map fits it
+ * (idf_wgrad_kr3_ok); the host keeps those that do not in a class of their own: mode | IDF_WGRAD_ROWSPLIT in both
+ * calls selects the row-split kernel for that class. */
+#define IDF_WGRAD_ROWSPLIT 16
+int idf_wgrad_kr3_ok(int H, int W);
 int idf_wgrad_desc_bytes(void);
 int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy, float* dW,
                         float* db, int B, int H, int W, int Cin, int Cout, int Cin_w, int Cout_w, int taps, int mode,

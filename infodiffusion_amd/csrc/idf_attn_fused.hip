@@ -382,7 +382,7 @@ extern "C" int idf_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, 
   hipError_t e;
   if (N == 256) e = D == 128 ? launch_fwd<128, 256>(qkv, o, lse, B, scale, st) : launch_fwd<64, 256>(qkv, o, lse, B, scale, st);
   else e = D == 128 ? launch_fwd<128, 64>(qkv, o, lse, B, scale, st) : launch_fwd<64, 64>(qkv, o, lse, B, scale, st);
-  if (e != hipSuccess) IDF_FAIL((int)e, "attn_fwd: %s", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "attn_fwd: %s", hipGetErrorString(e));
   return IDF_OK;
 }
 
@@ -395,7 +395,7 @@ static int attn_bwd_impl(const void* qkv, const void* dO, const float* lse, floa
   hipError_t e;
   if (N == 256) e = D == 128 ? launch_bwd<128, 256>(qkv, dO, lse, dsum, o, dqkv, B, scale, st) : launch_bwd<64, 256>(qkv, dO, lse, dsum, o, dqkv, B, scale, st);
   else e = D == 128 ? launch_bwd<128, 64>(qkv, dO, lse, dsum, o, dqkv, B, scale, st) : launch_bwd<64, 64>(qkv, dO, lse, dsum, o, dqkv, B, scale, st);
-  if (e != hipSuccess) IDF_FAIL((int)e, "attn_bwd: %s (query / key-value launch)", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "attn_bwd: %s (query / key-value launch)", hipGetErrorString(e));
   return IDF_OK;
 }
 

@@ -8,6 +8,7 @@
 #define IDF_OK 0
 #define IDF_ERR_UNSUPPORTED 1001   // shape/dtype outside what the kernels cover
 #define IDF_ERR_BADARG 1002
+#define IDF_ERR_HIP 1003           // a HIP runtime call / launch failed (the hipError string is in idf_last_error())
 
 #define IDF_F32 0
 #define IDF_BF16 1
@@ -27,7 +28,7 @@ void idf_set_error(const char* fmt, ...);
     if (_e != hipSuccess) {                                       \
       idf_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \
                     hipGetErrorString(_e));                       \
-      return (int)_e;                                             \
+      return IDF_ERR_HIP;                                         \
     }                                                             \
   } while (0)
 

@@ -493,7 +493,7 @@ extern "C" int idf_conv2d_wgrad(const void* x, const void* dy, float* dW, const 
   p.mode = mode; p.taps = taps; p.act = act; p.M = B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = idf_zero_f32(dW, (size_t)Cout * taps * Cin, st);     // a kernel, not a memset node (idf_common.h)
-  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad: memset failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "wgrad: memset failed: %s", hipGetErrorString(e));
   if (p.M == 0) return IDF_OK;
   if (dtype == IDF_F32) return launch_wgrad<float, 3>(p, dW, st);
   if (dtype == IDF_BF16) return launch_wgrad<bf16_t, 9>(p, dW, st);

@@ -412,7 +412,21 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   return IDF_OK;
 }
 
+// the shared-tile form stages (R + 2)(W + 2) input pixels with 3 vectors and R * W dy pixels with 2 vectors per thread of a
+// 768-thread block, twice (two LDS tiles): shapes beyond that (W = 128) stay with the row-split kernel
+bool kr3_fits(int H, int W) {
+  int R = 128 / W;
+  if (R > H) R = H;
+  if (R < 1 || (H % R)) return false;
+  const size_t lds = ((size_t)(R + 2) * (W + 2) + (size_t)R * W) * PITCHB * 2;
+  return (R + 2) * (W + 2) * 8 <= 3 * 768 && R * W * 8 <= 2 * 768 && lds <= 160 * 1024;
+}
+
 }  // namespace
+
+// 1 when the batched stride-1 3x3 weight gradient of an H x W map runs in the shared-tile form (kr3); the host keeps problems
+// that do not fit in a class of their own (mode | IDF_WGRAD_ROWSPLIT in idf_wgrad_desc_fill / idf_conv_wgrad_bf16_batched)
+extern "C" int idf_wgrad_kr3_ok(int H, int W) { return (g_kr3 && H > 0 && W >= 4 && !(W & (W - 1)) && kr3_fits(H, W)) ? 1 : 0; }
 
 // taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
 // (3x3 only).  H, W are the OUTPUT (dy) dims.  Returns IDF_ERR_UNSUPPORTED (without touching
@@ -435,7 +449,7 @@ extern "C" int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, flo
     e = idf_zero_f32(dW, nW, st);
     if (e == hipSuccess && db) e = idf_zero_f32(db, (size_t)p.Nw, st);
   }
-  if (e != hipSuccess) IDF_FAIL((int)e, "wgrad_bf16: zero fill failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "wgrad_bf16: zero fill failed: %s", hipGetErrorString(e));
   if (B == 0) return IDF_OK;
   dim3 g(gx, gy);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16<1, 0>), g, dim3(256), lds, st, p);
@@ -464,7 +478,11 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 96;
   static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 64;
   static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
-  const bool kr3 = g_kr3 && taps == 9 && mode == 0;
+  const bool rowsplit = (mode & 16) != 0;         // IDF_WGRAD_ROWSPLIT: the caller keeps this problem out of the shared-tile class
+  mode &= 15;
+  const bool kr3 = g_kr3 && taps == 9 && mode == 0 && !rowsplit;
+  if (kr3 && !kr3_fits(H, W))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_desc_fill: H%d W%d does not fit the shared-tile form (class it with IDF_WGRAD_ROWSPLIT)", H, W);
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
                    a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : tpb), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3);
   if (rc != IDF_OK) return rc;
@@ -481,16 +499,18 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
 extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
                                            int mode, void* stream) {
   if (n <= 0 || total_blocks <= 0) return IDF_OK;
+  const bool rowsplit = (mode & 16) != 0;
+  mode &= 15;
   if (!dev_table || (taps != 9 && taps != 1) || mode < 0 || mode > 2 || (mode && taps != 9))
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16_batched: bad arguments (taps %d mode %d)", taps, mode);
   hipStream_t st = (hipStream_t)stream;
   const WgDesc* tab = (const WgDesc*)dev_table;
   dim3 g(total_blocks);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n);
-  else if (mode == 0 && g_kr3) {
+  else if (mode == 0 && g_kr3 && !rowsplit) {
     static IdfLdsGrant grant;
     if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_tr_bf16_batched_kr3, (size_t)lds_bytes, grant); e != hipSuccess)
-      IDF_FAIL((int)e, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
+      IDF_FAIL(IDF_ERR_HIP, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
     hipLaunchKernelGGL(conv_wgrad_tr_bf16_batched_kr3, g, dim3(768), lds_bytes, st, tab, n);
   }
   else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n);

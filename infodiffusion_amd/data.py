@@ -37,9 +37,15 @@ class _Batches:
             self.n = len(arr) // (self.bs * world)
         self.seed = getattr(args, 'r_seed', 0)
         self.epoch = 0
-        # the reference shuffles every loader but CelebA's, in every mode (data.py:184 vs 197-243)
-        self.shuffle = args.dataset != 'celeba'
-        self.augment = args.dataset in ('celeba', 'ffhq') and getattr(args, 'mode', 'train') == 'train'   # data.py:165-166
+        # which loaders the reference shuffles: cifar10, dsprites, chairs always (data.py:197, 213, 230); CelebA only in the
+        # three-loader modes (data.py:175-180; shuffle=False otherwise, :184); mnist / fmnist / ffhq never (data.py:130, 144:
+        # DataLoader's default; :243)
+        mode = getattr(args, 'mode', 'train')
+        self.shuffle = args.dataset in ('cifar10', 'dsprites', 'chairs') or (
+            args.dataset == 'celeba' and mode in ('attr_classification', 'eval_fid', 'reconstruction'))
+        # RandomHorizontalFlip is part of the CelebA / FFHQ transform in every mode (data.py:165-166 `do_augment` defaults
+        # to True and no caller clears it; :237)
+        self.augment = args.dataset in ('celeba', 'ffhq')
 
     def __len__(self):
         return self.n

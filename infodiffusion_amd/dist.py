@@ -17,11 +17,12 @@ weights, `encoder.fc_mu/fc_var` with kld_weight = 0, the frozen time table) are
 skipped.
 
 Overlap with backward (`attach`): the backbone's backward ends before the encoder's begins (the encoder ran first
-in the forward pass), so the arena is cut at the backbone / encoder boundary and the backbone slice is all-reduced on
-the side stream from a hook on the latent `a` -- the moment its gradient is complete -- while the encoder's backward
-pass still runs; the encoder slice and the few stand-alone gradients follow at the end of backward.  The collectives
-sit on a side stream and are capturable (RCCL all-reduce inside a hipGraph replays correctly on this stack), so the
-whole data-parallel step -- exchange and optimizer included -- is one graph.
+in the forward pass), so the arena is cut at the backbone / encoder boundary.  The trainer (trainer.GraphedTrainStep)
+cuts the backward pass at the latent `a` too: after the backbone's half it calls `reduce_early()` -- the backbone slice
+goes onto the exchange stream -- then runs the encoder's half beside it and calls `all_reduce_grads()` for the encoder
+slice and the few stand-alone gradients, which also joins the exchange stream.  The collectives are always issued
+eagerly (never inside a stream capture: RCCL inside an open capture aborts intermittently on this stack); the three
+compute phases around them replay from three hipGraphs.
 """
 import torch
 import torch.distributed as dist
@@ -50,7 +51,6 @@ class GradSync:
         self._plan = None       # [(flat buffer, [views shaped/strided like the grads], [grad indices])]
         self._cut = None        # arena offset (floats) where the early slice ends; None: no early slice
         self._early_done = False
-        self.early_enabled = True   # cleared by the trainer when the exchange stays outside a captured forward + backward
 
     # ---------------------------------------------------------------- overlap with backward
     def attach(self, early_module):
@@ -85,9 +85,8 @@ class GradSync:
     def reduce_early(self, after=None):
         """All-reduce the early slice of the arena on the side stream (everything enqueued so far on the current
         stream has produced it); the rest of backward keeps running on the current stream.  `all_reduce_grads` joins
-        the side stream again -- so this must not run inside a stream capture that ends before that call
-        (`early_enabled`)."""
-        if (self._cut is None or not self.early_enabled or self._early_done
+        the side stream again.  Never call it inside a stream capture."""
+        if (self._cut is None or self._early_done
                 or (self.world == 1 and not self.force)):
             return
         flat = self.arena.flat

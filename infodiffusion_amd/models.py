@@ -343,10 +343,19 @@ class InfoDiff(nn.Module):
         self.encoder.ctx.act_dtype = dtype
 
     def attach_grad_sync(self, sync):
-        """Data parallel: overlap the backbone's share of the gradient exchange with the encoder's backward pass
-        (dist.GradSync.attach).  Returns whether the overlap is active."""
+        """Data parallel: cut the gradient arena at the backbone | encoder boundary (dist.GradSync.attach) and, when the
+        arena layout allows it and the loss reaches the encoder through the latent only (kld_weight == 0), cut the
+        backward pass at the latent as well (`cut_latent`): the trainer then runs backbone backward, puts the backbone's
+        slice on the wire, and runs the encoder's backward pass beside it.  Returns whether the cut is active."""
         self._dp_sync = sync if (sync is not None and sync.attach(self.backbone)) else None
-        return self._dp_sync is not None
+        self.cut_latent = self._dp_sync is not None and self.kld_weight == 0
+        self._latent_cut = None
+        return self.cut_latent
+
+    def pop_latent_cut(self):
+        """(latent as the encoder produced it, the leaf that replaced it downstream) of the last forward pass, or None."""
+        cut, self._latent_cut = getattr(self, '_latent_cut', None), None
+        return cut
 
     def _draw_idx(self, n):
         return _draw_idx(self, n)
@@ -417,17 +426,13 @@ class InfoDiff(nn.Module):
         else:
             a_q = a
         lat = a_q if use_q else a
-        sync = getattr(self, '_dp_sync', None)
-        if sync is not None and torch.is_grad_enabled() and lat.requires_grad:
-            # data parallel: the gradient of the latent is complete exactly when the backbone's backward pass has
-            # ended -- launch the backbone's deferred weight gradients and put its slice of the gradient arena on
-            # the wire while the encoder's backward pass runs (dist.GradSync.attach)
-            def _early(grad, sync=sync):
-                ops.WgradBatch.flush_async()
-                sync.reduce_early(after=ops.WgradBatch.side_stream())
-                return None
-            lat = lat.view_as(lat)
-            lat.register_hook(_early)
+        if getattr(self, 'cut_latent', False) and torch.is_grad_enabled() and lat.requires_grad:
+            # data parallel (kld_weight == 0, so lat is a): the latent enters the backbone AND the loss (the MMD term
+            # reads the returned `a`) as a leaf; whoever runs the backward pass (trainer.GraphedTrainStep) continues
+            # from `leaf.grad` into the encoder once the backbone's share of the gradient exchange is on the wire
+            leaf = lat.detach().requires_grad_(True)
+            self._latent_cut = (lat, leaf)
+            lat = a = leaf
         output = self.backbone(x_tilde, idx, lat)
         return (output, epsilon, a, mu, log_var) if get_target else output
 

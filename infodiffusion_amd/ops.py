@@ -598,6 +598,11 @@ def _slot_views(w_slot, b_slot, want_bias, shape):
     return w_slot.take(), (b_slot.take() if want_bias else None)
 
 
+@functools.lru_cache(maxsize=None)
+def _kr3_ok(H, W):
+    return bool(_lib.load().idf_wgrad_kr3_ok(H, W))
+
+
 class WgradBatch:
     """Deferred weight gradients.  Only the optimizer reads them, so backward just queues each
     convolution's (a, dy, arena slots) and ONE launch per (taps, mode) class at the end of the
@@ -628,6 +633,20 @@ class WgradBatch:
             except RuntimeError:          # not inside a backward pass: nothing to defer to
                 cls.flush()
                 return
+
+    @classmethod
+    def reset(cls):
+        """Forget everything queued by a backward pass that did not end (the autograd engine skips its final callbacks
+        when a node raises, so `flush` never ran): stale (a, dy, slot address) items must not be launched by a later
+        step, and `_cb_queued` must not keep later passes from queueing their own end-of-backward flush.  Safe to call
+        whenever no backward pass is running (trainer: before every forward, and after a failed capture)."""
+        cls.pending = []
+        cls._cb_queued = False
+        if cls._inflight:
+            if cls._side is not None and cls._inflight[0][0].is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_stream(cls._side)     # their operands may be freed now
+            cls._inflight = []
+        _LAZY_PENDING.clear()
 
     @classmethod
     def side_stream(cls):
@@ -665,9 +684,12 @@ class WgradBatch:
         if not items:
             return
         groups = {}
-        for it in items:
-            groups.setdefault((it[9], it[10]), []).append(it)
         lib = _lib.load()
+        for it in items:
+            mode = it[10]
+            if it[9] == 9 and mode == S1 and not _kr3_ok(it[5], it[6]):
+                mode |= 16          # IDF_WGRAD_ROWSPLIT: a map the shared-tile kernel does not take (W = 128) is a class of its own
+            groups.setdefault((it[9], mode), []).append(it)
         nb = lib.idf_wgrad_desc_bytes()
         capturing = torch.cuda.is_current_stream_capturing()
         classes = list(groups.items())

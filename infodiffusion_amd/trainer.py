@@ -1,22 +1,36 @@
 """The training step of reference run.py:195-200 (loss_fn -> zero_grad -> backward -> [gradient exchange]
--> clip + AdamW) as a captured hipGraph.
+-> clip + AdamW) as captured hipGraphs.
 
-Eagerly a CelebA step issues ~550 kernel launches from Python and is host-bound (~30 ms); replayed from a
+Eagerly a CelebA step issues ~500 kernel launches from Python and is host-bound (~30 ms); replayed from a
 graph it runs at the GPU's pace (~10 ms).  The step is captured after two eager warm-up steps (they build
-the allocator pools, the weight shadows and the optimizer state).  With a gradient exchange (`sync`) forward +
-backward are captured and the all-reduce + optimizer run eagerly after each replay (the overlap of the
-backbone's slice with the encoder's backward pass is then off: a collective forked inside a capture must be
-joined inside it).  IDF_DP_INGRAPH=1 captures the all-reduces (RCCL on a side stream, event-joined) and the
-optimizer too -- the whole data-parallel step as one graph; it works but the process aborts intermittently
-while such a capture is open on this stack, so it is opt-in.  Should a capture fail on ANY rank, every rank
-drops it together and retries with less in the graph at its next step.  A batch whose shape differs from the captured one (the last, short batch of an
-epoch) runs eagerly, after which the step is captured afresh (the eager pass re-homes gradients the graph's
-kernels write).  Objectives whose draws are made on the host every step (--prior 10mix / roll: numpy samplers,
-models.py:654-657) are never captured; the KL capacity of --use_C lives in a device scalar refreshed per call,
-so its schedule needs no re-capture."""
+the allocator pools, the weight shadows and the optimizer state).
+
+One GPU (no `sync`): the whole step is ONE graph.
+
+Data parallel (`sync`): the step is THREE graphs cut where the design already has its seams, and the RCCL
+collectives run eagerly between them -- no collective is ever issued inside an open capture (that aborts
+intermittently on this stack), yet the backbone's share of the exchange overlaps the encoder's backward pass:
+
+    G1  forward + backward of the loss down to the latent (the backbone's backward pass and its deferred
+        weight gradients; `InfoDiff.cut_latent`: the latent enters the backbone and the loss as a leaf)
+        -> eager: all-reduce of the backbone slice of the gradient arena on the exchange stream
+    G2  backward of the encoder from the latent's gradient (+ its deferred weight gradients)
+        -> eager: all-reduce of the rest (encoder slice + the few stand-alone gradients), join
+    G3  clip + AdamW
+
+Every rank issues the same collective sequence by construction (two all-reduces + the packed buckets per step,
+eager or replayed alike).  Models without a latent cut (Diff, VAE, InfoDiff with a KL term) run their whole
+backward in G1 and G2 is empty.  Should a capture fail on ANY rank, every rank drops it together (`_agree`)
+and trains eagerly -- the same three phases, uncaptured.  A batch whose shape differs from the captured one (the
+last, short batch of an epoch) runs eagerly, after which the step is captured afresh (the eager pass re-homes
+gradients the graph's kernels write).  Objectives whose draws are made on the host every step (--prior 10mix /
+roll: numpy samplers, models.py:654-657) are never captured; the KL capacity of --use_C lives in a device scalar
+refreshed per call, so its schedule needs no re-capture."""
 import sys
 
 import torch
+
+from . import ops
 
 
 class GraphedTrainStep:
@@ -24,39 +38,62 @@ class GraphedTrainStep:
         self.model, self.args, self.opt, self.sync = model, args, opt, sync
         self.pre_step = pre_step      # e.g. clip_grad_norm_ in front of a stock optimizer (between exchange and step)
         self.use_graph, self.warmup = use_graph, warmup
-        self.graph = None
+        self.graph = None             # one graph (no exchange) or the tuple (G1, G2 or None, G3)
         self.xbuf = None
         self.loss = None          # device scalar of the last step
         self.seen = 0
         host_prior = getattr(args, 'prior', 'regular') != 'regular' and getattr(args, 'mmd_weight', 0) != 0
         if host_prior:
             self.use_graph = False
-        # The gradient exchange stays OUTSIDE the captured step by default: forward + backward replay from the graph, the
-        # all-reduce and the optimizer follow eagerly (five launches).  Capturing RCCL collectives works on this stack but the
-        # process aborts intermittently while such a capture is open (3 of 8 runs of the one-rank test, 1 of 8 with every
-        # collective issued from the main thread; none in 8 with the exchange outside) -- IDF_DP_INGRAPH=1 opts in.
-        import os
-        self.sync_in_graph = sync is not None and os.environ.get('IDF_DP_INGRAPH', '0') == '1'
-        if sync is not None and not self.sync_in_graph and self.use_graph:
-            sync.early_enabled = False             # a collective forked inside a capture must be joined inside it
+        # data parallel: cut the backward pass at the latent so the backbone's slice of the gradients can travel while
+        # the encoder's backward pass runs (models.InfoDiff.cut_latent; models without one keep a single backward pass)
+        self.split = False
         if sync is not None and hasattr(model, 'attach_grad_sync'):
-            model.attach_grad_sync(sync)
+            self.split = bool(model.attach_grad_sync(sync))
 
-    def _fwd_bwd(self, x, epoch):
+    # ------------------------------------------------------------------ the phases of one step
+    def _phase_a(self, x, epoch):
+        """forward + the backward pass down to the latent cut (the whole backward pass when there is no cut)."""
+        ops.WgradBatch.reset()          # nothing of an earlier, aborted backward pass may leak into this one
         if self.sync is not None:
             self.sync.begin_step()
         loss = self.model.loss_fn(args=self.args, x=x, curr_epoch=epoch)
+        cut = self.model.pop_latent_cut() if self.split else None
         self.opt.zero_grad()
         loss.backward()
-        return loss.detach()
+        return loss.detach(), cut
 
-    def _tail(self):
-        if self.sync is not None:
-            self.sync.all_reduce_grads()
+    @staticmethod
+    def _phase_b(cut):
+        """the encoder's backward pass from the gradient that arrived at the latent leaf."""
+        if cut is not None:
+            lat, leaf = cut
+            if leaf.grad is not None:
+                lat.backward(leaf.grad)
+                leaf.grad = None
+
+    def _opt_step(self):
         if self.pre_step is not None:
             self.pre_step()
         self.opt.step()
 
+    def forward_backward(self, x, epoch=0):
+        """One eager forward + complete backward pass WITHOUT exchange or optimizer (measurement passes)."""
+        loss, cut = self._phase_a(x, epoch)
+        self._phase_b(cut)
+        return loss
+
+    def _eager_step(self, x, epoch):
+        loss, cut = self._phase_a(x, epoch)
+        if self.sync is not None and cut is not None:
+            self.sync.reduce_early()
+        self._phase_b(cut)
+        if self.sync is not None:
+            self.sync.all_reduce_grads()
+        self._opt_step()
+        return loss
+
+    # ------------------------------------------------------------------ capture
     def _capture(self, x, epoch):
         self.xbuf = x.clone()
         self.loss = torch.zeros((), dtype=torch.float32, device=x.device)
@@ -64,19 +101,47 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         self._warm_done = False
         with torch.cuda.stream(side):               # one step on a side stream: private-pool warm-up
-            self.loss.copy_(self._fwd_bwd(self.xbuf, epoch))
-            self._tail()
+            self.loss.copy_(self._eager_step(self.xbuf, epoch))
         self._warm_done = True
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
+        g1 = torch.cuda.CUDAGraph()
+        if self.sync is None:
+            with torch.cuda.graph(g1, capture_error_mode='thread_local'):
+                loss, cut = self._phase_a(self.xbuf, epoch)
+                self.loss.copy_(loss)
+                self._phase_b(cut)
+                self._opt_step()
+            self.graph = g1
+            return
         # thread_local: RCCL's watchdog thread keeps querying events while this thread captures
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            self.loss.copy_(self._fwd_bwd(self.xbuf, epoch))
-            if self.sync is None or self.sync_in_graph:
-                self._tail()
-        self.graph = g
+        with torch.cuda.graph(g1, capture_error_mode='thread_local'):
+            loss, cut = self._phase_a(self.xbuf, epoch)
+            self.loss.copy_(loss)
+        g2 = None
+        if cut is not None:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode='thread_local'):
+                self._phase_b(cut)
+        del cut
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode='thread_local'):
+            self._opt_step()
+        self.graph = (g1, g2, g3)
+
+    def _replay(self):
+        if self.sync is None:
+            self.graph.replay()
+            return
+        g1, g2, g3 = self.graph
+        self.sync.begin_step()
+        g1.replay()
+        if g2 is not None:
+            self.sync.reduce_early()        # backbone slice: on the wire while the encoder's backward pass replays
+            g2.replay()
+        self.sync.all_reduce_grads()        # the rest; joins the exchange stream
+        g3.replay()
 
     def _try_capture(self, x, epoch):
         """-> (captured, stepped).  Never raises: under data parallelism every rank must come out of here and meet
@@ -89,10 +154,12 @@ class GraphedTrainStep:
             # trained on already
             stepped = bool(self.loss is not None and self.xbuf is not None and self.xbuf.shape == x.shape
                            and getattr(self, '_warm_done', False))
-            print('graph capture %sfailed (%s: %s)' % ('with the gradient exchange ' if self.sync is not None and
-                                                       self.sync_in_graph else '', type(e).__name__, str(e)[:200]),
-                  file=sys.stderr)
+            print('graph capture failed (%s: %s)' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
             self.graph = None
+            # a backward pass that raised ran no end-of-backward callbacks: drop what it queued
+            ops.WgradBatch.reset()
+            if hasattr(self.model, 'pop_latent_cut'):
+                self.model.pop_latent_cut()
             if self.sync is not None:
                 self.sync.begin_step()              # a half-issued exchange must not leak into the next step
             torch.cuda.synchronize()
@@ -100,8 +167,8 @@ class GraphedTrainStep:
 
     def _agree(self, ok, stepped):
         """Under data parallelism every rank must take the same path (a rank that replays and a rank that steps
-        eagerly issue different numbers of collectives): ONE collective settles (capture worked everywhere, this
-        batch's step ran everywhere, ... anywhere)."""
+        eagerly could otherwise drift apart): ONE collective settles (capture worked everywhere, this batch's step ran
+        everywhere, ... anywhere)."""
         if self.sync is None or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
             return ok, stepped, stepped
         dev = self.loss.device if self.loss is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
@@ -124,28 +191,18 @@ class GraphedTrainStep:
                                    'have diverged')
             if not ok:
                 self.graph = None
-                if self.sync is not None and self.sync_in_graph:
-                    # together, at the next step: forward + backward only in the graph, exchange + optimizer eagerly
-                    # after each replay, no collective forked inside the capture
-                    self.sync_in_graph = False
-                    self.sync.early_enabled = False
-                    print('retrying at the next step with forward + backward only in the graph', file=sys.stderr)
-                else:
-                    self.use_graph = False
-                    print('training eagerly', file=sys.stderr)
+                self.use_graph = False
+                print('training eagerly', file=sys.stderr)
             if stepped:
                 # the capture's warm-up pass WAS this batch's optimisation step (capturing itself executes nothing):
                 # replaying / stepping now would train on the batch a second time
                 return self.loss
         if self.graph is not None and x.shape == self.xbuf.shape:
             self.xbuf.copy_(x)
-            self.graph.replay()
-            if self.sync is not None and not self.sync_in_graph:
-                self._tail()
+            self._replay()
             return self.loss
         had_graph = self.graph is not None
-        loss = self._fwd_bwd(x, epoch)
-        self._tail()
+        loss = self._eager_step(x, epoch)
         if had_graph:
             # this eager step dropped the `.grad` tensors that live in the graph's private pool and installed its own
             # (gradients outside the arena), and re-keyed the optimizer's chunk table: the graph would now write

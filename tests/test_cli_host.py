@@ -75,8 +75,8 @@ def test_save_original_img_mode_runs_without_a_gpu(tmp_path):
     assert len(files) == 2
     img = np.load(files[0])
     assert img.shape == (4, 1, 32, 32)
-    # the reference's loaders shuffle in every mode (data.py:178-180, 197, 230): each saved image is one of the
-    # source images, every source image is saved exactly once
+    # whatever the order (the reference's fmnist loader does not shuffle, data.py:144; cifar10 / chairs / dsprites do):
+    # each saved image is one of the source images, every source image is saved exactly once
     allimgs = np.concatenate([np.load(f) for f in files])
     src = raw.transpose(0, 3, 1, 2) / 255.0
     match = [int(np.argmin([np.abs(im - s_).max() for s_ in src])) for im in allimgs]

@@ -115,56 +115,114 @@ def test_grad_allreduce_world2():
 
 def _trainer_worker(rank, world, port, q):
     """GraphedTrainStep's decisions under a capture that fails on ONE rank only (stubbed capture: there is no GPU
-    here): every rank must reach the agreement collective, then fall back together -- first to forward + backward only
-    in the graph (exchange outside, early overlap off), then, when that fails on the other rank, to eager steps."""
+    here): every rank must reach the agreement collective, then fall back together to eager steps.  The model has a
+    latent cut (an `encoder` whose output enters the `backbone` and the loss as a leaf), so every step -- eager or the
+    capture's warm-up pass -- issues the three-phase sequence: backbone backward, early slice, encoder backward, rest."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from infodiffusion_amd.dist import GradSync
+    from infodiffusion_amd.grad_arena import GradArena, slot_of
     from infodiffusion_amd.trainer import GraphedTrainStep
     torch.manual_seed(0)
-    net = torch.nn.Linear(4, 2)
 
     class Model(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.net = net
+            self.backbone = torch.nn.Linear(4, 2)
+            self.encoder = torch.nn.Linear(4, 4)
+            self.cut_latent = False
+            self._latent_cut = None
+            self.calls = []
+
+        def attach_grad_sync(self, sync):
+            self.cut_latent = bool(sync.attach(self.backbone))
+            return self.cut_latent
+
+        def pop_latent_cut(self):
+            cut, self._latent_cut = self._latent_cut, None
+            return cut
 
         def loss_fn(self, args, x, curr_epoch=0):
-            return self.net(x).square().mean()
+            lat = self.encoder(x)
+            if self.cut_latent:
+                leaf = lat.detach().requires_grad_(True)
+                self._latent_cut = (lat, leaf)
+                lat = leaf
+            return self.backbone(lat).square().mean() + 0.1 * lat.square().mean()
 
     model = Model()
-    opt = torch.optim.SGD(model.parameters(), lr=0.1)
-    # default: the exchange stays outside the captured step (RCCL inside an open capture aborts intermittently on the
-    # MI355X stack), so the early slice is off from the start
-    os.environ.pop('IDF_DP_INGRAPH', None)
-    s0 = GradSync(model, world)
-    t0 = GraphedTrainStep(model, None, opt, sync=s0, use_graph=True, warmup=1)
-    default_mode = (t0.sync_in_graph, s0.early_enabled)
-    os.environ['IDF_DP_INGRAPH'] = '1'              # the opt-in mode has the longer fallback ladder: exercise that one
-    sync = GradSync(model, world)
+    ref = Model()
+    ref.load_state_dict(model.state_dict())
+
+    class ArenaSGD(torch.optim.SGD):
+        """SGD whose gradients live in a GradArena (what FusedClipAdamW does on the GPU): the slice exchange needs one."""
+        def __init__(self, params, lr):
+            params = list(params)
+            super().__init__(params, lr=lr)
+            self.arena = GradArena(params)
+
+        def zero_grad(self, set_to_none=True):
+            self.arena.zero()
+            super().zero_grad(set_to_none=True)
+
+        def step(self):
+            for p in self.param_groups[0]['params']:      # re-home the gradients in their arena slots
+                if p.grad is not None and not self.arena.holds(p.grad):
+                    v = slot_of(p).take()
+                    v.copy_(p.grad)
+                    p.grad = v
+            super().step()
+
+    opt = ArenaSGD(list(model.backbone.parameters()) + list(model.encoder.parameters()), lr=0.1)
+    sync = GradSync(model, world, arena=opt.arena)
+    seq = []
+    orig_early, orig_all = sync.reduce_early, sync.all_reduce_grads
+
+    def rehome():
+        # before an exchange the gradients must sit in the arena for the slices to carry them (CPU autograd hands
+        # AccumulateGrad fresh tensors; on the GPU the kernels write the slots themselves)
+        for p in opt.param_groups[0]['params']:
+            if p.grad is not None and not opt.arena.holds(p.grad):
+                v = slot_of(p).take()
+                v.copy_(p.grad)
+                p.grad = v
+
+    def re(*a, **k):
+        rehome()
+        seq.append('early')
+        return orig_early(*a, **k)
+
+    def ar(*a, **k):
+        rehome()
+        seq.append('rest')
+        return orig_all(*a, **k)
+    sync.reduce_early, sync.all_reduce_grads = re, ar
     step = GraphedTrainStep(model, None, opt, sync=sync, use_graph=True, warmup=1)
+    split = step.split
     log = []
-    fails = {2: 0, 3: 1}       # call number -> the rank whose capture fails in that call
+    fails = {2: 0}             # call number -> the rank whose capture fails in that call
 
     def fake_try_capture(x, epoch):
         call = step.seen
         step.xbuf = x.clone()
-        step.loss = step._fwd_bwd(x, epoch)         # the warm-up pass: a full step, collectives included
-        step._tail()
+        step.loss = step._eager_step(x, epoch)      # the warm-up pass: a full step, collectives included
         ok = fails.get(call) != rank
         if ok:
             step.graph = 'captured'                  # never replayed below: the other rank's failure drops it
-        log.append(('capture', call, ok, step.sync_in_graph, sync.early_enabled))
+        log.append(('capture', call, ok))
         return ok, True
     step._try_capture = fake_try_capture
     torch.manual_seed(10 + rank)
-    xs = [torch.randn(3, 4) for _ in range(5)]
+    xs = [torch.randn(3, 4) for _ in range(4)]
     states = []
     for x in xs:
         step(x, 0)
-        states.append((step.graph is not None, step.use_graph, step.sync_in_graph, sync.early_enabled))
-    q.put((rank, {'log': log, 'states': states, 'w': net.weight.detach().tolist(), 'default_mode': default_mode}))
+        states.append((step.graph is not None, step.use_graph))
+    # reference: the same four steps with one backward pass per step and the mean of both ranks' gradients
+    q.put((rank, {'log': log, 'states': states, 'split': split, 'seq': seq,
+                  'w': [p.detach().tolist() for p in model.parameters()],
+                  'x': [x.tolist() for x in xs], 'w0': [p.detach().tolist() for p in ref.parameters()]}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -181,12 +239,30 @@ def test_capture_failure_on_one_rank_takes_every_rank_down_the_same_path():
         p.join(timeout=60)
         assert p.exitcode == 0                         # nobody hung in a mismatched collective
     a, b = got[0], got[1]
-    assert a['default_mode'] == (False, False) and b['default_mode'] == (False, False)
+    assert a['split'] and b['split']                   # the arena is cut backbone | encoder and the backward pass with it
     assert a['states'] == b['states']
-    # (IDF_DP_INGRAPH=1) call 1 eager; call 2: capture fails on rank 0 -> both drop it, exchange leaves the graph, early overlap off;
-    # call 3: capture (forward + backward only) fails on rank 1 -> both train eagerly from then on
-    assert a['states'] == [(False, True, True, True), (False, True, False, False), (False, False, False, False),
-                           (False, False, False, False), (False, False, False, False)]
-    assert [e[:3] for e in a['log']] == [('capture', 2, False), ('capture', 3, True)]
-    assert [e[:3] for e in b['log']] == [('capture', 2, True), ('capture', 3, False)]
-    assert torch.equal(torch.tensor(a['w']), torch.tensor(b['w']))      # replicas still identical after 5 steps
+    # call 1 eager; call 2: the capture fails on rank 0 -> both ranks drop it and train eagerly from then on
+    assert a['states'] == [(False, True), (False, False), (False, False), (False, False)]
+    assert a['log'] == [('capture', 2, False)] and b['log'] == [('capture', 2, True)]
+    # every step issued the same collective sequence on both ranks: early slice, then the rest
+    assert a['seq'] == b['seq'] == ['early', 'rest'] * 4
+    T = torch.tensor
+    for wa, wb in zip(a['w'], b['w']):
+        assert torch.equal(T(wa), T(wb))               # replicas still identical after 4 steps
+    # and the split backward + sliced exchange trained exactly like one backward pass on the averaged gradients
+    bb, enc = torch.nn.Linear(4, 2), torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        for p, w in zip(list(bb.parameters()) + list(enc.parameters()), a['w0']):
+            p.copy_(T(w))
+    params = list(bb.parameters()) + list(enc.parameters())
+    for xa, xb in zip(a['x'], b['x']):
+        grads = []
+        for x in (T(xa), T(xb)):
+            lat = enc(x)
+            loss = bb(lat).square().mean() + 0.1 * lat.square().mean()
+            grads.append(torch.autograd.grad(loss, params))
+        with torch.no_grad():
+            for p, g0, g1 in zip(params, *grads):
+                p -= 0.1 * (g0 + g1) / 2
+    for p, w in zip(params, a['w']):
+        assert torch.allclose(p.detach(), T(w), atol=1e-6)

@@ -488,7 +488,11 @@ def _oracle_step(cfg, sd, fix, masks=None):
 # per parameter, whatever the kernels.  A per-parameter bound of 5e-2 therefore cannot hold in bf16; what a defect looks like
 # is different in kind -- a missing or mis-scaled gamma / beta / FiLM gradient is off by 0.5 ... 1.0 (a LazyGrad that held
 # tensor references instead of addresses read exactly 1.0 here).  The bounds below sit between the two populations.
+# Round 4: the band is also bounded in its upper tail -- measured p90 0.10, p99 0.14-0.17: p90 <= 0.15 and at most 2 % of the
+# parameters above 0.20 (a systematically mis-scaled FAMILY of gradients, e.g. every FiLM gradient 30 % off, moves the tail
+# long before any single parameter reaches the 0.40 cap).
 GRAD_TOL_MAX, GRAD_TOL_L2, GRAD_TOL_MEDIAN = 0.40, 0.35, 0.10
+GRAD_TOL_P90, GRAD_TOL_TAIL, GRAD_TOL_TAIL_SHARE = 0.15, 0.20, 0.02
 
 
 def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD_TOL_L2, tol_median=GRAD_TOL_MEDIAN):
@@ -511,8 +515,14 @@ def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD
     assert worst[0][0] < tol_max, (what, worst[:8])
     byl2 = sorted(worst, key=lambda t: -t[1])
     assert byl2[0][1] < tol_l2, (what, byl2[:8])
-    med = sorted(w[0] for w in worst)[len(worst) // 2]
+    errs = sorted(w[0] for w in worst)
+    med = errs[len(errs) // 2]
     assert med < tol_median, (what, med)
+    if len(errs) >= 50:        # whole-model checks: the upper tail of the distribution, not only its cap
+        p90 = errs[int(0.9 * (len(errs) - 1))]
+        tail = sum(e > GRAD_TOL_TAIL for e in errs) / len(errs)
+        assert p90 <= GRAD_TOL_P90, (what, p90)
+        assert tail <= GRAD_TOL_TAIL_SHARE, (what, tail, worst[:8])
     return n, worst[:3]
 
 
@@ -639,6 +649,69 @@ def test_bf16_train_step_celeba_at_the_benchmarked_batch(train, lazy, monkeypatc
     n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)),
                               'B=32 train=%s' % train)
     assert n > 500
+
+
+def test_bf16_train_step_a_dim_256_at_the_per_gpu_batch():
+    """BASELINE configs[3] at its per-GPU size: CelebA 64x64, a_dim 256, bf16, B = 32 (one rank's share of the 32 x 8 DDP
+    batch; the exchange itself is covered by the RCCL / gloo tests): loss, gradient norm and EVERY parameter's gradient
+    against the CPU oracle on the same draws, through the benchmark's launch shapes (eval mode: no dropout)."""
+    from infodiffusion_amd.optim import FusedClipAdamW
+    cfg = O.dataset_cfg('celeba', a_dim=256, mmd_weight=0.1)
+    model, args, sd = make_infodiff(cfg, DEV, 'bf16', None)
+    model.eval()
+    B = 32
+    gen = torch.Generator(device='cpu')
+    gen.manual_seed(7)
+    fix = {'x': torch.rand(B, *cfg.shape, generator=gen) * 2 - 1, 'idx': torch.randint(0, 1000, (B,), generator=gen),
+           'eps': torch.randn(B, *cfg.shape, generator=gen), 'reparam': torch.zeros(B, 256),
+           'prior': torch.randn(B, 256, generator=gen)}
+    opt = FusedClipAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_norm=1.0)
+    with _ReplayedDraws(fix):
+        loss = model.loss_fn(args_of(cfg), fix['x'].to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    ref_loss, ref_grads, ref_gn = _oracle_step(cfg, sd, fix)
+    assert rel(loss, ref_loss) < 1e-2, (float(loss), float(ref_loss))
+    gn = float(opt.total_norm())
+    assert abs(gn - ref_gn) / ref_gn < 2e-2, (gn, ref_gn)
+    n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)), 'a_dim 256, B=32')
+    assert n > 500
+
+
+def test_cifar_two_phase_ddim_b64_first_images_match_small_batch():
+    """BASELINE configs[4] at its per-GPU size (512 images over 8 GPUs = 64 per rank, sharded with no collective): the
+    two-phase sampler at the CIFAR shape (InfoDiff a_dim 256 for the first phase, the vanilla [1,2,4,8] UNet for the second)
+    at B = 64 is finite, and its first 4 images equal a B = 4 run on the same draws (other tile shapes and kernels, the
+    same arithmetic per image); the shard ranges of 512 images over 8 ranks tile the batch."""
+    from infodiffusion_amd.dist import shard_range
+    from infodiffusion_amd.models import Diff, InfoDiff
+    from infodiffusion_amd.sampling import TwoPhaseDiffusionProcess
+    assert [shard_range(512, r, 8) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+    cfg = O.dataset_cfg('cifar10', a_dim=256, diffusion_steps=20, deterministic=True, model='diff', is_latent=False,
+                        mode='eval_fid', split_step=8)
+    torch.manual_seed(4)
+    m2 = Diff(args_of(cfg, act_dtype='bf16'), DEV, cfg.shape).eval()
+    m1 = InfoDiff(args_of(cfg, act_dtype='bf16'), DEV, cfg.shape).eval()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(13)
+    xT = torch.randn(64, *cfg.shape, generator=g).to(DEV)
+    a = torch.randn(64, cfg.a_dim, generator=g).to(DEV)
+    noise = [torch.randn(64, *cfg.shape, generator=g).to(DEV) for _ in range(3)]
+
+    def run(n):
+        proc = TwoPhaseDiffusionProcess(args_of(cfg), m1, m2, DEV, cfg.shape)
+        k = [0]
+
+        def nz(x):
+            k[0] += 1
+            return noise[k[0] % 3][:n].clone()
+        proc._randn_like = nz
+        with torch.no_grad():
+            return proc.sampling(n, xT=xT[:n].clone(), a=a[:n].clone())
+    big, small = run(64), run(4)
+    assert torch.isfinite(big).all()
+    assert rel(big[:4], small) < 2e-2, rel(big[:4], small)
 
 
 def test_sampling_b256_first_images_match_small_batch():
@@ -884,10 +957,10 @@ def test_graphed_train_step_replays_and_follows_lr_changes():
 @pytest.mark.parametrize('tag,dtype', [('fmnist', 'fp32'), ('celeba', 'bf16')])
 def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
     """The whole data-parallel step on the real model over RCCL with one rank: gradients averaged over a world of 1 are
-    unchanged, so loss and gradient norm must equal the run without an exchange -- with the backbone slice of the arena
-    all-reduced in place, forward + backward replayed from the hipGraph and exchange + optimizer following each replay
-    (IDF_DP_INGRAPH=1: the backbone slice from the hook on the latent while the encoder's backward pass runs, everything
-    inside the graph).  fp32 (fmnist): every step to 1e-3 / 1e-2.
+    unchanged, so loss and gradient norm must equal the run without an exchange -- with the backward pass cut at the latent,
+    the step replayed as THREE hipGraphs (forward + backbone backward | encoder backward | clip + AdamW), the backbone slice
+    of the arena all-reduced in place on the exchange stream between the first two (beside the encoder's backward pass) and
+    the rest before the third, every collective issued eagerly.  fp32 (fmnist): every step to 1e-3 / 1e-2.
     bf16 (the benchmarked CelebA model): the first two steps (one eager warm-up, one more) to 1e-3 on the loss and
     1e-2 / 3e-2 on the norm; after that two runs of the SAME configuration drift apart (fp32 atomic order in the weight
     gradients feeding bf16 training), so the later steps only have to keep training."""
@@ -921,7 +994,8 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
             return out, step
         ref, _ = run(False)
         got, st = run(True)
-        assert st.graph is not None and st.sync_in_graph == (os.environ.get('IDF_DP_INGRAPH', '0') == '1')
+        # three graphs, the middle one being the encoder's backward pass behind the latent cut
+        assert st.split and isinstance(st.graph, tuple) and len(st.graph) == 3 and st.graph[1] is not None
         tols = [(1e-3, 1e-2)] * 5 if dtype == 'fp32' else [(1e-3, 1e-2), (1e-3, 3e-2)]
         for k, (tl, tn) in enumerate(tols):
             (l0, n0), (l1, n1) = ref[k], got[k]

@@ -138,6 +138,41 @@ int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void* x, const v
  * With x == NULL the epilogue is the plain one (out = dA).  bf16; Cin % 32 == 0, Cout % 64 == 0, W a power of two in
  * [4, 128]; idf_conv_dgrad_chain_tiles() < 0: shape not covered. */
 int idf_conv_dgrad_chain_tiles(int B, int H, int W, int Cin, int Cout, int taps);
+
+/* ---- image-resident ResBlock forward for the 8x8 maps (round 4) ------------------------------------------------------
+ * A whole AuxResBlock / ResBlock (modules.py:261-328, 206-258: three GroupNorm -> SiLU -> [Dropout] -> Conv3x3 stages, FiLM on
+ * the second, + shortcut) or ResBlock_encoder (modules.py:331-366: two stages) in ONE launch, one 512-thread workgroup per
+ * image: at 8x8 a workgroup owns all 64 pixels of every channel, so each GroupNorm's statistics close inside it and the next
+ * stage's activated tensor is written straight into the LDS image its conv reads.  bf16, 128 couts, Cin 128 or 256 (possibly
+ * the pair x | x2 of an up-path block, C1 % 32 == 0).  Arithmetic per element is that of idf_conv_gn_bf16 stage by stage.
+ *   stage i:  a_i = dropout_i(SiLU(FiLM_i(GroupNorm_i(h_{i-1}))))   h_i = conv3x3(a_i, w_i) + bias_i     (h_{-1} = x | x2)
+ *   y = h_last + (w_sc ? round_bf16(conv1x1(x | x2, w_sc) + b_sc) : x)
+ * st1 / st2: statistics partials of x / x2 as their producers left them ([B][T][C][2], see idf_conv_tiles); st_out
+ * [B][1][128][2]: those of y.  Training outputs per stage (all optional, NULL in inference): a_out [B,8,8,Cin_i] the activated
+ * conv input (for the weight gradient), h_out [B,8,8,128] the stage's conv output (the next GroupNorm's input; the last
+ * stage's h_out must be y), mean / rstd [B,32] and sc / sh [B,Cin_i] of the stage's GroupNorm (for idf_conv_dgrad_gn_bf16).
+ * seed == NULL: no dropout; else stage i drops with probability p_drop where its `drop` is non-zero, keyed by (seed, salt_i,
+ * element index) exactly as idf_conv_gn_bf16 does.  idf_resblock_small_ok: 1 when the shape is covered (C1 = 0: one source). */
+typedef struct {
+  const void* w;            /* [128][9][Cin_i] forward shadow (idf_pack_conv_weight) */
+  const float* bias;        /* [128] */
+  const float* gamma; const float* beta;                 /* [Cin_i] or NULL */
+  const float* film_t; const float* film_a; int ld_t, ld_a;   /* [B][2*Cin_i] (row stride ld) or NULL */
+  uint32_t salt; int drop;
+  void* a_out; float* mean; float* rstd; float* sc; float* sh; void* h_out;
+} IdfResblockStage;
+typedef struct {
+  const void* x; const void* x2; int C1, Cin;
+  const float* st1; const float* st2; int T1, T2;
+  int nstage;               /* 2 or 3 */
+  IdfResblockStage s[3];
+  const void* w_sc; const float* b_sc;                    /* 1x1 shortcut [128][Cin] + bias, or NULL: identity (Cin == 128) */
+  void* y; float* st_out;
+  const uint64_t* seed; float p_drop; float eps;
+  int B;
+} IdfResblockArgs;
+int idf_resblock_small_ok(int B, int H, int W, int Cin, int C1, int Cout, int nstage);
+int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
 int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T, const float* in_mean,
                               const float* in_rstd, const float* in_sc, const float* in_gamma, const float* in_beta,
                               const float* in_film_t, const float* in_film_a, int in_ld_t, int in_ld_a,

@@ -17,6 +17,19 @@ ERR_UNSUPPORTED, ERR_BADARG = 1001, 1002
 
 _p, _i, _l, _f, _u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
+class ResblockStage(C.Structure):
+    """IdfResblockStage (include/infodiff_hip.h)."""
+    _fields_ = [('w', _p), ('bias', _p), ('gamma', _p), ('beta', _p), ('film_t', _p), ('film_a', _p), ('ld_t', _i), ('ld_a', _i),
+                ('salt', _u32), ('drop', _i), ('a_out', _p), ('mean', _p), ('rstd', _p), ('sc', _p), ('sh', _p), ('h_out', _p)]
+
+
+class ResblockArgs(C.Structure):
+    """IdfResblockArgs (include/infodiff_hip.h)."""
+    _fields_ = [('x', _p), ('x2', _p), ('C1', _i), ('Cin', _i), ('st1', _p), ('st2', _p), ('T1', _i), ('T2', _i),
+                ('nstage', _i), ('s', ResblockStage * 3), ('w_sc', _p), ('b_sc', _p), ('y', _p), ('st_out', _p),
+                ('seed', _p), ('p_drop', _f), ('eps', _f), ('B', _i)]
+
+
 SIGNATURES = {
     'idf_version': ([], C.c_int),
     'idf_last_error': ([], C.c_char_p),
@@ -32,6 +45,8 @@ SIGNATURES = {
     'idf_conv_dgrad_chain_sc_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i, _p, _p] + [_i] * 5 + [_p] + [_p, _p, _p, _i],
                                      C.c_int),
     'idf_conv_dgrad_gn_ok': ([_i] * 6, C.c_int),
+    'idf_resblock_small_ok': ([_i] * 7, C.c_int),
+    'idf_resblock_small_fwd': ([C.POINTER(ResblockArgs), _p], C.c_int),
     'idf_conv_dgrad_gn_bf16': ([_p] * 10 + [_i, _i] + [_p] * 10 + [_u32, _f] + [_i] * 7 + [_p], C.c_int),
     'idf_conv_dgrad_chain_tiles': ([_i] * 6, C.c_int),
     'idf_conv_dgrad_chain_bf16': ([_p, _p, _p, _i] + [_p] * 7 + [_i, _i] + [_p] * 5 + [_p] + [_p, _p, _p, _i] + [_p] * 3 +

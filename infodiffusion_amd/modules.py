@@ -338,6 +338,26 @@ class _ResBase(nn.Module):
         return ops.fused_conv(x, conv.weight, conv.bias, cfg, gn.weight, gn.bias, film_t, film_a, residual, seed,
                               passthrough, want_stats=True, x_single_use=single)
 
+    def _small(self, x, ft, fa, want_alias):
+        """The whole block as one launch where a workgroup can own an image (8x8 maps, ops.resblock_small): y [, alias of
+        x], or None when the fused kernel does not cover this call."""
+        x1, x2 = x if isinstance(x, tuple) else (x, None)
+        names = [n for n in ('block1', 'block2', 'block3') if hasattr(self, n)]
+        has_sc = isinstance(self.shortcut, nn.Conv2d)
+        out_ch = getattr(self, names[-1])[-1].weight.shape[0]
+        if (x2 is not None and not has_sc) or not ops.resblock_small_ok(x1, x2, out_ch, len(names)):
+            return None
+        if not has_sc and x1.shape[1] != out_ch:
+            return None
+        stages = []
+        for k, name in enumerate(names):
+            blk = getattr(self, name)
+            stages.append((blk[-1], blk[0], _cfg(getattr(self, '_sh_' + name), ops.S1, 9, _ACT_SILU, self.p_drop, self.salt + k)))
+        seed = self.ctx.seed if self.training else None
+        film_stage = 1 if (ft is not None or fa is not None) else -1
+        return ops.resblock_small(x1, x2, stages, (self.shortcut, self._cfg_sc) if has_sc else None, ft, fa, film_stage, seed,
+                                  self.p_drop, [False] + [True] * (len(names) - 1), want_alias)
+
     def _block1(self, x, want_alias=False):
         """(h, residual[, alias of x]) of the block's first stage.  x may be the pair (h_prev, skip) of an
         up-path block: the concatenation is then read in place by the two-source kernels instead of being
@@ -375,10 +395,15 @@ class ResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb, want_alias=False):
-        h, res, *alias = self._block1(x, want_alias)
         ft = self._film.pop('t', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
+        small = self._small(x, ft, None, want_alias)
+        if small is not None:
+            h, *alias = small if want_alias else (small,)
+            h = self.attn(h)
+            return (h, alias[0]) if want_alias else h
+        h, res, *alias = self._block1(x, want_alias)
         h = self._gn_conv('block2', h, film_t=ft, drop_site=1, single=True)
         h = self._gn_conv('block3', h, drop_site=2, residual=res, single=True)
         h = self.attn(h)
@@ -402,13 +427,20 @@ class AuxResBlock(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, temb, aemb=None, want_alias=False):
-        h, res, *alias = self._block1(x, want_alias)
         ft = self._film.pop('t', None) if self._film else None
         fa = self._film.pop('a', None) if self._film else None
         if ft is None:
             ft = ops.linear(temb, self.temb_proj[1].weight, self.temb_proj[1].bias, silu_in=True)
         if fa is None:
             fa = ops.linear(aemb, self.aemb_proj[1].weight, self.aemb_proj[1].bias, silu_in=True)
+        small = self._small(x, ft, fa, want_alias)
+        if small is not None:
+            h, *alias = small if want_alias else (small,)
+            h = self.attn(h)
+            if self.use_crossattn:
+                h = self.crossattn(h, aemb)
+            return (h, alias[0]) if want_alias else h
+        h, res, *alias = self._block1(x, want_alias)
         h = self._gn_conv('block2', h, film_t=ft, film_a=fa, drop_site=1, single=True)
         h = self._gn_conv('block3', h, drop_site=2, residual=res, single=True)
         h = self.attn(h)
@@ -429,6 +461,11 @@ class ResBlock_encoder(_ResBase):
         self._setup(dropout)
 
     def forward(self, x, want_alias=False):
+        small = self._small(x, None, None, want_alias)
+        if small is not None:
+            h, *alias = small if want_alias else (small,)
+            h = self.attn(h)
+            return (h, alias[0]) if want_alias else h
         h, res, *alias = self._block1(x, want_alias)
         h = self._gn_conv('block2', h, drop_site=1, residual=res, single=True)
         h = self.attn(h)

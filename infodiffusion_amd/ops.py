@@ -1168,6 +1168,213 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
     return out[0], out[1]
 
 
+# ------------------------------------------- image-resident ResBlock at the 8x8 maps
+_RB_SMALL = os.environ.get('IDF_RB_SMALL', '1') != '0'
+_RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '64'))     # one workgroup per image: pays while the batch leaves CUs idle
+
+
+@functools.lru_cache(maxsize=None)
+def _rb_small_shape_ok(B, H, W, Cin, C1, Cout, nstage):
+    return bool(_lib.load().idf_resblock_small_ok(B, H, W, Cin, C1, Cout, nstage))
+
+
+def resblock_small_ok(x, x2, Cout, nstage):
+    """idf_resblock_small_fwd covers this block input (bf16, 8x8, 128 couts, batch small enough to be launch-bound)."""
+    if not (_RB_SMALL and x.is_cuda and x.dtype == torch.bfloat16 and (x2 is None or x2.dtype == torch.bfloat16)):
+        return False
+    B, C1, H, W = x.shape
+    if B > _RB_SMALL_MAXB or (x2 is not None and x2.shape[2:] != x.shape[2:]):
+        return False
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    return _rb_small_shape_ok(B, H, W, Cin, C1 if x2 is not None else 0, Cout, nstage)
+
+
+class _ResBlockSmall(torch.autograd.Function):
+    """A whole ResBlock / AuxResBlock / ResBlock_encoder at 8x8 as ONE forward launch (idf_resblock_small_fwd: one
+    workgroup per image, every GroupNorm closes in-block, the stages chained through LDS).  The backward pass is the
+    per-stage one of `_FusedConv` / `_BlockEntryCat` -- the data-gradient convs that carry the GroupNorm backward as their
+    epilogue, deferred weight gradients -- issued stage by stage from the tensors the forward launch left behind.
+
+    tensors = [w, b, gn_w, gn_b] per stage (+ [sc_w, sc_b] when meta['has_sc']).  Outputs: y, statistics partials of y
+    (non-differentiable), [an alias of x for the skip connection that branches off the block input]."""
+
+    @staticmethod
+    def forward(ctx, x, x2, film_t, film_a, seed, st1, st2, meta, *tensors):
+        ctx.set_materialize_grads(False)
+        x = _nhwc(x)
+        x2 = _nhwc(x2) if x2 is not None else None
+        n, has_sc, cfgs = meta['nstage'], meta['has_sc'], meta['cfgs']
+        B, C1, H, W = x.shape
+        Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+        Cout = tensors[0].shape[0]
+        dev, dt = x.device, x.dtype
+        train = meta['train']
+        need = ctx.needs_input_grad
+        A = _lib.ResblockArgs()
+        A.x, A.x2, A.C1, A.Cin = _p(x), _p(x2), C1 if x2 is not None else Cin, Cin
+        A.st1, A.T1 = _p(st1), st1.shape[1]
+        A.st2, A.T2 = (_p(st2), st2.shape[1]) if st2 is not None else (None, 0)
+        A.nstage = n
+        y = empty_nhwc(B, Cout, H, W, dt, dev)
+        st_out = torch.empty((B, 1, Cout, 2), dtype=torch.float32, device=dev)
+        keep = []           # per stage: a, h (None for the last), mean, rstd, sc, sh
+        p_drop = meta['p_drop'] if seed is not None else 0.0
+        for i in range(n):
+            w, b, gw, gb = tensors[4 * i:4 * i + 4]
+            S = A.s[i]
+            ci = Cin if i == 0 else Cout
+            S.w, S.bias = _p(cfgs[i]['shadows'](dt, train)[0]), _p(b)
+            S.gamma, S.beta = _p(gw), _p(gb)
+            ft, fa = (film_t, film_a) if i == meta['film_stage'] else (None, None)
+            S.film_t, S.film_a, S.ld_t, S.ld_a = _p(ft), _p(fa), _ld(ft), _ld(fa)
+            S.salt, S.drop = cfgs[i]['salt'], int(meta['drop'][i] and seed is not None)
+            a = h = mean = rstd = sc = sh = None
+            if train:
+                a = empty_nhwc(B, ci, H, W, dt, dev)
+                mean = torch.empty((B, 32), dtype=torch.float32, device=dev)
+                rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
+                sc = torch.empty((B, ci), dtype=torch.float32, device=dev)
+                sh = torch.empty((B, ci), dtype=torch.float32, device=dev)
+                if i + 1 < n:
+                    h = empty_nhwc(B, Cout, H, W, dt, dev)
+            S.a_out, S.mean, S.rstd, S.sc, S.sh = _p(a), _p(mean), _p(rstd), _p(sc), _p(sh)
+            S.h_out = _p(y) if i + 1 == n else _p(h)
+            keep += [a, h, mean, rstd, sc, sh]
+        if has_sc:
+            A.w_sc, A.b_sc = _p(meta['cfg_sc']['shadows'](dt, train)[0]), _p(tensors[4 * n + 1])
+        A.y, A.st_out = _p(y), _p(st_out)
+        A.seed, A.p_drop, A.eps, A.B = _p(seed), float(p_drop), GN_EPS, B
+        call('idf_resblock_small_fwd', ctypes.byref(A), _st())
+        ctx.meta, ctx.p_drop = meta, p_drop
+        ctx.save_for_backward(x, x2, film_t, film_a, seed, *keep, *tensors)
+        ctx.mark_non_differentiable(st_out)
+        outs = (y, st_out)
+        if meta['passthrough']:
+            outs += (x.detach(),)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dy, _dst, *dalias):
+        meta = ctx.meta
+        n, has_sc, cfgs, slots = meta['nstage'], meta['has_sc'], meta['cfgs'], meta['slots']
+        sv = ctx.saved_tensors
+        x, x2, film_t, film_a, seed = sv[:5]
+        keep = sv[5:5 + 6 * n]
+        tensors = sv[5 + 6 * n:]
+        p_drop = ctx.p_drop
+        dt = x.dtype
+        B, C1, H, W = x.shape
+        Cout = tensors[0].shape[0]
+        if dy is None:
+            dy = torch.zeros((B, Cout, H, W), dtype=dt, device=x.device).contiguous(memory_format=CL)
+        g = _nhwc(dy.to(dt))
+        dskip = _nhwc(dalias[0].to(dt)) if (dalias and dalias[0] is not None) else None
+        grads = [None] * (4 * n + (2 if has_sc else 0))
+        dft = dfa = None
+        # the residual branch: an identity joins the first stage's GroupNorm backward as it stands, a 1x1 shortcut first
+        # takes its weight gradient (over the raw input, read in place) and its data gradient
+        ds = g
+        for i in range(n - 1, 0, -1):
+            a, h_prev = keep[6 * i], keep[6 * (i - 1) + 1]
+            mean, rstd, sc, sh = keep[6 * i + 2:6 * i + 6]
+            w, b, gw, gb = tensors[4 * i:4 * i + 4]
+            ws, bs, gws, gbs = slots[4 * i:4 * i + 4]
+            ft, fa = (film_t, film_a) if i == meta['film_stage'] else (None, None)
+            sd = seed if meta['drop'][i] else None
+            pd = p_drop if meta['drop'][i] else 0.0
+            w_dgrad = cfgs[i]['shadows'](dt, True)[1]
+            dx, dgw, dgb, dft_i, dfa_i = conv_dgrad_gn_raw(g, w_dgrad, h_prev, gw, gb, ft, fa, mean, rstd, sc, sh, sd,
+                                                           cfgs[i]['salt'], pd, 2, 9, (gws, gbs))
+            if ft is not None or fa is not None:
+                dft, dfa = dft_i, dfa_i
+            defer = _grad_free(ws) and _grad_free(bs)
+            dW, db = conv_wgrad_bias_raw(a, g, S1, 9, True, ws, bs, defer)
+            grads[4 * i:4 * i + 4] = [dW, db, dgw, dgb]
+            g = dx
+        # first stage: its input is the block input
+        a0 = keep[0]
+        mean, rstd, sc, sh = keep[2:6]
+        w, b, gw, gb = tensors[0:4]
+        ws, bs, gws, gbs = slots[0:4]
+        w_dgrad = cfgs[0]['shadows'](dt, True)[1]
+        dx2 = None
+        if x2 is None:
+            dres = ds
+            if has_sc:
+                sw, sb = tensors[4 * n], tensors[4 * n + 1]
+                sws, sbs = slots[4 * n], slots[4 * n + 1]
+                grads[4 * n], grads[4 * n + 1] = conv_wgrad_bias_raw(x, ds, S1, 1, True, sws, sbs, _grad_free(sws) and _grad_free(sbs))
+                dres = conv_dgrad_raw(ds, meta['cfg_sc']['shadows'](dt, True)[1], S1, 1, x.shape)
+            dx, dgw, dgb, _, _ = conv_dgrad_gn_raw(g, w_dgrad, x, gw, gb, None, None, mean, rstd, sc, sh, None,
+                                                   cfgs[0]['salt'], 0.0, 2, 9, (gws, gbs), dres, dskip)
+        else:
+            sw, sb = tensors[4 * n], tensors[4 * n + 1]
+            sws, sbs = slots[4 * n], slots[4 * n + 1]
+            dx, dx2, dgw, dgb, dsW, dsb = _entry_cat_bwd(x, x2, g, ds, gw, gb, mean, rstd, sc, sh, cfgs[0], meta['cfg_sc'],
+                                                          (gws, gbs), (sws, sbs))
+            grads[4 * n], grads[4 * n + 1] = dsW, dsb
+        defer = _grad_free(ws) and _grad_free(bs)
+        dW, db = conv_wgrad_bias_raw(a0, g, S1, 9, True, ws, bs, defer)
+        grads[0:4] = [dW, db, dgw, dgb]
+        return (dx, dx2, dft, dfa, None, None, None, None) + tuple(grads)
+
+
+def _entry_cat_bwd(x1, x2, dh, ds, gn_w, gn_b, mean, rstd, sc, sh, cfg, cfg_sc, gslots, sslots):
+    """Backward of a block entry over the skip pair x1 | x2 (what `_BlockEntryCat.backward` does for its own node):
+    dh = gradient of the first conv's output, ds = gradient of the 1x1 shortcut's output -> (dx1, dx2, dgamma, dbeta,
+    shortcut dW, shortcut db); the first conv's own weight gradient is the caller's."""
+    B, C1, H, W = x1.shape
+    C = C1 + x2.shape[1]
+    got = _defer_or_launch_wgrad(x1, ds, sslots[0], sslots[1], 1, a2=x2)
+    if got is None:
+        xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL)
+        got = conv_wgrad_bias_raw(xc, ds, S1, 1, True)
+    dsW, dsb = got
+    w_sc_dgrad = cfg_sc['shadows'](x1.dtype, True)[1]
+    w_dgrad = cfg['shadows'](x1.dtype, True)[1]
+    chain_ok = _BWD_CHAIN and C1 % 64 == 0 and chain_tiles(B, H, W, dh.shape[1], C, 9) > 0
+    if chain_ok:
+        ride = _SC_FUSE and B * H * W <= _SC_FUSE_MAXPIX and ds.shape[1] % 32 == 0
+        if ride:
+            du, part, dxs = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'],
+                                                 shortcut=(ds, w_sc_dgrad))
+        else:
+            dxs = conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
+            du, part, _ = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'])
+        (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, gslots, dres=dxs,
+                                                       x2=x2)
+    else:
+        dxs = conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
+        dA = conv_dgrad_raw(dh, w_dgrad, S1, 9, (B, C, H, W))
+        (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None, cfg['salt'], 0.0,
+                                                       cfg['act'], gslots, dres=dxs, x2=x2)
+    return dx1, dx2, dgw, dgb, dsW, dsb
+
+
+def resblock_small(x, x2, stages, shortcut, film_t, film_a, film_stage, seed, p_drop, drop, want_alias):
+    """stages = [(conv, gn, cfg)] (2 or 3), shortcut = (conv, cfg) or None.  -> y (statistics attached) [, alias of x]."""
+    train = torch.is_grad_enabled() and (x.requires_grad or (x2 is not None and x2.requires_grad))
+    tensors, slots = [], []
+    for conv, gn, _ in stages:
+        tensors += [conv.weight, conv.bias, gn.weight, gn.bias]
+    if shortcut is not None:
+        tensors += [shortcut[0].weight, shortcut[0].bias]
+    if torch.is_grad_enabled():
+        slots = [slot_of(t) for t in tensors]
+    else:
+        slots = [None] * len(tensors)
+    meta = dict(nstage=len(stages), has_sc=shortcut is not None, cfgs=[c for _, _, c in stages],
+                cfg_sc=shortcut[1] if shortcut is not None else None, slots=slots, passthrough=int(bool(want_alias)),
+                train=train, film_stage=film_stage, drop=list(drop), p_drop=p_drop)
+    st1 = stats_of(x)
+    st2 = stats_of(x2) if x2 is not None else None
+    out = _ResBlockSmall.apply(x, x2, film_t, film_a, seed, st1, st2, meta, *tensors)
+    y = _tag(out[0], out[1])
+    if want_alias:
+        return y, _tag(out[2], st1)
+    return y
+
+
 # ------------------------------------------------------------------ attention
 _ATTN_BWD_ONE = os.environ.get('IDF_ATTN_BWD_ONE', '1') != '0'      # query and key-value halves of the backward in one launch
 

@@ -156,9 +156,10 @@ def cpu_baseline(margs, budget_s=240):
 
 def pmc_traffic_file(names):
     """Average HBM bytes per launch over the kernels whose name contains one of `names`, from the committed rocprofv3
-    PMC passes of this round (profiles/r03_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    PMC passes of the latest round (profiles/rNN_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), or None."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
+        files = sorted(fn for fn in os.listdir(os.path.join(ROOT, 'profiles')) if fn.endswith('_pmc_traffic.json'))
+        with open(os.path.join(ROOT, 'profiles', files[-1])) as f:      # the latest round's passes
             d = json.load(f)
         ks = [v for k, v in d.items() if any(n in k for n in names)]
         n = sum(v['launches'] for v in ks)

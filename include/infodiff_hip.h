@@ -170,6 +170,7 @@ typedef struct {
   void* y; float* st_out;
   const uint64_t* seed; float p_drop; float eps;
   int B;
+  int w_layout;             /* 0: s[i].w is the forward shadow [128][9][Cin_i]; 1: the fragment-major shadow (idf_pack_conv_weights_batched) */
 } IdfResblockArgs;
 int idf_resblock_small_ok(int B, int H, int W, int Cin, int C1, int Cout, int nstage);
 int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
@@ -261,9 +262,11 @@ int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fw
                          int taps, int dtype, void* stream);
 
 /* the same for every conv of a network in one launch.  table (device): nrows x
- * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long tile, pad}
+ * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long tile; void* w_frag}
  * -- one block per row = one (tap, 32-cout, 64-cin) tile, tile = tap | cout_tile << 8 | cin_tile << 32;
- * Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow. */
+ * Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow.  w_frag (optional; 3x3, O % 16 == 0, I % 64 == 0):
+ * a third shadow, the forward weights fragment-major for idf_resblock_small_fwd (IdfResblockArgs.w_layout = 1):
+ * [I / 64][O / 16][tap][half][lane = fq * 16 + fr][8] with o = 16 * (O / 16 index) + fr, i = 64 * pair + 32 * half + 8 * fq + e. */
 int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream);
 
 /* ---- GroupNorm(32) + AdaGN/FiLM fold (modules.py:132, 214-228, 312-318; nn.GroupNorm eps 1e-5)

@@ -27,7 +27,7 @@ class ResblockArgs(C.Structure):
     """IdfResblockArgs (include/infodiff_hip.h)."""
     _fields_ = [('x', _p), ('x2', _p), ('C1', _i), ('Cin', _i), ('st1', _p), ('st2', _p), ('T1', _i), ('T2', _i),
                 ('nstage', _i), ('s', ResblockStage * 3), ('w_sc', _p), ('b_sc', _p), ('y', _p), ('st_out', _p),
-                ('seed', _p), ('p_drop', _f), ('eps', _f), ('B', _i)]
+                ('seed', _p), ('p_drop', _f), ('eps', _f), ('B', _i), ('w_layout', _i)]
 
 
 SIGNATURES = {

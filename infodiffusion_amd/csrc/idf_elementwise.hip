@@ -318,7 +318,10 @@ struct PackDesc {
   int O, I, taps;         // this source tensor
   int Ototal, o0;         // rows of the (possibly concatenated) shadow and this tensor's first row
   long e0;                // packed tile origin: tap | ot << 8 | it << 32
-  long n;                 // unused
+  void* wfrag;            // optional third shadow (3x3, O % 16 == 0, I % 64 == 0): the forward weights fragment-major for the
+                          // image-resident ResBlock kernel (idf_resblock.hip): [I / 64][O / 16][tap][half][lane = fq * 16 + fr][8]
+                          // with o = 16 * wave + fr, i = 64 * pair + 32 * half + 8 * fq + e -- a wave's A fragment is 1 KB of
+                          // consecutive bytes
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __restrict__ tab) {
@@ -337,6 +340,11 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __res
       if (wf) Elem<T>::st(wf + ((size_t)(d.o0 + o) * d.taps + tap) * d.I + i, v);
     }
     tile[(tid >> 6) + k * 4][tid & 63] = v;
+    if (d.wfrag && o < d.O && i < d.I) {
+      const int oo = d.o0 + o, wave = oo >> 4, fr = oo & 15, pair = i >> 6, half = (i >> 5) & 1, fq = (i >> 3) & 3, e = i & 7;
+      Elem<T>::st(reinterpret_cast<T*>(d.wfrag) +
+                      ((((size_t)(pair * (d.Ototal >> 4) + wave) * d.taps + tap) * 2 + half) * 64 + fq * 16 + fr) * 8 + e, v);
+    }
   }
   if (!wd) return;
   __syncthreads();

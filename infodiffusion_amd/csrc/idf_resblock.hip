@@ -9,13 +9,23 @@
 // memory round trip + coefficient fold + epilogue) on 64 of 256 CUs; this kernel runs the stages back to back on 32 CUs
 // at the pace of its MFMA / weight stream.
 //
-// LDS:  Abuf [Cin/32][100 halo pixels][64 B]   the activated conv input, 32-channel chunk major, halo-tile layout of
-//                                              idf_conv3x3.hip (64-byte pixel rows, 16-byte slots XOR-swizzled); the border
-//                                              pixels are zeroed once and stay zero (the reference pads the ACTIVATED tensor)
-//       Wbuf [9][128][64 B]                    one 32-channel weight slab of all 128 couts; the next slab travels in
-//                                              registers while the MFMAs run (register double buffering), across stage
-//                                              boundaries too; the fp32 output tile Hbuf [64][132] aliases it between stages
-//       cof / chs / part                       coefficients, channel sums, wave partials
+// Work split: wave w of the 8 owns couts 16 w .. 16 w + 15 of ALL 64 pixels (4 MFMA tiles of 16 pixels x 16 couts).
+//  * Weights never touch LDS: a wave's A fragments (16 couts x 32 channels of one tap = 16 B per lane) are loaded from
+//    global memory straight into registers, one 64-channel chunk pair (18 fragments) ahead of the MFMAs that use them -- each
+//    fragment register is re-loaded right behind its last MFMA, across stage boundaries too -- so the conv loop has NO
+//    workgroup barrier and no LDS write phase (the first form of this kernel staged
+//    a [9][128][64 B] slab per chunk through LDS: 930 cycles of ds_write_b128 + two barriers per chunk, 34 us per block; this
+//    form: see profiles/r04_resblock_small.txt).
+//  * A wave's 16 couts are 4 whole GroupNorm groups (128 channels / 32 groups = 4 per group = the 4 couts one lane holds), and
+//    the 16 lanes of a DPP row hold the same couts: each GroupNorm's statistics, its coefficient fold and the activation of
+//    the next stage's input happen in the wave's registers -- two workgroup barriers per stage in all (the LDS image is
+//    free / the LDS image is written).
+// LDS:  Abuf [Cin/32][10 rows][16][96 B]       the activated conv input, 32-channel chunk major, as a halo image (10 x 10 pixels
+//                                              used, 64 of the 96 bytes of a pixel used: the padding makes the fragment reads
+//                                              bank-conflict-free, see WH / PPB below); the border pixels are zeroed once and
+//                                              stay zero (the reference pads the ACTIVATED tensor)
+//       cof / chs                              coefficients and channel sums of the first GroupNorm (its statistics come
+//                                              from the producers' partials)
 // Arithmetic per element is the per-op path's (pro_vec: fold, SiLU, dropout keyed by the element's index in the dense
 // activated tensor; statistics of the bf16-ROUNDED outputs; the shortcut rounded to bf16 before it joins): results agree
 // with the per-op launches up to the summation order of the statistics.
@@ -26,14 +36,28 @@
 
 namespace {
 
-constexpr int CK = 32, NPX = 64, WH = 10, NPH = 100, BN = 128, NT = 512, PF = BN + 4;
-constexpr int WSLAB = 9 * BN * 64;              // bytes of a weight slab
-constexpr int WV = 9 * BN * 4 / NT;             // 16-byte weight vectors per thread per slab (9)
+constexpr int CK = 32, NPX = 64, BN = 128, NT = 512;
+// LDS image of one 32-channel chunk: 10 halo rows of 16 pixel slots (10 used), 96 bytes per pixel (64 used): with a row pitch of
+// 16 pixels and a pixel pitch of 96 B the ds_read_b128 of an MFMA fragment -- 16 lanes = two image rows of 8 pixels, 4 lane
+// groups = the 4 channel slots -- is bank-conflict-free (brute-forced over the gfx950 lane groups; the 10-pixel row / 64-byte
+// pitch of idf_conv3x3.hip, with or without its XOR swizzle, is 2-way here because an 8-pixel row breaks the run of
+// consecutive halo rows), and every tap / chunk displacement is an instruction immediate.
+constexpr int WH = 16, HROWS = 10, PPB = 96, NPH = HROWS * WH, CHB = NPH * PPB;      // bytes of a chunk image: 15360
 constexpr int MAXC = 256;
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
-__device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
+// byte offset of the 16-byte channel slot q of halo pixel h inside a chunk image
+__device__ __forceinline__ int aoff(int h, int q) { return h * PPB + q * 16; }
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
 
 // a = act(x * sc + sh) on one 16-byte vector (8 bf16 channels), dropout keyed by the vector's index in the dense activated
 // tensor: idf_conv3x3.hip's pro_vec
@@ -51,17 +75,29 @@ __device__ __forceinline__ uint4 act_vec(const uint4 raw, const float (&scv)[8],
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// (mean, rstd) of a group from its (sum, sum of squares) over n = 2^k elements.  mu and var in double as
+// idf_conv3x3.hip's pro_coefficients forms them (the divisions by n are exact multiplications); 1 / sqrt as v_rsq_f32 + one
+// Newton step in double (2e-14 relative: the float it rounds to is pro_coefficients' except on rounding ties) -- the
+// double-precision divide and square root sequences were 1 us per GroupNorm here.
+__device__ __forceinline__ void group_stats(double a, double d, double inv_n, float eps, float* mean, float* rstd) {
+  const double mu = a * inv_n;
+  double var = d * inv_n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double vd = var + (double)eps;
+  const double r0 = (double)__builtin_amdgcn_rsqf((float)vd);
+  *rstd = (float)(r0 * (1.5 - 0.5 * vd * r0 * r0));
+  *mean = (float)mu;
+}
+
 // (sc, sh) of channel c from the per-channel sums chs [C][2] (sum, sum of squares over the image's 64 pixels): the fold of
-// idf_conv3x3.hip's pro_coefficients, same expressions in the same order
+// idf_conv3x3.hip's pro_coefficients
 __device__ __forceinline__ void fold_channel(const float* chs, int c, int C, int b, const IdfResblockStage& s, float eps,
                                              float* cof) {
   const int cpg = C >> 5, g = c / cpg;
   double a = 0.0, d = 0.0;
   for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
-  const double n = (double)NPX * cpg;
-  double mu = a / n, var = d / n - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const float r = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mu;
+  float mf, r;
+  group_stats(a, d, 1.0 / ((double)NPX * cpg), eps, &mf, &r);
   const float ga = s.gamma ? s.gamma[c] : 1.f, be = s.beta ? s.beta[c] : 0.f;
   float sc = r * ga, sh = be - mf * sc;
   if (s.film_t) { const float f = 1.f + s.film_t[(size_t)b * s.ld_t + c]; sc *= f; sh = sh * f + s.film_t[(size_t)b * s.ld_t + C + c]; }
@@ -75,6 +111,35 @@ __device__ __forceinline__ void fold_channel(const float* chs, int c, int C, int
 
 struct RbK { IdfResblockArgs a; uint32_t thr; float dscale; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for every
+// global store of the epilogue (h, a: ~2 us of write latency) and for the weight fragments prefetched for the next stage;
+// nothing in global memory is shared between the waves of this kernel (stamps: the two barriers of a stage cost 3.3 us of its
+// 4.5-us epilogue, stage 0 7.5 us -- profiles/r04_resblock_small.txt).
+__device__ __forceinline__ void rb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Diagnostic build only (tools/build_variant.sh rbstamp idf_resblock.hip -DIDF_RB_STAMP; never in the shipped library):
+// wave 0 of every block stamps s_memtime at the phase boundaries and adds the differences to g_rb_stamps
+// [0] stage 0 (input, first fold, shortcut, activation), [1 + 2 k] conv loop of stage k, [2 + 2 k] its epilogue, [7] blocks
+#ifdef IDF_RB_STAMP
+__device__ unsigned long long g_rb_stamps[8];
+__device__ __forceinline__ unsigned long long rb_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define RB_STAMP(var) const unsigned long long var = rb_now()
+#define RB_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_rb_stamps[i], (b) - (a)); } while (0)
+#else
+#define RB_STAMP(var)
+#define RB_ADD(i, a, b)
+#endif
+
+// one 64-channel PAIR of chunks of this wave's weights: 9 taps x 2 x (16 couts x 32 channels), 16 B per lane, tap and chunk.
+// Pairs, because a weight row [cout][tap][Cin] is read in 128-byte lines = 64 channels: fetching the two halves of a line with
+// back-to-back loads uses every line once (chunk by chunk each line crossed the L2 -> L1 path twice, which is what bounds a
+// CU that streams 0.9 MB of weights per block)
+struct WPair { bf16x8_t t[9][2]; };
+
 __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const IdfResblockArgs& p = k_in.a;
@@ -83,61 +148,55 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
   const uint32_t thr = k_in.thr;
   const float dscale = k_in.dscale;
   const int Cin = p.Cin, nck1 = Cin / CK;
-  unsigned char* const Abuf = smem;                                   // [nck1][NPH][64]
-  unsigned char* const Wbuf = smem + (size_t)nck1 * NPH * 64;         // [9][BN][64]   (Hbuf aliases it)
-  float* const Hbuf = reinterpret_cast<float*>(Wbuf);                 // [NPX][PF]
-  float* const cof = reinterpret_cast<float*>(Wbuf + WSLAB);          // [MAXC][2]
-  float* const chs = cof + 2 * MAXC;                                  // [MAXC][2]
-  float* const part = chs + 2 * MAXC;                                 // [8][BN][2]
+  unsigned char* const Abuf = smem;                                               // [nck1][HROWS][WH][PPB]
+  float* const cof = reinterpret_cast<float*>(smem + (size_t)nck1 * CHB);    // [MAXC][2]
+  float* const chs = cof + 2 * MAXC;                                              // [MAXC][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RB_STAMP(t_begin);
   const int fr = lane & 15, fq = lane >> 4;
-  const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;            // this wave's 32 pixels x 32 couts
+  const int wn0 = wave * 16;                                 // this wave's 16 couts
+  const int c0 = wn0 + fq * 4;                               // the 4 couts this lane holds in the MFMA output = one GroupNorm group
   const bool drop_any = p.seed != nullptr;
   const uint64_t seedv = drop_any ? *p.seed : 0;
 
-  int hbase[2], wbase[2];
+  int hbase[4];                                              // halo row of tap (0, 0) of this lane's pixel in each 16-pixel slice
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pl = wm0 + i * 16 + fr;
+  for (int i = 0; i < 4; ++i) {
+    const int pl = i * 16 + fr;
     hbase[i] = (pl >> 3) * WH + (pl & 7);
-    const int n = wn0 + i * 16 + fr;
-    wbase[i] = n * 64 + swz(n, fq) * 16;
   }
-  // weight slab plan: idx over [BN][9][4 slots]
-  int wsrc[WV], wlds[WV];
+  // this lane's piece of the wave's weight fragments: row (cout) wn0 + fr, channels fq * 8 .. + 7 of a chunk
+  // Where fragment (tap, half) of chunk pair cp lives for this lane.  Layout 0: the forward shadow [cout][tap][cin] (a wave
+  // instruction gathers 16 rows x 64 B).  Layout 1 (idf_resblock_pack_weight): fragment-major [pair][wave][tap][half][lane][8]
+  // -- every wave instruction reads 1 KB of consecutive bytes.
+  const bool wfrag = p.w_layout == 1;
+  auto wptr = [&](const bf16_t* w, int cin, int cp, int tap, int half) __attribute__((always_inline)) -> const bf16_t* {
+    if (wfrag) return w + ((size_t)((cp * 8 + wave) * 18 + tap * 2 + half) * 64 + lane) * 8;
+    return w + (size_t)(wn0 + fr) * 9 * cin + (size_t)tap * cin + (cp * 2 + half) * CK + fq * 8;
+  };
+  auto load_w = [&](WPair& W, const bf16_t* w, int cin, int cp) __attribute__((always_inline)) {     // chunks 2 cp, 2 cp + 1
 #pragma unroll
-  for (int k = 0; k < WV; ++k) {
-    const int idx = tid + k * NT, ch = idx & 3, r = idx >> 2, tap = r % 9, n = r / 9;
-    wsrc[k] = (n * 9 + tap) * 4 + ch;                      // (row, slot): element offset = row * Cin_stage + chunk * 32 + slot * 8
-    wlds[k] = (tap * BN + n) * 64 + swz(n, ch) * 16;
-  }
-  // (builtin vectors, not HIP's uint4 struct: its assignment from memory is a memcpy the optimizer does not split, which
-  // leaves the array in scratch)
-  u32x4_t wreg[WV];
-#define load_w(wptr, cin_, ck_)                                                                                          \
-  do {                                                                                                                   \
-    _Pragma("unroll") for (int k_ = 0; k_ < WV; ++k_)                                                                    \
-      wreg[k_] = *reinterpret_cast<const u32x4_t*>((wptr) + (size_t)(wsrc[k_] >> 2) * (cin_) + (ck_) * CK + (wsrc[k_] & 3) * 8); \
-  } while (0)
-#define store_w()                                                                                                        \
-  do {                                                                                                                   \
-    _Pragma("unroll") for (int k_ = 0; k_ < WV; ++k_) *reinterpret_cast<u32x4_t*>(Wbuf + wlds[k_]) = wreg[k_];             \
-  } while (0)
+    for (int tap = 0; tap < 9; ++tap) {
+      W.t[tap][0] = *reinterpret_cast<const bf16x8_t*>(wptr(w, cin, cp, tap, 0));
+      W.t[tap][1] = *reinterpret_cast<const bf16x8_t*>(wptr(w, cin, cp, tap, 1));
+    }
+  };
 
   // ---- stage 0: the block input.  Its vectors and the statistics partials are fetched together (one round trip).
   // element-wise thread map over a 64-pixel x C-channel tensor: vector v = tid + k * NT -> pixel v / (C / 8), slot v % (C / 8)
   const int vpp1 = Cin / 8;                                  // vectors per pixel of the input
   const int nv1 = NPX * vpp1 / NT;                           // vectors per thread: 2 (128 channels) or 4 (256)
-  uint4 xraw[4];
+  u32x4_t xraw[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    xraw[k] = make_uint4(0, 0, 0, 0);
+    xraw[k] = u32x4_t{0, 0, 0, 0};
     if (k < nv1) {
       const int v = tid + k * NT, pl = v / vpp1, c = (v - pl * vpp1) * 8;
       const bf16_t* src = (px2 && c >= p.C1) ? px2 + ((size_t)(b * NPX + pl) * (Cin - p.C1) + (c - p.C1))
                                              : px + ((size_t)(b * NPX + pl) * (px2 ? p.C1 : Cin) + c);
-      xraw[k] = *reinterpret_cast<const uint4*>(src);
+      xraw[k] = *reinterpret_cast<const u32x4_t*>(src);
     }
   }
   for (int c = tid; c < Cin; c += NT) {
@@ -147,6 +206,8 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
     const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl, T, (size_t)Cs);
     chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
   }
+  WPair wA;                  // ONE pair in registers: every fragment is re-loaded for the next pair right behind its last MFMA
+  load_w(wA, reinterpret_cast<const bf16_t*>(p.s[0].w), Cin, 0);     // conv1's first chunk pair flies through all of stage 0
   // zero the halo border of every chunk image (36 border pixels x 4 slots per chunk)
   for (int i = tid; i < nck1 * 36 * 4; i += NT) {
     const int ck = i / 144, r = i - ck * 144, bp = r >> 2, q = r & 3;
@@ -155,53 +216,57 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
     if (bp < 10) { hy = 0; hx = bp; } else if (bp < 20) { hy = 9; hx = bp - 10; }
     else if (bp < 28) { hy = bp - 19; hx = 0; } else { hy = bp - 27; hx = 9; }
     const int h = hy * WH + hx;
-    *reinterpret_cast<uint4*>(Abuf + (size_t)ck * NPH * 64 + h * 64 + swz(h, q) * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<u32x4_t*>(Abuf + (size_t)ck * CHB + aoff(h, q)) = u32x4_t{0, 0, 0, 0};
   }
-  __syncthreads();
+  rb_barrier();   
   for (int c = tid; c < Cin; c += NT) fold_channel(chs, c, Cin, b, p.s[0], p.eps, cof);
 
-  f32x4_t sacc[2][2];        // the 1x1 shortcut, MFMA layout
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) sacc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  auto a_slot = [&](int pl, int c) -> unsigned char* {      // LDS home of the 8 channels c.. of pixel pl
+  uint2 res[4];              // the residual branch in the MFMA output layout (couts c0 .. c0 + 3 of pixels i * 16 + fr), bf16:
+                             // the raw input (identity) or the 1x1 shortcut + bias, rounded as the tensor it is in the per-op path
+  auto a_slot = [&](int pl, int c) -> unsigned char* {      // LDS home of the 8 channels (c & ~7).. of pixel pl
     const int h = ((pl >> 3) + 1) * WH + (pl & 7) + 1;
-    return Abuf + (size_t)(c >> 5) * NPH * 64 + h * 64 + swz(h, (c & 31) >> 3) * 16;
+    return Abuf + (size_t)(c >> 5) * CHB + aoff(h, (c & 31) >> 3);
   };
   if (p.w_sc) {
-    // raw input -> Abuf, the whole [128][Cin] shortcut weight -> Wbuf ([chunk][n][64 B]), centre-tap MFMAs
+    // raw input -> Abuf; centre-tap MFMAs against the [128][Cin] shortcut weight, fragments straight from global memory
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (k < nv1) {
         const int v = tid + k * NT, pl = v / vpp1, c = (v - pl * vpp1) * 8;
-        *reinterpret_cast<uint4*>(a_slot(pl, c)) = xraw[k];
+        *reinterpret_cast<u32x4_t*>(a_slot(pl, c)) = xraw[k];
       }
-    for (int i = tid; i < BN * nck1 * 4; i += NT) {
-      const int q = i & 3, r = i >> 2, ck = r % nck1, n = r / nck1;
-      *reinterpret_cast<uint4*>(Wbuf + ((size_t)ck * BN + n) * 64 + swz(n, q) * 16) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.w_sc) + (size_t)n * Cin + ck * CK + q * 8);
-    }
-    __syncthreads();
-    for (int ck = 0; ck < nck1; ++ck) {
-      bf16x8_t wf[2], xf[2];
+    bf16x8_t ws[8];
+    const bf16_t* wsb = reinterpret_cast<const bf16_t*>(p.w_sc) + (size_t)(wn0 + fr) * Cin + fq * 8;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Wbuf + (size_t)ck * BN * 64 + wbase[a]);
+    for (int ck = 0; ck < 8; ++ck)
+      if (ck < nck1) ws[ck] = *reinterpret_cast<const bf16x8_t*>(wsb + ck * CK);
+    float4 bsc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.b_sc) bsc4 = *reinterpret_cast<const float4*>(p.b_sc + c0);
+    rb_barrier();   
+    f32x4_t sacc[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int h = hbase[i] + WH + 1;
-        xf[i] = *reinterpret_cast<const bf16x8_t*>(Abuf + (size_t)ck * NPH * 64 + h * 64 + swz(h, fq) * 16);
+    for (int i = 0; i < 4; ++i) sacc[i] = f32x4_t{bsc4.x, bsc4.y, bsc4.z, bsc4.w};
+#pragma unroll
+    for (int ck = 0; ck < 8; ++ck)
+      if (ck < nck1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int h = hbase[i] + WH + 1;
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(Abuf + (size_t)ck * CHB + aoff(h, fq));
+          sacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[ck], xf, sacc[i], 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) sacc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], sacc[a][i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      res[i].x = (uint32_t)f32_to_bf16(sacc[i][0]) | ((uint32_t)f32_to_bf16(sacc[i][1]) << 16);
+      res[i].y = (uint32_t)f32_to_bf16(sacc[i][2]) | ((uint32_t)f32_to_bf16(sacc[i][3]) << 16);
     }
-    __syncthreads();         // Abuf / Wbuf free again (and cof complete)
+    rb_barrier();            // the raw image has been read (and cof is complete)
   } else {
-    __syncthreads();         // cof complete
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const uint2*>(px + (size_t)(b * NPX + i * 16 + fr) * BN + c0);
+    rb_barrier();            // cof complete
   }
-  load_w(reinterpret_cast<const bf16_t*>(p.s[0].w), Cin, 0);  // first slab of conv1 flies during the activation
   {
     const IdfResblockStage& s = p.s[0];
 #pragma unroll
@@ -215,151 +280,158 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
           scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
         }
         const unsigned e0 = (unsigned)((b * NPX + pl) * Cin + c);
-        const uint4 o = act_vec(xraw[k], scv, shv, s.drop && drop_any, seedv, s.salt, thr, dscale, e0 >> 3);
+        const uint4 o = act_vec(make_uint4(xraw[k][0], xraw[k][1], xraw[k][2], xraw[k][3]), scv, shv, s.drop && drop_any, seedv,
+                                s.salt, thr, dscale, e0 >> 3);
         *reinterpret_cast<uint4*>(a_slot(pl, c)) = o;
         if (s.a_out) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(s.a_out) + e0) = o;
       }
   }
+  rb_barrier();              // the activated image of conv1 is in place
+  RB_STAMP(t_s0);
+  RB_ADD(0, t_begin, t_s0);
+  RB_ADD(7, 0ull, 1ull);
 
-  // ---- the conv stages
-  const int cc = (tid & 15) * 8;                             // this thread's 8 couts in the element-wise passes (fixed)
-  // (the stage index is a compile-time constant in each copy of the body: p.s[] is then read from the kernel arguments,
-  // not from a scratch copy of the struct)
+  // ---- the conv stages.  (The stage index is a compile-time constant in each copy of the body: p.s[] is then read from
+  // the kernel arguments, not from a scratch copy of the struct.)
   auto run_stage = [&](auto ST) __attribute__((always_inline)) {
     constexpr int st = decltype(ST)::value;
     const IdfResblockStage& s = p.s[st];
     const IdfResblockStage& nx = p.s[st + 1 < 3 ? st + 1 : 2];
-    const int cin = st == 0 ? Cin : BN, nck = cin / CK;
+    const int cin = st == 0 ? Cin : BN, nck = cin / CK;      // 4 or 8 chunks: always even
     const bool last = st + 1 == p.nstage;
-    f32x4_t acc[2][2];
+    const bf16_t* const wp = reinterpret_cast<const bf16_t*>(s.w);
+    // what the epilogue needs from memory does not depend on the conv: fetched now, used after the MFMAs
+    const float4 bias4 = *reinterpret_cast<const float4*>(s.bias + c0);
+    float4 gam4 = make_float4(1.f, 1.f, 1.f, 1.f), bet4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ft0 = make_float4(0.f, 0.f, 0.f, 0.f), ft1 = ft0, fa0 = ft0, fa1 = ft0;
+    if (!last) {
+      if (nx.gamma) gam4 = *reinterpret_cast<const float4*>(nx.gamma + c0);
+      if (nx.beta) bet4 = *reinterpret_cast<const float4*>(nx.beta + c0);
+      if (nx.film_t) { ft0 = *reinterpret_cast<const float4*>(nx.film_t + (size_t)b * nx.ld_t + c0); ft1 = *reinterpret_cast<const float4*>(nx.film_t + (size_t)b * nx.ld_t + BN + c0); }
+      if (nx.film_a) { fa0 = *reinterpret_cast<const float4*>(nx.film_a + (size_t)b * nx.ld_a + c0); fa1 = *reinterpret_cast<const float4*>(nx.film_a + (size_t)b * nx.ld_a + BN + c0); }
+    }
+    f32x4_t acc[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    RB_STAMP(t_c0);
+    const int ncp = nck / 2;                   // 2 or 4 chunk pairs
+    for (int cp = 0; cp < ncp; ++cp) {
+      // where this lane's fragments of the NEXT pair live (the next stage's first pair behind this stage's last)
+      const bf16_t* nb = nullptr;
+      int ncin = cin, ncp_i = cp + 1;
+      if (cp + 1 < ncp) nb = wp;
+      else if (!last) { ncin = BN; ncp_i = 0; nb = reinterpret_cast<const bf16_t*>(nx.w); }
+      // 18 steps (9 taps x 2 chunks); the pixel fragments of step k + 1 are requested before the MFMAs of step k are issued
+      // (left to itself hipcc issued read -> wait -> MFMA one at a time: the LDS latency sat in front of every MFMA)
+      const unsigned char* X0 = Abuf + (size_t)(2 * cp) * CHB;
+      bf16x8_t xfA[4], xfB[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int ck = 0; ck < nck; ++ck) {
-      store_w();
-      __syncthreads();       // slab in place; the activated image (written before the loop / by the previous epilogue) too
-      if (ck + 1 < nck) load_w(reinterpret_cast<const bf16_t*>(s.w), cin, ck + 1);
-      else if (!last) load_w(reinterpret_cast<const bf16_t*>(nx.w), BN, 0);          // the next stage's first slab travels through its epilogue
-      const unsigned char* Xs = Abuf + (size_t)ck * NPH * 64;
+      for (int i = 0; i < 4; ++i) xfA[i] = *reinterpret_cast<const bf16x8_t*>(X0 + aoff(hbase[i], fq));
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (tap / 3) * WH + (tap % 3);
-        bf16x8_t wf[2], xf[2];
+      for (int k = 0; k < 18; ++k) {
+        const int half = k & 1, tap = k >> 1;      // tap major: the two halves of a 128-byte weight line are loaded back to back
+        bf16x8_t (&cur)[4] = (k & 1) ? xfB : xfA;
+        bf16x8_t (&nxt)[4] = (k & 1) ? xfA : xfB;
+        if (k + 1 < 18) {
+          const int nh = (k + 1) & 1, nt = (k + 1) >> 1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Wbuf + tap * BN * 64 + wbase[a]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int h = hbase[i] + toff;
-          xf[i] = *reinterpret_cast<const bf16x8_t*>(Xs + h * 64 + swz(h, fq) * 16);
+          for (int i = 0; i < 4; ++i)
+            nxt[i] = *reinterpret_cast<const bf16x8_t*>(X0 + (size_t)nh * CHB + aoff(hbase[i] + (nt / 3) * WH + (nt % 3), fq));
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-    // ---- epilogue: fp32 tile (+ bias, + the shortcut) -> Hbuf (the weight slab is dead); the order of the additions is the
-    // per-op path's: (acc + bias) + residual, the shortcut rounded to bf16 first (it was a tensor of its own there)
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int nl = wn0 + a * 16 + fq * 4;
-      const float4 bb = *reinterpret_cast<const float4*>(s.bias + nl);
-      const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-      float bsv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (last && p.w_sc && p.b_sc) {
-        const float4 bs = *reinterpret_cast<const float4*>(p.b_sc + nl);
-        bsv[0] = bs.x; bsv[1] = bs.y; bsv[2] = bs.z; bsv[3] = bs.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[a][i][r] += bbv[r];
-          if (last && p.w_sc) acc[a][i][r] += bf16_to_f32(f32_to_bf16(sacc[a][i][r] + bsv[r]));
-        }
-        const int pl = wm0 + i * 16 + fr;
-        *reinterpret_cast<float4*>(Hbuf + pl * PF + nl) = make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA.t[tap][half], cur[i], acc[i], 0, 0, 0);
+        if (nb) wA.t[tap][half] = *reinterpret_cast<const bf16x8_t*>(wptr(nb, ncin, ncp_i, tap, half));
+        // pin the step: without this the scheduler sinks each weight re-load down to its use in the next pair (a full memory
+        // latency in front of every tap) and undoes the read-ahead of the pixel fragments
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
-    float ssum[8], ssq[8];
+    RB_STAMP(t_c1);
+    RB_ADD(1 + 2 * st, t_c0, t_c1);
+    // ---- epilogue, in the wave's registers.  Additions in the per-op path's order: (acc + bias) + residual, the shortcut
+    // rounded to bf16 first (it was a tensor of its own there).  A lane holds couts c0 .. c0 + 3 of pixels i * 16 + fr.
+    const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+    float hr[4][4];            // the stage's output as a reader of the tensor sees it (rounded to bf16)
+    uint2 hp[4];
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
-    uint4 hv[2];             // this thread's two output vectors (pixels tid / 16 and tid / 16 + 32), bf16
+    for (int i = 0; i < 4; ++i) {
+      float o[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int pl = (tid >> 4) + kk * 32;
-      float o[8];
-      const float4 v0 = *reinterpret_cast<const float4*>(Hbuf + pl * PF + cc), v1 = *reinterpret_cast<const float4*>(Hbuf + pl * PF + cc + 4);
-      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-      const size_t e0 = (size_t)(b * NPX + pl) * BN + cc;
-      if (last && !p.w_sc) {                                 // identity residual: the raw block input
-        float r[8];
-        Vec16<bf16_t>::load(px + e0, r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      for (int r = 0; r < 4; ++r) o[r] = acc[i][r] + bb[r];
+      if (last) {
+        o[0] += __uint_as_float(res[i].x << 16); o[1] += __uint_as_float(res[i].x & 0xffff0000u);
+        o[2] += __uint_as_float(res[i].y << 16); o[3] += __uint_as_float(res[i].y & 0xffff0000u);
       }
-      uint32_t w4[4];
+      hp[i].x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+      hp[i].y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      hr[i][0] = __uint_as_float(hp[i].x << 16); hr[i][1] = __uint_as_float(hp[i].x & 0xffff0000u);
+      hr[i][2] = __uint_as_float(hp[i].y << 16); hr[i][3] = __uint_as_float(hp[i].y & 0xffff0000u);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w4[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
-      hv[kk] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      for (int r = 0; r < 4; ++r) { ssum[r] += hr[i][r]; ssq[r] += hr[i][r] * hr[i][r]; }
+      if (s.h_out) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(s.h_out) + (size_t)(b * NPX + i * 16 + fr) * BN + c0) = hp[i];
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                          // statistics of what a reader of the tensor sees (rounded)
-        const float lo = __uint_as_float(w4[i] << 16), hi = __uint_as_float(w4[i] & 0xffff0000u);
-        ssum[2 * i] += lo; ssq[2 * i] += lo * lo; ssum[2 * i + 1] += hi; ssq[2 * i + 1] += hi * hi;
+    for (int r = 0; r < 4; ++r) { ssum[r] = row16_sum(ssum[r]); ssq[r] = row16_sum(ssq[r]); }      // over the wave's 64 pixels
+    if (last) {
+      if (p.st_out && fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reinterpret_cast<float2*>(p.st_out)[(size_t)b * BN + c0 + r] = make_float2(ssum[r], ssq[r]);
       }
-      if (s.h_out) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(s.h_out) + e0) = hv[kk];
+      RB_STAMP(t_e1);
+      RB_ADD(2 + 2 * st, t_c1, t_e1);
+      return;
     }
-    // lanes 16 apart hold the same couts: fold them, then the waves through LDS
+    // the next stage's GroupNorm: this lane's 4 couts ARE one group (128 channels / 32 groups)
+    float mf, rs;
+    group_stats((double)ssum[0] + (double)ssum[1] + (double)ssum[2] + (double)ssum[3],
+                (double)ssq[0] + (double)ssq[1] + (double)ssq[2] + (double)ssq[3], 1.0 / 256.0, p.eps, &mf, &rs);
+    const float ga[4] = {gam4.x, gam4.y, gam4.z, gam4.w}, be[4] = {bet4.x, bet4.y, bet4.z, bet4.w};
+    const float t0[4] = {ft0.x, ft0.y, ft0.z, ft0.w}, t1[4] = {ft1.x, ft1.y, ft1.z, ft1.w};
+    const float a0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, a1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
+    float scv[4], shv[4];
 #pragma unroll
-    for (int off = 32; off >= 16; off >>= 1)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], off, 64); ssq[e] += __shfl_xor(ssq[e], off, 64); }
-    if (lane < 16) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { part[(wave * BN + cc + e) * 2] = ssum[e]; part[(wave * BN + cc + e) * 2 + 1] = ssq[e]; }
+    for (int r = 0; r < 4; ++r) {
+      float sc = rs * ga[r], sh = be[r] - mf * sc;
+      if (nx.film_t) { const float f = 1.f + t0[r]; sc *= f; sh = sh * f + t1[r]; }
+      if (nx.film_a) { const float f = 1.f + a0[r]; sc *= f; sh = sh * f + a1[r]; }
+      scv[r] = sc; shv[r] = sh;
     }
-    __syncthreads();
-    if (tid < BN) {
-      float a = 0.f, q = 0.f;
-#pragma unroll
-      for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + tid) * 2]; q += part[(w * BN + tid) * 2 + 1]; }
-      chs[2 * tid] = a; chs[2 * tid + 1] = q;
-      if (last && p.st_out) reinterpret_cast<float2*>(p.st_out)[(size_t)b * BN + tid] = make_float2(a, q);
+    if (nx.sc && fr == 0) {
+      *reinterpret_cast<float4*>(nx.sc + (size_t)b * BN + c0) = make_float4(scv[0], scv[1], scv[2], scv[3]);
+      *reinterpret_cast<float4*>(nx.sh + (size_t)b * BN + c0) = make_float4(shv[0], shv[1], shv[2], shv[3]);
+      nx.mean[b * 32 + (c0 >> 2)] = mf; nx.rstd[b * 32 + (c0 >> 2)] = rs;
     }
-    if (last) return;
-    __syncthreads();
-    if (tid < BN) fold_channel(chs, tid, BN, b, nx, p.eps, cof);
-    __syncthreads();
-    {
-      float scv[8], shv[8];
+    const bool drop = nx.drop && drop_any;
+    uint2 ap[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * cc + 4 * q);
-        scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int pl = (tid >> 4) + kk * 32;
-        const unsigned e0 = (unsigned)((b * NPX + pl) * BN + cc);
-        const uint4 o = act_vec(hv[kk], scv, shv, nx.drop && drop_any, seedv, nx.salt, thr, dscale, e0 >> 3);
-        *reinterpret_cast<uint4*>(a_slot(pl, cc)) = o;
-        if (nx.a_out) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(nx.a_out) + e0) = o;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const unsigned e0 = (unsigned)((b * NPX + i * 16 + fr) * BN + c0);     // index in the dense activated tensor
+      const uint32_t h = drop ? idf_vec_hash(seedv, nx.salt, e0 >> 3) : 0u;
+      float v[4] = {hr[i][0], hr[i][1], hr[i][2], hr[i][3]};
+      idf_act_vec<4>(v, scv, shv, 2, drop, h, (int)(c0 & 7), thr, dscale);
+      ap[i].x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      ap[i].y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      if (nx.a_out) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(nx.a_out) + e0) = ap[i];
     }
-    // (the next stage's loop starts with store_w + barrier: Hbuf's readers are past it by then, Abuf's writes before it)
-    __syncthreads();
+    rb_barrier();              // every wave is past its last read of the activated image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint2*>(a_slot(i * 16 + fr, c0) + (c0 & 4) * 2) = ap[i];
+    rb_barrier();              // the next stage's image is in place
+    RB_STAMP(t_e2);
+    RB_ADD(2 + 2 * st, t_c1, t_e2);
   };
   run_stage(std::integral_constant<int, 0>{});
   run_stage(std::integral_constant<int, 1>{});
   if (p.nstage == 3) run_stage(std::integral_constant<int, 2>{});
-#undef load_w
-#undef store_w
 }
 
 }  // namespace
+#ifdef IDF_RB_STAMP
+extern "C" int idf_debug_rb_stamps(void** dev_addr) {
+  return hipGetSymbolAddress(dev_addr, HIP_SYMBOL(g_rb_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int idf_resblock_small_ok(int B, int H, int W, int Cin, int C1, int Cout, int nstage) {
   if (B <= 0 || H != 8 || W != 8 || Cout != BN || (Cin != 128 && Cin != 256) || (nstage != 2 && nstage != 3)) return 0;
@@ -384,7 +456,7 @@ extern "C" int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream)
       IDF_FAIL(IDF_ERR_BADARG, "resblock_small_fwd: mean / rstd / sc / sh go together (stage %d)", i);
   }
   if (p.s[p.nstage - 1].h_out != p.y) IDF_FAIL(IDF_ERR_BADARG, "resblock_small_fwd: the last stage's output is y");
-  const size_t lds = (size_t)(p.Cin / CK) * NPH * 64 + WSLAB + (size_t)(4 * MAXC + 8 * BN * 2) * sizeof(float);
+  const size_t lds = (size_t)(p.Cin / CK) * CHB + (size_t)(4 * MAXC) * sizeof(float);
   static IdfLdsGrant grant;
   if (hipError_t e = idf_ensure_lds((const void*)resblock8_fwd_kernel, lds, grant); e != hipSuccess)
     IDF_FAIL(IDF_ERR_HIP, "resblock_small_fwd: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));

@@ -1171,6 +1171,7 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
 # ------------------------------------------- image-resident ResBlock at the 8x8 maps
 _RB_SMALL = os.environ.get('IDF_RB_SMALL', '1') != '0'
 _RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '64'))     # one workgroup per image: pays while the batch leaves CUs idle
+_RB_WFRAG = os.environ.get('IDF_RB_WFRAG', '1') != '0'              # fragment-major weights (modules._Shadows.request_frag): 35.5 -> 23.2 us per block
 
 
 @functools.lru_cache(maxsize=None)
@@ -1219,11 +1220,18 @@ class _ResBlockSmall(torch.autograd.Function):
         st_out = torch.empty((B, 1, Cout, 2), dtype=torch.float32, device=dev)
         keep = []           # per stage: a, h (None for the last), mean, rstd, sc, sh
         p_drop = meta['p_drop'] if seed is not None else 0.0
+        # weights: the fragment-major shadows once every stage has one (requested at a conv's first pass through here, packed
+        # with the next re-pack of the network's shadows), the [cout][tap][cin] forward shadows until then
+        shadows = [cfgs[i]['shadows'](dt, train) for i in range(n)]
+        frag = _RB_WFRAG and all(v[2] is not None for v in shadows)
+        if _RB_WFRAG and not frag:
+            for i in range(n):
+                cfgs[i]['shadows'].request_frag()
         for i in range(n):
             w, b, gw, gb = tensors[4 * i:4 * i + 4]
             S = A.s[i]
             ci = Cin if i == 0 else Cout
-            S.w, S.bias = _p(cfgs[i]['shadows'](dt, train)[0]), _p(b)
+            S.w, S.bias = _p(shadows[i][2 if frag else 0]), _p(b)
             S.gamma, S.beta = _p(gw), _p(gb)
             ft, fa = (film_t, film_a) if i == meta['film_stage'] else (None, None)
             S.film_t, S.film_a, S.ld_t, S.ld_a = _p(ft), _p(fa), _ld(ft), _ld(fa)
@@ -1244,6 +1252,7 @@ class _ResBlockSmall(torch.autograd.Function):
             A.w_sc, A.b_sc = _p(meta['cfg_sc']['shadows'](dt, train)[0]), _p(tensors[4 * n + 1])
         A.y, A.st_out = _p(y), _p(st_out)
         A.seed, A.p_drop, A.eps, A.B = _p(seed), float(p_drop), GN_EPS, B
+        A.w_layout = 1 if frag else 0
         call('idf_resblock_small_fwd', ctypes.byref(A), _st())
         ctx.meta, ctx.p_drop = meta, p_drop
         ctx.save_for_backward(x, x2, film_t, film_a, seed, *keep, *tensors)

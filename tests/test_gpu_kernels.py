@@ -580,14 +580,17 @@ def test_resblock_small_one_launch_matches_the_per_op_path(kind, cin, dual, trai
         return y.detach().float().clone(), {k: v.detach().float().clone() for k, v in g.items() if v is not None}, fwd
 
     y_ref, g_ref, fwd_ref = run(False)
-    y_got, g_got, fwd_got = run(True)
     assert 'idf_resblock_small_fwd' not in fwd_ref and any(n.startswith('idf_conv_gn') for n in fwd_ref)
-    assert fwd_got.count('idf_resblock_small_fwd') == 1 and not any(n.startswith('idf_conv') for n in fwd_got), fwd_got
-    assert rel(y_got, y_ref) < 1e-2, rel(y_got, y_ref)
-    if train:
-        assert set(g_got) == set(g_ref) and len(g_ref) >= (8 if kind == 'enc' else 12)
-        for k in g_ref:
-            assert rel(g_got[k], g_ref[k]) < 2e-2, (k, rel(g_got[k], g_ref[k]))
+    # twice: the first fused pass reads the [cout][tap][cin] shadows and asks for fragment-major ones, the second reads those
+    for attempt in range(2):
+        assert (blk._sh_block1.val[2] is not None) == (attempt == 1)
+        y_got, g_got, fwd_got = run(True)
+        assert fwd_got.count('idf_resblock_small_fwd') == 1 and not any(n.startswith('idf_conv') for n in fwd_got), fwd_got
+        assert rel(y_got, y_ref) < 1e-2, (attempt, rel(y_got, y_ref))
+        if train:
+            assert set(g_got) == set(g_ref) and len(g_ref) >= (8 if kind == 'enc' else 12)
+            for k in g_ref:
+                assert rel(g_got[k], g_ref[k]) < 2e-2, (attempt, k, rel(g_got[k], g_ref[k]))
 
 
 def test_wgrad_batch_survives_a_backward_pass_that_raised():

@@ -16,5 +16,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_$c -- python3 bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-sampling --no-large-batch > $out/${tag}_$c.log 2>&1
 done
 python tools/pmc_traffic.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_traffic.json
+# MFMA-pipe counters of the same eager steps (their own pass: --pmc with --kernel-trace only)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $out/${tag}_MFMA -- python3 bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-sampling --no-large-batch > $out/${tag}_MFMA.log 2>&1
+python tools/pmc_mfma.py $out/${tag}_MFMA $out/${tag}_pmc_mfma.json > $out/${tag}_pmc_mfma.txt
+rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_MFMA
 rm -rf $out/${tag}_p1 $out/${tag}_p2      # the databases are large; the summaries above are what is kept
 ls -la $out | grep ${tag}_

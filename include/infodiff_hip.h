@@ -173,6 +173,26 @@ typedef struct {
   int w_layout;             /* 0: s[i].w is the forward shadow [128][9][Cin_i]; 1: the fragment-major shadow (idf_pack_conv_weights_batched) */
 } IdfResblockArgs;
 int idf_resblock_small_ok(int B, int H, int W, int Cin, int C1, int Cout, int nstage);
+
+/* ---- per-op 3x3 convs of the 16x16 / 8x8 maps with fragment-major weights (round 4): a workgroup = 4 waves x 16 couts over
+ * 64 pixels (4 rows of a 16x16 map, a whole 8x8 map) or a whole 16x16 map; weights straight into registers, the input of all
+ * channel chunks in LDS, no workgroup barrier in the conv loop, the epilogue in the wave's registers.
+ * idf_conv_wr_gn_bf16: idf_conv_gn_bf16's contract for act 2 (SiLU), taps 9: y = conv(dropout(SiLU(FiLM(GN(x | x2))))) + bias
+ * (+ res), training outputs a_out / mean / rstd / sc / sh, st_out [B][idf_conv_wr_tiles(.., 0)][Cout][2].
+ * idf_conv_wr_dgrad_gn_bf16: idf_conv_dgrad_gn_bf16's contract (act 2, taps 9) on a whole image per workgroup.
+ * idf_conv_wr_tiles: pixel tiles per image of the forward form (whole = 0) / 1 when the whole-image form covers the shape
+ * (whole = 1); 0: not covered (H = W in {8, 16}, Cin in {64, 128, 256}, Cout % 64 == 0, Cout <= 256). */
+int idf_conv_wr_tiles(int B, int H, int W, int Cin, int Cout, int whole);
+int idf_conv_wr_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                        const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
+                        float eps, const uint64_t* seed, uint32_t salt, float p_drop, const void* w_frag, const float* bias,
+                        const void* res, void* y, void* a_out, float* mean, float* rstd, float* sc, float* sh, float* st_out,
+                        int B, int H, int W, int Cin, int Cout, void* stream);
+int idf_conv_wr_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x, const void* dres, const void* dres2, void* dx,
+                              const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                              int ld_a, const float* mean, const float* rstd, const float* sc, const float* sh, float* dfilm_t,
+                              float* dfilm_a, float* dgb, float* dgamma_acc, float* dbeta_acc, const uint64_t* seed,
+                              uint32_t salt, float p_drop, int B, int H, int W, int Cin, int Cout, void* stream);
 int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
 int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T, const float* in_mean,
                               const float* in_rstd, const float* in_sc, const float* in_gamma, const float* in_beta,
@@ -262,11 +282,14 @@ int idf_pack_conv_weight(const float* src, long so, long si, long st, void* w_fw
                          int taps, int dtype, void* stream);
 
 /* the same for every conv of a network in one launch.  table (device): nrows x
- * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long tile; void* w_frag}
+ * {const float* src; void* w_fwd; void* w_dgrad; long so, si, st; int O, I, taps, Ototal, o0; long tile; void* w_frag;
+ *  void* w_dgrad_frag}
  * -- one block per row = one (tap, 32-cout, 64-cin) tile, tile = tap | cout_tile << 8 | cin_tile << 32;
  * Ototal/o0 place a source tensor inside a concatenated (q|k|v) shadow.  w_frag (optional; 3x3, O % 16 == 0, I % 64 == 0):
  * a third shadow, the forward weights fragment-major for idf_resblock_small_fwd (IdfResblockArgs.w_layout = 1):
- * [I / 64][O / 16][tap][half][lane = fq * 16 + fr][8] with o = 16 * (O / 16 index) + fr, i = 64 * pair + 32 * half + 8 * fq + e. */
+ * [I / 64][O / 16][tap][half][lane = fq * 16 + fr][8] with o = 16 * (O / 16 index) + fr, i = 64 * pair + 32 * half + 8 * fq + e;
+ * w_dgrad_frag (optional; 3x3, I % 16 == 0, Ototal % 64 == 0): the data-gradient weights in the same form (for
+ * idf_conv_wr_dgrad_gn_bf16). */
 int idf_pack_conv_weights_batched(const void* table, int nrows, int dtype, void* stream);
 
 /* ---- GroupNorm(32) + AdaGN/FiLM fold (modules.py:132, 214-228, 312-318; nn.GroupNorm eps 1e-5)

@@ -322,6 +322,8 @@ struct PackDesc {
                           // image-resident ResBlock kernel (idf_resblock.hip): [I / 64][O / 16][tap][half][lane = fq * 16 + fr][8]
                           // with o = 16 * wave + fr, i = 64 * pair + 32 * half + 8 * fq + e -- a wave's A fragment is 1 KB of
                           // consecutive bytes
+  void* wdfrag;           // optional fourth shadow (3x3, I % 16 == 0, Ototal % 64 == 0): the data-gradient weights [I][taps
+                          // flipped][O] in the same fragment-major form (their "cout" is i, their "cin" is o)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __restrict__ tab) {
@@ -351,8 +353,15 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __res
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     int i = ib + (tid >> 5) + k * 8, o = ob + (tid & 31);
-    if (o < d.O && i < d.I)
-      Elem<T>::st(wd + ((size_t)i * d.taps + (d.taps - 1 - tap)) * d.Ototal + d.o0 + o, tile[tid & 31][(tid >> 5) + k * 8]);
+    if (o < d.O && i < d.I) {
+      const float v = tile[tid & 31][(tid >> 5) + k * 8];
+      Elem<T>::st(wd + ((size_t)i * d.taps + (d.taps - 1 - tap)) * d.Ototal + d.o0 + o, v);
+      if (d.wdfrag) {
+        const int kk = d.o0 + o, pair = kk >> 6, half = (kk >> 5) & 1, fq = (kk >> 3) & 3, e = kk & 7, wave = i >> 4, fr = i & 15;
+        Elem<T>::st(reinterpret_cast<T*>(d.wdfrag) +
+                        ((((size_t)(pair * (d.I >> 4) + wave) * d.taps + (d.taps - 1 - tap)) * 2 + half) * 64 + fq * 16 + fr) * 8 + e, v);
+      }
+    }
   }
 }
 

@@ -426,7 +426,386 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
   if (p.nstage == 3) run_stage(std::integral_constant<int, 2>{});
 }
 
+// =====================================================================================================================
+// Per-op 3x3 convs of the small maps (16x16, 8x8) in the same form: a workgroup = 4 waves x 16 couts (a 64-cout tile) over a
+// pixel tile of 64 pixels (4 rows of a 16x16 map / a whole 8x8 map) or 256 pixels (a whole 16x16 map); the weights come
+// fragment-major straight into registers, the activated input of ALL channel chunks lies in LDS (pitch-96 image, immediates
+// for every tap), the conv loop has no workgroup barrier, the epilogue works in the wave's registers:
+//   PRO:  y = conv(dropout(SiLU(FiLM(GroupNorm(x | x2))))) + bias (+ res), statistics partials of y   (idf_conv_gn_bf16's job)
+//   GNB:  dx = GroupNormBackward(conv(dy, w_dgrad)) (+ dres + dres2) on a whole-image tile           (idf_conv_dgrad_gn_bf16's)
+// Replaces the register-staged halo kernel's 64-pixel launches at these levels (19.8 / 13.5 us per launch at B = 32).
+struct WrP {
+  const bf16_t* x; const bf16_t* x2; int C1, Cin;         // conv input (x | x2), [B, H, W, .]
+  const bf16_t* w; int Cout;                              // fragment-major weights, all couts
+  int B, H, tiles_per_img, n_tiles;
+  // PRO
+  const float* st1; const float* st2; int T1, T2;
+  const float* gamma; const float* beta; const float* film_t; const float* film_a; int ld_t, ld_a;
+  float eps; const uint64_t* seed; uint32_t salt, thr; float dscale;
+  bf16_t* a_out; float* mean_out; float* rstd_out; float* sc_out; float* sh_out;
+  // plain epilogue
+  const float* bias; const bf16_t* res; bf16_t* y; float* st_out;
+  // GNB epilogue: y = dx, res / res2 = branch gradients, gamma .. dscale as above describe the GroupNorm being differentiated
+  const bf16_t* gx; const bf16_t* res2; const float* gsc; const float* gsh; const float* gmean; const float* grstd;
+  float* dfilm_t; float* dfilm_a; float* dgb; float* dgam; float* dbet;
+};
+
+template <bool W16, int NF, bool PRO, bool GNB>
+__global__ __launch_bounds__(256) void conv_wr_kernel(const WrP p) {
+  constexpr int W = W16 ? 16 : 8, WHP = W16 ? 18 : 16, R = NF * 16 / W, HR = R + 2, WH2 = W + 2;
+  constexpr int CHBW = HR * WHP * PPB;                      // bytes of one chunk image
+  constexpr int FRS = W16 ? WHP : 32;                       // halo pixels between the first pixels of consecutive fragments
+  constexpr int PB = NF * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Cin = p.Cin, nck = Cin / CK;
+  unsigned char* const Abuf = smem;
+  float* const cof = reinterpret_cast<float*>(smem + (size_t)nck * CHBW);     // PRO: [Cin][2] | chs [Cin][2]
+  float* const chs = cof + 2 * MAXC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x - tile * p.n_tiles) * 64;
+  const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
+  const int c0 = n0 + wave * 16 + fq * 4;                   // the 4 couts this lane holds in the MFMA output
+  const int wg = (n0 >> 4) + wave;                          // this wave's 16-cout slice of the fragment-major weights
+  const bool drop = (PRO || GNB) && p.seed != nullptr;
+  const uint64_t seedv = drop ? *p.seed : 0;
+
+  auto wptr = [&](int cp, int tap, int half) __attribute__((always_inline)) -> const bf16_t* {
+    return p.w + ((size_t)((cp * (p.Cout >> 4) + wg) * 18 + tap * 2 + half) * 64 + lane) * 8;
+  };
+  WPair wA;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    wA.t[tap][0] = *reinterpret_cast<const bf16x8_t*>(wptr(0, tap, 0));
+    wA.t[tap][1] = *reinterpret_cast<const bf16x8_t*>(wptr(0, tap, 1));
+  }
+  // GNB: the GroupNorm input in the MFMA output layout (8 bytes per lane and fragment), fetched ahead of the conv
+  uint2 gxr[GNB ? NF : 1];
+  if constexpr (GNB) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      gxr[i] = *reinterpret_cast<const uint2*>(p.gx + ((size_t)tile * PB + i * 16 + fr) * p.Cout + c0);
+  }
+
+  // ---- the input tile -> LDS, every chunk.  PRO: statistics fold first, act(x * sc + sh) on the way in.
+  if constexpr (PRO) {
+    for (int c = tid; c < Cin; c += 256) {
+      const float* st = p.st1;
+      int T = p.T1, Cs = p.x2 ? p.C1 : Cin, cl = c;
+      if (p.x2 && c >= p.C1) { st = p.st2; T = p.T2; Cs = Cin - p.C1; cl = c - p.C1; }
+      const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(st) + (size_t)b * T * Cs + cl, T, (size_t)Cs);
+      chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
+    }
+  }
+  const int vshift = Cin == 256 ? 5 : (Cin == 128 ? 4 : 3);      // log2(Cin / 8) (Cin 64, 128 or 256)
+  const int nitems = (HR * WH2) << vshift;
+  auto item = [&](int v, int& hp, int& c, bool& ok, const bf16_t*& src) __attribute__((always_inline)) {
+    const int pix = v >> vshift;
+    c = (v - (pix << vshift)) * 8;
+    const int hy = pix / WH2, hx = pix - hy * WH2;
+    hp = hy * WHP + hx;
+    const int iy = oy0 + hy - 1, ix = hx - 1;
+    ok = v < nitems && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+    const size_t gp = (size_t)(b * p.H + iy) * W + ix;
+    src = (p.x2 && c >= p.C1) ? p.x2 + gp * (Cin - p.C1) + (c - p.C1) : p.x + gp * (p.x2 ? p.C1 : Cin) + c;
+  };
+  constexpr int BATCH = 8;
+  u32x4_t xr[BATCH];
+  {     // first batch in flight across the fold
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      int hp, c; bool ok; const bf16_t* src;
+      item(tid + k * 256, hp, c, ok, src);
+      xr[k] = ok ? *reinterpret_cast<const u32x4_t*>(src) : u32x4_t{0, 0, 0, 0};
+    }
+  }
+  if constexpr (PRO) {
+    rb_barrier();
+    const int cpg = Cin >> 5;
+    for (int c = tid; c < Cin; c += 256) {
+      const int g = c / cpg;
+      double a = 0.0, d = 0.0;
+      for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
+      float mf, r;
+      group_stats(a, d, 1.0 / ((double)p.H * W * cpg), p.eps, &mf, &r);
+      const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+      float sc = r * ga, sh = be - mf * sc;
+      if (p.film_t) { const float f = 1.f + p.film_t[(size_t)b * p.ld_t + c]; sc *= f; sh = sh * f + p.film_t[(size_t)b * p.ld_t + Cin + c]; }
+      if (p.film_a) { const float f = 1.f + p.film_a[(size_t)b * p.ld_a + c]; sc *= f; sh = sh * f + p.film_a[(size_t)b * p.ld_a + Cin + c]; }
+      cof[2 * c] = sc; cof[2 * c + 1] = sh;
+      if (p.sc_out && oy0 == 0 && n0 == 0) {
+        p.sc_out[(size_t)b * Cin + c] = sc; p.sh_out[(size_t)b * Cin + c] = sh;
+        if (c == g * cpg) { p.mean_out[b * 32 + g] = mf; p.rstd_out[b * 32 + g] = r; }
+      }
+    }
+    rb_barrier();
+  }
+  for (int v0 = 0; v0 < nitems; v0 += BATCH * 256) {
+    u32x4_t nx[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      int hp, c; bool ok; const bf16_t* src;
+      item(v0 + BATCH * 256 + tid + k * 256, hp, c, ok, src);
+      nx[k] = ok ? *reinterpret_cast<const u32x4_t*>(src) : u32x4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      int hp, c; bool ok; const bf16_t* src;
+      const int v = v0 + tid + k * 256;
+      item(v, hp, c, ok, src);
+      if (v < nitems) {
+        u32x4_t o = xr[k];
+        if (PRO && ok) {
+          float scv[8], shv[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * c + 4 * q);
+            scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
+          }
+          const int pix = v >> vshift, hy = pix / WH2, hx = pix - hy * WH2;
+          const unsigned e0 = (unsigned)(((b * p.H + oy0 + hy - 1) * W + hx - 1) * Cin + c);
+          const uint4 a4 = act_vec(make_uint4(o[0], o[1], o[2], o[3]), scv, shv, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+          o = u32x4_t{a4.x, a4.y, a4.z, a4.w};
+          if (p.a_out && n0 == 0 && (unsigned)(hy - 1) < (unsigned)R) *reinterpret_cast<u32x4_t*>(p.a_out + e0) = o;
+        }
+        *reinterpret_cast<u32x4_t*>(Abuf + (size_t)(c >> 5) * CHBW + aoff(hp, (c & 31) >> 3)) = o;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) xr[k] = nx[k];
+  }
+  rb_barrier();
+
+  // ---- the conv: 18 steps per 64-channel pair, 4 fragments per sub-step, pixel fragments read one sub-step ahead
+  f32x4_t acc[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int lbase = (W16 ? fr : ((fr >> 3) * 16 + (fr & 7))) * PPB + fq * 16;
+  const int ncp = nck / 2;
+  constexpr int NSUB = NF / 4;
+  for (int cp = 0; cp < ncp; ++cp) {
+    const unsigned char* X0 = Abuf + (size_t)(2 * cp) * CHBW + lbase;
+    const bool more = cp + 1 < ncp;
+    bf16x8_t xfA[4], xfB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xfA[j] = *reinterpret_cast<const bf16x8_t*>(X0 + (size_t)(j * FRS) * PPB);
+#pragma unroll
+    for (int k = 0; k < 18 * NSUB; ++k) {
+      const int step = k / NSUB, sub = k % NSUB, half = step & 1, tap = step >> 1;
+      bf16x8_t (&cur)[4] = (k & 1) ? xfB : xfA;
+      bf16x8_t (&nxt)[4] = (k & 1) ? xfA : xfB;
+      if (k + 1 < 18 * NSUB) {
+        const int ns = (k + 1) / NSUB, nsub = (k + 1) % NSUB, nh = ns & 1, nt = ns >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          nxt[j] = *reinterpret_cast<const bf16x8_t*>(X0 + (size_t)nh * CHBW + (size_t)((nsub * 4 + j) * FRS + (nt / 3) * WHP + (nt % 3)) * PPB);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[sub * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA.t[tap][half], cur[j], acc[sub * 4 + j], 0, 0, 0);
+      if (sub == NSUB - 1 && more) wA.t[tap][half] = *reinterpret_cast<const bf16x8_t*>(wptr(cp + 1, tap, half));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  const size_t gp0 = (size_t)tile * PB;                      // first pixel of the tile in [B * H * W] (tiles are whole rows)
+  if constexpr (!GNB) {
+    // ---- plain epilogue: (acc + bias) + residual, rounded; statistics partial of the tile
+    const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const size_t e = (gp0 + i * 16 + fr) * p.Cout + c0;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = acc[i][r] + bb[r];
+      if (p.res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + e);
+        o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+        o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      uint2 hp2;
+      hp2.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+      hp2.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      *reinterpret_cast<uint2*>(p.y + e) = hp2;
+      const float h0 = __uint_as_float(hp2.x << 16), h1 = __uint_as_float(hp2.x & 0xffff0000u);
+      const float h2 = __uint_as_float(hp2.y << 16), h3 = __uint_as_float(hp2.y & 0xffff0000u);
+      ssum[0] += h0; ssq[0] += h0 * h0; ssum[1] += h1; ssq[1] += h1 * h1;
+      ssum[2] += h2; ssq[2] += h2 * h2; ssum[3] += h3; ssq[3] += h3 * h3;
+    }
+    if (p.st_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ssum[r] = row16_sum(ssum[r]); ssq[r] = row16_sum(ssq[r]); }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reinterpret_cast<float2*>(p.st_out)[(size_t)tile * p.Cout + c0 + r] = make_float2(ssum[r], ssq[r]);
+      }
+    }
+  } else {
+    // ---- GroupNorm backward on the accumulator tile (the tile is a whole image): gnb_epilogue's algebra (idf_conv3x3.hip)
+    // in the wave's registers.  A lane holds channels c0 .. c0 + 3 of pixels i * 16 + fr; a GroupNorm group is cpg = C / 32
+    // channels: this lane's 4 (C = 128), or those of two neighbouring lane groups (C = 256).
+    const int C = p.Cout, cpg = C >> 5, g = c0 / cpg;
+    const float4 sc4 = *reinterpret_cast<const float4*>(p.gsc + (size_t)b * C + c0), sh4 = *reinterpret_cast<const float4*>(p.gsh + (size_t)b * C + c0);
+    const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float mu = p.gmean[b * 32 + g], rs = p.grstd[b * 32 + g];
+    float ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, stv[4] = {0.f, 0.f, 0.f, 0.f}, btv[4] = {0.f, 0.f, 0.f, 0.f},
+          sav[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.gamma) { const float4 t = *reinterpret_cast<const float4*>(p.gamma + c0); ga[0] = t.x; ga[1] = t.y; ga[2] = t.z; ga[3] = t.w; }
+    if (p.beta) { const float4 t = *reinterpret_cast<const float4*>(p.beta + c0); be[0] = t.x; be[1] = t.y; be[2] = t.z; be[3] = t.w; }
+    if (p.film_t) {
+      const float4 t = *reinterpret_cast<const float4*>(p.film_t + (size_t)b * p.ld_t + c0), u = *reinterpret_cast<const float4*>(p.film_t + (size_t)b * p.ld_t + C + c0);
+      stv[0] = t.x; stv[1] = t.y; stv[2] = t.z; stv[3] = t.w; btv[0] = u.x; btv[1] = u.y; btv[2] = u.z; btv[3] = u.w;
+    }
+    if (p.film_a) { const float4 t = *reinterpret_cast<const float4*>(p.film_a + (size_t)b * p.ld_a + c0); sav[0] = t.x; sav[1] = t.y; sav[2] = t.z; sav[3] = t.w; }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      float xv[4] = {__uint_as_float(gxr[i].x << 16), __uint_as_float(gxr[i].x & 0xffff0000u),
+                     __uint_as_float(gxr[i].y << 16), __uint_as_float(gxr[i].y & 0xffff0000u)};
+      float dav[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, du[4];
+      const size_t e0 = (gp0 + i * 16 + fr) * C + c0;
+      const uint32_t h = drop ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
+      if (drop) idf_dact_vec_t<4, true, true>(dav, xv, scv, shv, h, (int)(c0 & 7), p.thr, p.dscale, du);
+      else idf_dact_vec_t<4, true, false>(dav, xv, scv, shv, h, (int)(c0 & 7), p.thr, p.dscale, du);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] += du[r]; s2[r] += du[r] * xv[r]; acc[i][r] = du[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+    float P1 = 0.f, P2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float D1 = s1[r], D2 = rs * (s2[r] - mu * s1[r]);
+      const float f = (1.f + stv[r]) * (1.f + sav[r]);
+      const float Gf = ga[r] * D2 + be[r] * D1, Ge = D1;
+      if (fr == 0) {
+        const int c = c0 + r;
+        if (p.dfilm_t) { p.dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sav[r]); p.dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sav[r]); }
+        if (p.dfilm_a) { p.dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + stv[r]) + Ge * btv[r]; p.dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
+        if (p.dgb) { p.dgb[((size_t)b * 2 + 0) * C + c] = f * D2; p.dgb[((size_t)b * 2 + 1) * C + c] = f * D1; }
+        if (p.dgam) atomicAdd(p.dgam + c, f * D2);
+        if (p.dbet) atomicAdd(p.dbet + c, f * D1);
+      }
+      P1 += ga[r] * f * D1; P2 += ga[r] * f * D2;
+    }
+    if (cpg == 8) { P1 += __shfl_xor(P1, 16, 64); P2 += __shfl_xor(P2, 16, 64); }       // the group's other 4 channels
+    const float invN = 1.f / ((float)PB * cpg);
+    const float k1 = -rs * rs * P2 * invN, k0 = (-rs * P1 + rs * rs * mu * P2) * invN;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const size_t e0 = (gp0 + i * 16 + fr) * C + c0;
+      const float xv[4] = {__uint_as_float(gxr[i].x << 16), __uint_as_float(gxr[i].x & 0xffff0000u),
+                           __uint_as_float(gxr[i].y << 16), __uint_as_float(gxr[i].y & 0xffff0000u)};
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = scv[r] * acc[i][r] + k1 * xv[r] + k0;
+      if (p.res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + e0);
+        o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+        o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      if (p.res2) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res2 + e0);
+        o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+        o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      uint2 ov;
+      ov.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+      ov.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      *reinterpret_cast<uint2*>(p.y + e0) = ov;
+    }
+  }
+}
+
+template <bool W16, int NF, bool PRO, bool GNB>
+int launch_wr(const WrP& p, hipStream_t st) {
+  constexpr int WHP = W16 ? 18 : 16, R = NF * 16 / (W16 ? 16 : 8);
+  const size_t lds = (size_t)(p.Cin / CK) * (R + 2) * WHP * PPB + (PRO ? (size_t)4 * MAXC * sizeof(float) : 0);
+  if (lds > 160 * 1024) return 1;
+  auto kern = conv_wr_kernel<W16, NF, PRO, GNB>;
+  static IdfLdsGrant grant;
+  if (idf_ensure_lds((const void*)kern, lds, grant) != hipSuccess) return 2;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(256), lds, st, p);
+  return 0;
+}
+
+// coverage of the forms above: tiles per image (= T of the statistics partials) or 0.  whole != 0: the tile must be the image
+int wr_tiles(int B, int H, int W, int Cin, int Cout, int whole) {
+  if (B <= 0 || H != W || (W != 8 && W != 16) || (Cin != 64 && Cin != 128 && Cin != 256) || (Cout % 64) || Cout > 256) return 0;
+  if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
+  if (W == 8) return 1;
+  if (whole) return Cin <= 128 ? 1 : 0;       // a 16x16 image of 256 channels does not fit LDS in one piece
+  return 4;
+}
+
 }  // namespace
+
+extern "C" int idf_conv_wr_tiles(int B, int H, int W, int Cin, int Cout, int whole) { return wr_tiles(B, H, W, Cin, Cout, whole); }
+
+// y = conv3x3(dropout(SiLU(FiLM(GroupNorm(x | x2))))) + bias (+ res): idf_conv_gn_bf16's contract (act 2, taps 9) on 16x16 / 8x8
+// maps with the weights fragment-major (idf_pack_conv_weights_batched's w_frag); st_out [B][idf_conv_wr_tiles(..., 0)][Cout][2].
+extern "C" int idf_conv_wr_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
+                                   const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t,
+                                   int ld_a, float eps, const uint64_t* seed, uint32_t salt, float p_drop, const void* w_frag,
+                                   const float* bias, const void* res, void* y, void* a_out, float* mean, float* rstd, float* sc,
+                                   float* sh, float* st_out, int B, int H, int W, int Cin, int Cout, void* stream) {
+  const int T = wr_tiles(B, H, W, Cin, Cout, 0);
+  if (!T) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_wr_gn_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (!x2) { C1 = Cin; st2 = nullptr; T2 = 0; }
+  if (!x || !w_frag || !y || !st1 || T1 < 1 || (x2 && (!st2 || T2 < 1 || C1 <= 0 || C1 >= Cin || (C1 % CK))))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_wr_gn_bf16: bad arguments");
+  if ((sc != nullptr) != (sh != nullptr) || (sc != nullptr) != (mean != nullptr) || (sc != nullptr) != (rstd != nullptr))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_wr_gn_bf16: mean / rstd / sc / sh go together");
+  WrP p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = C1; p.Cin = Cin; p.w = (const bf16_t*)w_frag; p.Cout = Cout;
+  p.B = B; p.H = H; p.tiles_per_img = T; p.n_tiles = Cout / 64;
+  p.st1 = st1; p.st2 = st2; p.T1 = T1; p.T2 = T2; p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * Cin; p.ld_a = ld_a ? ld_a : 2 * Cin; p.eps = eps;
+  p.salt = salt; p.thr = idf_drop_thresh(p_drop); p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = p_drop > 0.f ? seed : nullptr;
+  p.a_out = (bf16_t*)a_out; p.mean_out = mean; p.rstd_out = rstd; p.sc_out = sc; p.sh_out = sh;
+  p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y; p.st_out = st_out;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = W == 16 ? launch_wr<true, 4, true, false>(p, s) : launch_wr<false, 4, true, false>(p, s);
+  if (rc) IDF_FAIL(IDF_ERR_HIP, "conv_wr_gn_bf16: LDS request refused (%d)", rc);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// dx = GroupNormBackward(conv3x3(dy, w_dgrad)) (+ dres + dres2): idf_conv_dgrad_gn_bf16's contract (act 2, taps 9) on whole
+// 16x16 / 8x8 images, w_frag = the data-gradient weights fragment-major; Cin = channels of dy, Cout = channels of x / dx.
+extern "C" int idf_conv_wr_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x, const void* dres, const void* dres2,
+                                         void* dx, const float* gamma, const float* beta, const float* film_t,
+                                         const float* film_a, int ld_t, int ld_a, const float* mean, const float* rstd,
+                                         const float* sc, const float* sh, float* dfilm_t, float* dfilm_a, float* dgb,
+                                         float* dgamma_acc, float* dbeta_acc, const uint64_t* seed, uint32_t salt,
+                                         float p_drop, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!wr_tiles(B, H, W, Cin, Cout, 1) || (Cout != 128 && Cout != 256))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_wr_dgrad_gn_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (!dy || !w_frag || !x || !dx || !mean || !rstd || !sc || !sh) IDF_FAIL(IDF_ERR_BADARG, "conv_wr_dgrad_gn_bf16: null argument");
+  WrP p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)dy; p.C1 = Cin; p.Cin = Cin; p.w = (const bf16_t*)w_frag; p.Cout = Cout;
+  p.B = B; p.H = H; p.tiles_per_img = 1; p.n_tiles = Cout / 64;
+  p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * Cout; p.ld_a = ld_a ? ld_a : 2 * Cout;
+  p.salt = salt; p.thr = idf_drop_thresh(p_drop); p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = p_drop > 0.f ? seed : nullptr;
+  p.res = (const bf16_t*)dres; p.res2 = (const bf16_t*)dres2; p.y = (bf16_t*)dx;
+  p.gx = (const bf16_t*)x; p.gsc = sc; p.gsh = sh; p.gmean = mean; p.grstd = rstd;
+  p.dfilm_t = dfilm_t; p.dfilm_a = dfilm_a; p.dgb = dgb; p.dgam = dgamma_acc; p.dbet = dbeta_acc;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = W == 16 ? launch_wr<true, 16, false, true>(p, s) : launch_wr<false, 4, false, true>(p, s);
+  if (rc) IDF_FAIL(IDF_ERR_HIP, "conv_wr_dgrad_gn_bf16: LDS request refused (%d)", rc);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
 #ifdef IDF_RB_STAMP
 extern "C" int idf_debug_rb_stamps(void** dev_addr) {
   return hipGetSymbolAddress(dev_addr, HIP_SYMBOL(g_rb_stamps)) == hipSuccess ? 0 : 1;

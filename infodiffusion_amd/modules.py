@@ -41,7 +41,7 @@ class _Shadows:
     def __init__(self, *convs):
         self.convs = convs
         self.key = None
-        self.val = [None, None, None]      # forward, data-gradient, [forward fragment-major: want_frag]
+        self.val = [None, None, None, None]      # forward, data-gradient, [fragment-major forward / data-gradient: want_frag]
         # the image-resident ResBlock kernel (ops.resblock_small) reads its weights fragment-major; a conv it has met once
         # gets that third shadow from the next re-pack on
         self.want_frag = False
@@ -74,20 +74,28 @@ class _Shadows:
             if v is None or v.dtype != dtype or v.device != dev:
                 self.val[j] = torch.empty(shape, dtype=dtype, device=dev)
                 self.key = None
-        if self.want_frag and (self.val[2] is None or self.val[2].dtype != dtype or self.val[2].device != dev):
-            self.val[2] = torch.empty((O * kh * kw * I,), dtype=dtype, device=dev)
-            self.key = None
+        if self.want_frag:
+            for j, fits, on in ((2, O % 16 == 0 and I % 64 == 0, True), (3, I % 16 == 0 and O % 64 == 0, need_dgrad)):
+                if fits and on and (self.val[j] is None or self.val[j].dtype != dtype or self.val[j].device != dev):
+                    self.val[j] = torch.empty((O * kh * kw * I,), dtype=dtype, device=dev)
+                    self.key = None
 
     def request_frag(self):
-        """The fragment-major forward shadow, from the next re-pack on (3x3, O % 16 == 0, I % 64 == 0, one conv)."""
+        """The fragment-major shadows (forward: O % 16 == 0, I % 64 == 0; data gradient: I % 16 == 0, O % 64 == 0), from the
+        next re-pack on (3x3, one conv)."""
         w = self.convs[0].weight
-        if not self.want_frag and len(self.convs) == 1 and w.shape[2:] == (3, 3) and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0:
+        if not self.want_frag and len(self.convs) == 1 and w.shape[2:] == (3, 3) and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
             self.want_frag = True
             self.key = None
 
     def stale(self, dtype, need_dgrad):
+        if self.want_frag:
+            O, I = sum(c.weight.shape[0] for c in self.convs), self.convs[0].weight.shape[1]
+            if (O % 16 == 0 and I % 64 == 0 and self.val[2] is None) or (need_dgrad and I % 16 == 0 and O % 64 == 0
+                                                                         and self.val[3] is None):
+                return True
         return (self.key != self.current_key(dtype) or self.val[0] is None or self.val[0].dtype != dtype
-                or (need_dgrad and self.val[1] is None) or (self.want_frag and self.val[2] is None))
+                or (need_dgrad and self.val[1] is None))
 
     def __call__(self, dtype, need_dgrad):
         if self.stale(dtype, need_dgrad):        # stand-alone use (block tests): individual pack
@@ -97,9 +105,10 @@ class _Shadows:
                 self.val[0].copy_(wf)
                 if wd is not None:
                     self.val[1].copy_(wd)
-                if self.val[2] is not None:
-                    O, taps, I = wf.shape
-                    self.val[2].copy_(wf.view(O // 16, 16, taps, I // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1))
+                for j, m in ((2, wf), (3, wd)):       # [N][taps][K] -> [K / 64][N / 16][tap][half][fq][fr][8]
+                    if self.val[j] is not None and m is not None:
+                        N, taps, K = m.shape
+                        self.val[j].copy_(m.view(N // 16, 16, taps, K // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1))
             self.key = self.current_key(dtype)
         return self.val
 
@@ -113,8 +122,8 @@ def _pack_dtype():
         import numpy as np
         _PACK_DT = np.dtype([('src', '<i8'), ('wf', '<i8'), ('wd', '<i8'), ('so', '<i8'), ('si', '<i8'), ('st', '<i8'),
                              ('O', '<i4'), ('I', '<i4'), ('taps', '<i4'), ('Ototal', '<i4'), ('o0', '<i4'),
-                             ('e0', '<i8'), ('wfrag', '<i8')], align=True)
-        assert _PACK_DT.itemsize == 88
+                             ('e0', '<i8'), ('wfrag', '<i8'), ('wdfrag', '<i8')], align=True)
+        assert _PACK_DT.itemsize == 96
     return _PACK_DT
 
 
@@ -143,7 +152,8 @@ class ShadowSet:
         for s in self.items:
             s.ensure_buffers(dtype, need_dgrad)
         tkey = (dtype, tuple((c.weight.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0,
-                              s.val[2].data_ptr() if s.val[2] is not None else 0)
+                              s.val[2].data_ptr() if s.val[2] is not None else 0,
+                              s.val[3].data_ptr() if s.val[3] is not None else 0)
                              for s in self.items for c in s.convs))
         if tkey != self.tkey:
             rows = []
@@ -163,7 +173,8 @@ class ShadowSet:
                                              s.val[1].data_ptr() if s.val[1] is not None else 0,
                                              w.stride(0), w.stride(1), st, O, I, taps, Ot, o0,
                                              tap | (ot << 8) | (it << 32),
-                                             s.val[2].data_ptr() if s.val[2] is not None else 0))
+                                             s.val[2].data_ptr() if s.val[2] is not None else 0,
+                                             s.val[3].data_ptr() if s.val[3] is not None else 0))
                     o0 += O
             host = torch.from_numpy(np.array(rows, dtype=_pack_dtype()).view(np.uint8).reshape(len(rows), -1).copy())
             dev = self.items[0].val[0].device

@@ -209,8 +209,29 @@ def _gn_advice(B, H, W, Cin, Cout, taps):
     return bool(_lib.load().idf_conv_gn_advice(B, H, W, Cin, Cout, taps))
 
 
+_WR = os.environ.get('IDF_CONV_WR', '1') != '0'          # the small-map convs with fragment-major weights (idf_conv_wr_*)
+_WR_MAXB = int(os.environ.get('IDF_CONV_WR_MAXB', '64'))   # launch-bound batches only (64 / 256 workgroups of 4 waves)
+_WR_GNB16 = os.environ.get('IDF_CONV_WR_GNB16', '0') != '0'
+
+
+@functools.lru_cache(maxsize=None)
+def wr_tiles(B, H, W, Cin, Cout, whole):
+    return int(_lib.load().idf_conv_wr_tiles(B, H, W, Cin, Cout, int(whole)))
+
+
+def _wr_frag(shadows, j, B, H, W, Cin, Cout, whole):
+    """The fragment-major shadow j (2 forward, 3 data gradient) when idf_conv_wr_* covers the shape and the shadow exists; a
+    conv met here for the first time is asked for one (it comes with the next re-pack)."""
+    if not (_WR and shadows is not None and B <= _WR_MAXB and wr_tiles(B, H, W, Cin, Cout, whole) > 0):
+        return None
+    v = shadows.val[j]
+    if v is None:
+        shadows.request_frag()
+    return v
+
+
 def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
-                keep_a=False, keep_coef=False, want_stats=False, shortcut=None):
+                keep_a=False, keep_coef=False, want_stats=False, shortcut=None, shadows=None):
     """y = conv(act(GN/FiLM(x | x2))) + bias (+ residual) in one launch -> (y, a, mean, rstd, sc, sh, st_out);
     a / the coefficients are None unless asked for (training).  shortcut = (w_sc [Cs][Cin] kernel layout, bias_sc, Cs): the
     same launch also computes s = conv1x1(x | x2) + bias_sc (the block's shortcut over the raw input), returned last."""
@@ -225,6 +246,14 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
         rstd = torch.empty((B, 32), dtype=torch.float32, device=dev)
         sc = torch.empty((B, Cin), dtype=torch.float32, device=dev)
         sh = torch.empty((B, Cin), dtype=torch.float32, device=dev)
+    wfrag = _wr_frag(shadows, 2, B, H, W, Cin, Cout, 0) if (taps == 9 and act == 2 and shortcut is None) else None
+    if wfrag is not None:
+        # 16x16 / 8x8: weights fragment-major into registers, barrier-free conv loop, epilogue in the wave's registers
+        st = torch.empty((B, wr_tiles(B, H, W, Cin, Cout, 0), Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
+        call('idf_conv_wr_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
+             _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, _p(seed), salt, float(p_drop),
+             _p(wfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout, _st())
+        return y, a, mean, rstd, sc, sh, st
     st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev, 1) if want_stats else None
     ws = torch.empty((B, Cin, 2), dtype=torch.float32, device=dev) if B * H * W >= (1 << 18) else None
     args = (_p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
@@ -425,7 +454,7 @@ def conv_dgrad_gn_ok(dy, x, mode, taps, advice=True):
 
 
 def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, taps,
-                      acc=None, dres=None, dres2=None):
+                      acc=None, dres=None, dres2=None, shadows=None):
     """dx and the GroupNorm's parameter / FiLM gradients from dy in ONE launch: the stride-1 data-gradient conv with the
     GroupNorm backward as its epilogue.  Returns what gn_fused_bwd_raw returns."""
     B, C, H, W = x.shape
@@ -435,6 +464,19 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
     acc = _gn_acc(acc)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    # (whole 16x16 images in this form -- 4 waves x 256 pixels -- measured SLOWER than the 512-thread register-staged kernel:
+    # 25.8 vs 19.7 us at B = 32, profiles/r04_conv_wr.txt; 8x8 only unless IDF_CONV_WR_GNB16=1)
+    wfrag = _wr_frag(shadows, 3, B, H, W, dy.shape[1], C, 1) if (taps == 9 and act == 2 and C in (128, 256) and
+                                                              (W == 8 or _WR_GNB16)) else None
+    if wfrag is not None:
+        call('idf_conv_wr_dgrad_gn_bf16', _p(dy), _p(wfrag), _p(x), _p(dres), _p(dres2), _p(dx), _p(gamma), _p(beta), _p(film_t),
+             _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
+             _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop), B, H, W, dy.shape[1], C,
+             _st())
+        if acc:
+            return dx, acc[0], acc[1], dft, dfa
+        dgam = colsum_raw(dgb)
+        return dx, dgam[:C], dgam[C:], dft, dfa
     call('idf_conv_dgrad_gn_bf16', _p(dy), _p(w_dgrad), _p(x), _p(dres), _p(dres2), _p(dx), _p(gamma), _p(beta), _p(film_t),
          _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop), act, B, H, W,
@@ -832,7 +874,8 @@ class _FusedConv(torch.autograd.Function):
         if act and mode == S1 and xst is not None and conv_gn_ok(x, None, taps, Cout):
             y, a, mean, rstd, sc, sh, st = conv_gn_raw(
                 x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias, residual,
-                Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats)
+                Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats,
+                shadows=cfg['shadows'])
         else:
             ast = getattr(x, '_gn', None)
             if (act and ast is not None and x.dtype == torch.bfloat16 and x.shape[1] % 32 == 0 and ast.shape[0] == x.shape[0]
@@ -939,7 +982,8 @@ class _FusedConv(torch.autograd.Function):
             elif fused_bwd:
                 # small maps: the data-gradient conv's tile is a whole image, its epilogue IS the GroupNorm backward
                 dx, dgw, dgb, dft, dfa = conv_dgrad_gn_raw(dy, w_dgrad, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
-                                                           seed, salt, p_drop, act, taps, gslots, dres_in, dres2_in)
+                                                           seed, salt, p_drop, act, taps, gslots, dres_in, dres2_in,
+                                                           shadows=cfg['shadows'])
             else:
                 if not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
                     dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
@@ -1057,9 +1101,12 @@ class _BlockEntryCat(torch.autograd.Function):
             # GroupNorm + SiLU applied while the conv stages the two sources; statistics from their producers
             # (the 1x1 shortcut over the same raw input rides in the launch: IDF_SC_FUSE)
             ride = _SC_FUSE and B * H * W <= _SC_FUSE_MAXPIX and w.shape[0] > 32 and sw.shape[0] % 8 == 0
+            if cfg['act'] == 2 and _wr_frag(cfg['shadows'], 2, B, H, W, C, w.shape[0], 0) is not None:
+                ride = False       # the fragment-major form carries no rider: the 1x1 shortcut is its own launch below
             out = conv_gn_raw(x1, x2, st1, st2, gn_w, gn_b, None, None, None, cfg['salt'], 0.0, cfg['act'], w_fwd, b, None,
                               w.shape[0], 9, keep_a=need[2], keep_coef=any(need[i] for i in (0, 1, 4, 5)), want_stats=True,
-                              shortcut=(cfg_sc['shadows'](x1.dtype, train)[0], sb, sw.shape[0]) if ride else None)
+                              shortcut=(cfg_sc['shadows'](x1.dtype, train)[0], sb, sw.shape[0]) if ride else None,
+                              shadows=cfg['shadows'])
             h, a, mean, rstd, sc, sh, st = out[:7]
             s = out[7] if ride else None
         else:
@@ -1293,7 +1340,7 @@ class _ResBlockSmall(torch.autograd.Function):
             pd = p_drop if meta['drop'][i] else 0.0
             w_dgrad = cfgs[i]['shadows'](dt, True)[1]
             dx, dgw, dgb, dft_i, dfa_i = conv_dgrad_gn_raw(g, w_dgrad, h_prev, gw, gb, ft, fa, mean, rstd, sc, sh, sd,
-                                                           cfgs[i]['salt'], pd, 2, 9, (gws, gbs))
+                                                           cfgs[i]['salt'], pd, 2, 9, (gws, gbs), shadows=cfgs[i]['shadows'])
             if ft is not None or fa is not None:
                 dft, dfa = dft_i, dfa_i
             defer = _grad_free(ws) and _grad_free(bs)
@@ -1315,7 +1362,7 @@ class _ResBlockSmall(torch.autograd.Function):
                 grads[4 * n], grads[4 * n + 1] = conv_wgrad_bias_raw(x, ds, S1, 1, True, sws, sbs, _grad_free(sws) and _grad_free(sbs))
                 dres = conv_dgrad_raw(ds, meta['cfg_sc']['shadows'](dt, True)[1], S1, 1, x.shape)
             dx, dgw, dgb, _, _ = conv_dgrad_gn_raw(g, w_dgrad, x, gw, gb, None, None, mean, rstd, sc, sh, None,
-                                                   cfgs[0]['salt'], 0.0, 2, 9, (gws, gbs), dres, dskip)
+                                                   cfgs[0]['salt'], 0.0, 2, 9, (gws, gbs), dres, dskip, shadows=cfgs[0]['shadows'])
         else:
             sw, sb = tensors[4 * n], tensors[4 * n + 1]
             sws, sbs = slots[4 * n], slots[4 * n + 1]

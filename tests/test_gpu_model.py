@@ -856,6 +856,8 @@ def test_gradient_arena_matches_standalone_gradients_and_survives_accumulation()
         loss.backward()
         return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
+    grads()        # the first pass of a network asks for the fragment-major weight shadows of its 16x16 / 8x8 convs: from the
+    #                second pass on the same kernels run every time, which is what the tight bound below presumes
     model.zero_grad(set_to_none=True)
     ref = grads()                                     # no arena exists yet: stand-alone path
     opt = FusedClipAdamW(model.parameters(), lr=0.0, weight_decay=0.0)

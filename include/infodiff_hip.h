@@ -183,6 +183,13 @@ int idf_resblock_small_ok(int B, int H, int W, int Cin, int C1, int Cout, int ns
  * idf_conv_wr_tiles: pixel tiles per image of the forward form (whole = 0) / 1 when the whole-image form covers the shape
  * (whole = 1); 0: not covered (H = W in {8, 16}, Cin in {64, 128, 256}, Cout % 64 == 0, Cout <= 256). */
 int idf_conv_wr_tiles(int B, int H, int W, int Cin, int Cout, int whole);
+
+/* the head conv (models.py:258, 300: Conv2d(3 | 1, ch, 3, padding 1)): Cin <= 3, the whole contraction is one MFMA K-step;
+ * w = the forward shadow [Cout][9][Cin]; st_out (optional) = statistics partials of y, [B][idf_conv_fewc_tiles()][Cout][2]
+ * (0 tiles: shape not covered -- use idf_conv2d_fwd). */
+int idf_conv_fewc_tiles(int B, int H, int W, int Cin, int Cout);
+int idf_conv3x3_fewc_bf16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                          float* st_out, void* stream);
 int idf_conv_wr_gn_bf16(const void* x, const void* x2, int C1, const float* st1, int T1, const float* st2, int T2,
                         const float* gamma, const float* beta, const float* film_t, const float* film_a, int ld_t, int ld_a,
                         float eps, const uint64_t* seed, uint32_t salt, float p_drop, const void* w_frag, const float* bias,

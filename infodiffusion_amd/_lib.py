@@ -47,6 +47,8 @@ SIGNATURES = {
     'idf_conv_dgrad_gn_ok': ([_i] * 6, C.c_int),
     'idf_resblock_small_ok': ([_i] * 7, C.c_int),
     'idf_conv_wr_tiles': ([_i] * 6, C.c_int),
+    'idf_conv_fewc_tiles': ([_i] * 5, C.c_int),
+    'idf_conv3x3_fewc_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p], C.c_int),
     'idf_conv_wr_gn_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _u32, _f] + [_p] * 10 + [_i] * 5 + [_p], C.c_int),
     'idf_conv_wr_dgrad_gn_bf16': ([_p] * 10 + [_i, _i] + [_p] * 10 + [_u32, _f] + [_i] * 5 + [_p], C.c_int),
     'idf_resblock_small_fwd': ([C.POINTER(ResblockArgs), _p], C.c_int),

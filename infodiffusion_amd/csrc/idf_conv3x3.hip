@@ -1613,6 +1613,72 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
 }
 
 
+// ---------------------------------------------------------------- few input channels (the network's head conv)
+// 3x3 stride-1 conv over an image of Cin <= 3 channels (modules / models.py:258, 300: head = Conv2d(3, ch)): the whole contraction
+// is K = 9 * Cin <= 27, ONE MFMA K-step.  The generic implicit-GEMM kernel spent 111 us on it at B = 256 (a 3.6-GFLOP conv that
+// writes 134 MB) and left no statistics for the first GroupNorm; here a block stages the (R + 2) x (W + 2) x Cin halo tile and
+// the [64][32] zero-padded weight tile in LDS, each lane gathers its 8 k-values per pixel fragment with 2-byte LDS reads, and
+// the epilogue is lds_epilogue (bias, full-line stores, statistics partials): HBM-bound on the output.
+__global__ __launch_bounds__(512) void conv3x3_fewc_bf16(const C3P p) {
+  constexpr int TM = 4, TN = 2, BM = 256, BN = 64, NT = 512, NWM = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = p.W, R = p.R, WH = W + 2, npix_h = (R + 2) * WH, Cin = p.Cin;
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                              // [npix_h][4] (channel 3 unused)
+  bf16_t* Ws = reinterpret_cast<bf16_t*>(smem + (size_t)npix_h * 8);         // [BN][32], k = tap * Cin + c, zero beyond 9 * Cin
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
+  const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int i = tid; i < npix_h * 4; i += NT) {
+    const int pix = i >> 2, c = i & 3;
+    const int hy = pix / WH, hx = pix - hy * WH, iy = oy0 + hy - 1, ix = hx - 1;
+    bf16_t v = 0;
+    if (c < Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) v = p.x[((size_t)(b * p.H + iy) * W + ix) * Cin + c];
+    Xs[i] = v;
+  }
+  for (int i = tid; i < BN * 32; i += NT) {
+    const int n = i >> 5, k = i & 31;
+    Ws[i] = (k < 9 * Cin && n0 + n < p.Cout) ? p.w[(size_t)(n0 + n) * 9 * Cin + k] : (bf16_t)0;
+  }
+  __syncthreads();
+  // this lane's 8 k-values: k = fq * 8 + e -> (tap, c); their halo offsets relative to the pixel's window origin
+  int koff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = fq * 8 + e;
+    if (k < 9 * Cin) { const int tap = k / Cin, c = k - tap * Cin; koff[e] = ((tap / 3) * WH + (tap % 3)) * 4 + c; }
+    else koff[e] = -1;
+  }
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t wf[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const bf16x8_t*>(Ws + (wn0 + a * 16 + fr) * 32 + fq * 8);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int pl = wm0 + i * 16 + fr;
+    if (pl >= R * W) pl = 0;
+    const int base = ((pl >> p.wshift) * WH + (pl & (W - 1))) * 4;
+    uint32_t w4[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const uint32_t lo = koff[e] >= 0 ? Xs[base + koff[e]] : 0u, hi = koff[e + 1] >= 0 ? Xs[base + koff[e + 1]] : 0u;
+      w4[e >> 1] = lo | (hi << 16);
+    }
+    const u32x4_t xv = {w4[0], w4[1], w4[2], w4[3]};
+    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, xv);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf, acc[a][i], 0, 0, 0);
+  }
+  __syncthreads();
+  uint4 none[(BM * (BN / 8) + NT - 1) / NT];
+  lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, R * W, tid, wm0, wn0, none, false);
+}
+
 // magic multiplier for the division by the halo-row width; 0 when not exact over [0, npix)
 inline unsigned wh_magic(int WH, int npix) {
   unsigned m = 65536u / (unsigned)WH + 1u;
@@ -1917,6 +1983,40 @@ extern "C" int idf_conv3x3_bf16(const void* x, const void* w, const float* bias,
   if (int e = fill_common(p, B, H, W, Cin, Cout, mode, 3, &BM))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, e == 1 ? "conv3x3_bf16: halo too large (H%d W%d)" : "conv3x3_bf16: tensor too large for 32-bit offsets", H, W);
   dispatch3<false, false>(p, mode, BM, (hipStream_t)stream);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// Pixel tiles per image of idf_conv3x3_fewc_bf16 (= T of its statistics partials); 0: not covered (Cin <= 3, Cout % 8 == 0,
+// W a power of two in [8, 64], H * W >= 256, 256-pixel tiles of whole rows).
+extern "C" int idf_conv_fewc_tiles(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || Cin < 1 || Cin > 3 || (Cout & 7) || W < 8 || W > 64 || (W & (W - 1)) || H * W < 256) return 0;
+  const int R = 256 / W;
+  if (H % R || (long)B * H * W * Cout >= (1L << 31)) return 0;
+  return H / R;
+}
+
+// y = conv3x3(x, w) + bias, stride 1, for an input of Cin <= 3 channels (the head conv): x [B,H,W,Cin] bf16, w the forward
+// shadow [Cout][9][Cin]; st_out (optional): statistics partials of y [B][idf_conv_fewc_tiles()][Cout][2].
+extern "C" int idf_conv3x3_fewc_bf16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                                     int Cout, float* st_out, void* stream) {
+  const int T = idf_conv_fewc_tiles(B, H, W, Cin, Cout);
+  if (!T) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv3x3_fewc_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (!x || !w || !y) IDF_FAIL(IDF_ERR_BADARG, "conv3x3_fewc_bf16: null argument");
+  C3P p;
+  clear_pro(p);
+  p.x = (const bf16_t*)x; p.x2 = nullptr; p.C1 = Cin; p.w = (const bf16_t*)w; p.bias = bias; p.res = nullptr; p.y = (bf16_t*)y;
+  p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout; p.st_out = st_out;
+  int ws = 0;
+  while ((1 << ws) < W) ++ws;
+  p.wshift = ws;
+  p.R = 256 / W; p.tiles_per_img = T; p.n_tiles = idf_cdiv(Cout, 64); p.wh_magic = 1;
+  size_t lds = (size_t)256 * (64 + 4) * sizeof(float);            // the epilogue's fp32 tile (>= halo + weight tiles)
+  p.aux_off = (int)lds;
+  lds += (size_t)8 * 64 * 8;
+  static IdfLdsGrant grant;
+  if (idf_ensure_lds((const void*)conv3x3_fewc_bf16, lds, grant) != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "conv3x3_fewc_bf16: LDS request refused");
+  hipLaunchKernelGGL(conv3x3_fewc_bf16, dim3(B * T * p.n_tiles), dim3(512), lds, (hipStream_t)stream, p);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -136,6 +136,11 @@ def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device, pro=0):
     return torch.empty((B, T, Cout, 2), dtype=torch.float32, device=device) if T > 0 else None
 
 
+@functools.lru_cache(maxsize=None)
+def fewc_tiles(B, H, W, Cin, Cout):
+    return int(_lib.load().idf_conv_fewc_tiles(B, H, W, Cin, Cout))
+
+
 def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, act, Cout, out_hw_=None, want_stats=False):
     """x logical [B,Cin,Hs,Ws] NHWC-dense; w_fwd [Cout][taps][Cin] in x.dtype.  want_stats: returns (y, st) where
     st = the statistics partials of y (None when the kernel that ran does not produce them)."""
@@ -158,6 +163,13 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
         # 1x1 conv = [pixels, Cin] x [Cout, Cin]^T (+bias, +residual): the short-K GEMM
         M = B * Ho * Wo
         bgemm_raw(x, 0, w_fwd, 0, y, 0, bias, 1, 0, 0, 0, Cin, Cin, Cout, M, Cout, Cin, 0, 0, res=residual)
+        return done()
+    if (taps == 9 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin <= 3 and residual is None
+            and fewc_tiles(B, Ho, Wo, Cin, Cout) > 0):
+        # the head conv: one MFMA K-step, statistics of y for the first GroupNorm on the way out
+        if want_stats:
+            st = torch.empty((B, fewc_tiles(B, Ho, Wo, Cin, Cout), Cout, 2), dtype=torch.float32, device=x.device)
+        call('idf_conv3x3_fewc_bf16', _p(x), _p(w_fwd), _p(bias), _p(y), B, Ho, Wo, Cin, Cout, _p(st), _st())
         return done()
     if uses_halo_kernel(x.dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
         if want_stats:

@@ -509,6 +509,31 @@ def test_gn_one_launch_small(C, H, dtype):
     assert rel(dx2, xr.grad + dres.float()) < btol
 
 
+@pytest.mark.parametrize('B,Cin,H,Cout', [(3, 3, 64, 64), (2, 1, 32, 64), (5, 3, 16, 128), (33, 3, 64, 64)])
+def test_head_conv_few_input_channels_vs_pytorch(B, Cin, H, Cout):
+    """idf_conv3x3_fewc_bf16 (the network's head conv: Cin <= 3, one MFMA K-step, statistics of y in the epilogue) through
+    ops.conv_raw against fp32 PyTorch on the same bf16-valued operands; the statistics partials against the channel sums of y."""
+    x = rnd(1, B, Cin, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    w = (rnd(2, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5).to(DEV)
+    bias = rnd(3, Cout).to(DEV)
+    wf, _ = ops.pack_weight(w, torch.bfloat16, True, False)
+    names = []
+    orig = ops.call
+    ops.call = lambda n, *a: (names.append(n), orig(n, *a))[1]
+    try:
+        y, st = ops.conv_raw(x, wf, bias, None, None, None, None, 0, 0.0, ops.S1, 9, 0, Cout, want_stats=True)
+    finally:
+        ops.call = orig
+    assert names == ['idf_conv3x3_fewc_bf16'], names
+    ref = F.conv2d(x.float(), wf.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias, padding=1)
+    assert rel(y, ref) < 1e-2, rel(y, ref)
+    assert st is not None and st.shape == (B, H * H // 256, Cout, 2)
+    s1, s2 = _chan_sums(y)
+    got = st.double().sum(dim=1)
+    assert float((got[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+    assert float((got[..., 0] - s1).abs().max()) < 2e-3 * (1 + float(s1.abs().max()))
+
+
 class _FragShadows:
     """What ops._wr_frag wants of a modules._Shadows: val = [forward, data-gradient, fragment-major forward, fragment-major
     data-gradient] shadows of one 3x3 conv, packed here by torch ops ([N][taps][K] -> [K/64][N/16][tap][half][fq][fr][8])."""

@@ -201,6 +201,30 @@ int idf_conv_wr_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x,
                               float* dfilm_a, float* dgb, float* dgamma_acc, float* dbeta_acc, const uint64_t* seed,
                               uint32_t salt, float p_drop, int B, int H, int W, int Cin, int Cout, void* stream);
 int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
+
+/* The backward of the same blocks: the data-gradient convs of stages nstage-1 .. first with the GroupNorm / FiLM / SiLU / dropout
+ * backward behind each (what idf_conv_wr_dgrad_gn_bf16 computes per stage) in ONE launch, one workgroup per image; every stage
+ * has 128 channels.  Stage i: x = its GroupNorm input (h_{i-1}; the block input for stage 0), w_frag = the data-gradient weights
+ * of its conv fragment-major, mean .. sh as the forward pass saved them, dx = the gradient w.r.t. x (= the gradient of stage
+ * i-1's conv output: read by that conv's weight gradient, and by this launch as the next stage's dy).  Side outputs per stage as
+ * idf_conv_dgrad_gn_bf16 (dfilm_t / dfilm_a [B,256], dgb [B,2,128] or the dgamma_acc / dbeta_acc accumulators).
+ * first = 0 (one-source block input, identity residual): the block's dy (+ dres2, the skip alias' gradient) joins stage 0's dx;
+ * first >= 1: the launch stops above the block input (two-source inputs / 1x1 shortcuts keep their own launches). */
+typedef struct {
+  const void* w_frag; const void* x;
+  const float* gamma; const float* beta; const float* film_t; const float* film_a; int ld_t, ld_a;
+  const float* mean; const float* rstd; const float* sc; const float* sh;
+  uint32_t salt; int drop;
+  float* dfilm_t; float* dfilm_a; float* dgb; float* dgamma_acc; float* dbeta_acc;
+  void* dx;
+} IdfResblockBwdStage;
+typedef struct {
+  const void* dy; int nstage, first;
+  IdfResblockBwdStage s[3];
+  const void* dres2;
+  const uint64_t* seed; float p_drop; int B;
+} IdfResblockBwdArgs;
+int idf_resblock_small_bwd(const IdfResblockBwdArgs* args, void* stream);
 int idf_conv_dgrad_chain_bf16(const void* dy, const void* in_x, const float* in_part, int in_T, const float* in_mean,
                               const float* in_rstd, const float* in_sc, const float* in_gamma, const float* in_beta,
                               const float* in_film_t, const float* in_film_a, int in_ld_t, int in_ld_a,

@@ -30,6 +30,19 @@ class ResblockArgs(C.Structure):
                 ('seed', _p), ('p_drop', _f), ('eps', _f), ('B', _i), ('w_layout', _i)]
 
 
+class ResblockBwdStage(C.Structure):
+    """IdfResblockBwdStage (include/infodiff_hip.h)."""
+    _fields_ = [('w_frag', _p), ('x', _p), ('gamma', _p), ('beta', _p), ('film_t', _p), ('film_a', _p), ('ld_t', _i), ('ld_a', _i),
+                ('mean', _p), ('rstd', _p), ('sc', _p), ('sh', _p), ('salt', _u32), ('drop', _i), ('dfilm_t', _p), ('dfilm_a', _p),
+                ('dgb', _p), ('dgamma_acc', _p), ('dbeta_acc', _p), ('dx', _p)]
+
+
+class ResblockBwdArgs(C.Structure):
+    """IdfResblockBwdArgs (include/infodiff_hip.h)."""
+    _fields_ = [('dy', _p), ('nstage', _i), ('first', _i), ('s', ResblockBwdStage * 3), ('dres2', _p), ('seed', _p),
+                ('p_drop', _f), ('B', _i)]
+
+
 SIGNATURES = {
     'idf_version': ([], C.c_int),
     'idf_last_error': ([], C.c_char_p),
@@ -52,6 +65,7 @@ SIGNATURES = {
     'idf_conv_wr_gn_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _u32, _f] + [_p] * 10 + [_i] * 5 + [_p], C.c_int),
     'idf_conv_wr_dgrad_gn_bf16': ([_p] * 10 + [_i, _i] + [_p] * 10 + [_u32, _f] + [_i] * 5 + [_p], C.c_int),
     'idf_resblock_small_fwd': ([C.POINTER(ResblockArgs), _p], C.c_int),
+    'idf_resblock_small_bwd': ([C.POINTER(ResblockBwdArgs), _p], C.c_int),
     'idf_conv_dgrad_gn_bf16': ([_p] * 10 + [_i, _i] + [_p] * 10 + [_u32, _f] + [_i] * 7 + [_p], C.c_int),
     'idf_conv_dgrad_chain_tiles': ([_i] * 6, C.c_int),
     'idf_conv_dgrad_chain_bf16': ([_p, _p, _p, _i] + [_p] * 7 + [_i, _i] + [_p] * 5 + [_p] + [_p, _p, _p, _i] + [_p] * 3 +

@@ -427,6 +427,184 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
 }
 
 // =====================================================================================================================
+// Image-resident ResBlock BACKWARD for the 8x8 maps: the data-gradient convs of stages n-1 .. first and the GroupNorm / FiLM /
+// SiLU / dropout backward behind each (idf_conv_wr_dgrad_gn_bf16's arithmetic) chained in ONE launch, one workgroup per image:
+// the gradient a stage hands to the stage before it is written to memory (the weight gradient of that stage's conv reads it)
+// AND into the LDS image the next data-gradient conv reads.  Same work split as the forward kernel: wave w owns channels
+// 16 w .. 16 w + 15, a lane's 4 channels are one GroupNorm group (128 channels), weights fragment-major into registers.
+struct RbBK { IdfResblockBwdArgs a; uint32_t thr; float dscale; };
+
+__global__ __launch_bounds__(NT) void resblock8_bwd_kernel(const RbBK k_in) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const IdfResblockBwdArgs& p = k_in.a;
+  unsigned char* const Abuf = smem;                         // [4 chunks][HROWS][WH][PPB]: the current stage's dy
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c0 = wave * 16 + fq * 4;
+  const bool drop_any = p.seed != nullptr;
+  const uint64_t seedv = drop_any ? *p.seed : 0;
+  const bf16_t* const pdy = reinterpret_cast<const bf16_t*>(p.dy);
+
+  auto wptr = [&](const void* w, int cp, int tap, int half) __attribute__((always_inline)) -> const bf16_t* {
+    return reinterpret_cast<const bf16_t*>(w) + ((size_t)((cp * 8 + wave) * 18 + tap * 2 + half) * 64 + lane) * 8;
+  };
+  auto a_slot = [&](int pl, int c) -> unsigned char* {
+    const int h = ((pl >> 3) + 1) * WH + (pl & 7) + 1;
+    return Abuf + (size_t)(c >> 5) * CHB + aoff(h, (c & 31) >> 3);
+  };
+  // dy -> LDS (raw), halo border zeroed once
+  u32x4_t dyr[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = tid + k * NT, pl = v >> 4, c = (v & 15) * 8;
+    dyr[k] = *reinterpret_cast<const u32x4_t*>(pdy + (size_t)(b * NPX + pl) * BN + c);
+  }
+  WPair wA;
+  {
+    const void* w0 = p.s[p.nstage - 1].w_frag;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      wA.t[tap][0] = *reinterpret_cast<const bf16x8_t*>(wptr(w0, 0, tap, 0));
+      wA.t[tap][1] = *reinterpret_cast<const bf16x8_t*>(wptr(w0, 0, tap, 1));
+    }
+  }
+  for (int i = tid; i < 4 * 36 * 4; i += NT) {
+    const int ck = i / 144, r = i - ck * 144, bp = r >> 2, q = r & 3;
+    int hy, hx;
+    if (bp < 10) { hy = 0; hx = bp; } else if (bp < 20) { hy = 9; hx = bp - 10; }
+    else if (bp < 28) { hy = bp - 19; hx = 0; } else { hy = bp - 27; hx = 9; }
+    *reinterpret_cast<u32x4_t*>(Abuf + (size_t)ck * CHB + aoff(hy * WH + hx, q)) = u32x4_t{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = tid + k * NT, pl = v >> 4, c = (v & 15) * 8;
+    *reinterpret_cast<u32x4_t*>(a_slot(pl, c)) = dyr[k];
+  }
+  rb_barrier();
+
+  const int lbase = ((fr >> 3) * 16 + (fr & 7)) * PPB + fq * 16;
+  auto run_stage = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+    if (st >= p.nstage || st < p.first) return;
+    const IdfResblockBwdStage& s = p.s[st];
+    const IdfResblockBwdStage& nx = p.s[st > 0 ? st - 1 : 0];
+    const bool more_stages = st > p.first;
+    const bf16_t* const gx = reinterpret_cast<const bf16_t*>(s.x);
+    // operands of the epilogue, fetched ahead of the conv
+    uint2 gxr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gxr[i] = *reinterpret_cast<const uint2*>(gx + (size_t)(b * NPX + i * 16 + fr) * BN + c0);
+    const float4 sc4 = *reinterpret_cast<const float4*>(s.sc + (size_t)b * BN + c0), sh4 = *reinterpret_cast<const float4*>(s.sh + (size_t)b * BN + c0);
+    const float mu = s.mean[b * 32 + (c0 >> 2)], rs = s.rstd[b * 32 + (c0 >> 2)];
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f), t0 = b4, t1 = b4, a0 = b4;
+    if (s.gamma) g4 = *reinterpret_cast<const float4*>(s.gamma + c0);
+    if (s.beta) b4 = *reinterpret_cast<const float4*>(s.beta + c0);
+    if (s.film_t) { t0 = *reinterpret_cast<const float4*>(s.film_t + (size_t)b * s.ld_t + c0); t1 = *reinterpret_cast<const float4*>(s.film_t + (size_t)b * s.ld_t + BN + c0); }
+    if (s.film_a) a0 = *reinterpret_cast<const float4*>(s.film_a + (size_t)b * s.ld_a + c0);
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int cp = 0; cp < 2; ++cp) {
+      const void* nb = nullptr;
+      int ncp_i = cp + 1;
+      if (cp == 0) nb = s.w_frag;
+      else if (more_stages) { nb = nx.w_frag; ncp_i = 0; }
+      const unsigned char* X0 = Abuf + (size_t)(2 * cp) * CHB + lbase;
+      bf16x8_t xfA[4], xfB[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xfA[j] = *reinterpret_cast<const bf16x8_t*>(X0 + (size_t)(j * 32) * PPB);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        const int half = k & 1, tap = k >> 1;
+        bf16x8_t (&cur)[4] = (k & 1) ? xfB : xfA;
+        bf16x8_t (&nxt)[4] = (k & 1) ? xfA : xfB;
+        if (k + 1 < 18) {
+          const int nh = (k + 1) & 1, nt = (k + 1) >> 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            nxt[j] = *reinterpret_cast<const bf16x8_t*>(X0 + (size_t)nh * CHB + (size_t)(j * 32 + (nt / 3) * WH + (nt % 3)) * PPB);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA.t[tap][half], cur[j], acc[j], 0, 0, 0);
+        if (nb) wA.t[tap][half] = *reinterpret_cast<const bf16x8_t*>(wptr(nb, ncp_i, tap, half));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- GroupNorm backward in the wave's registers (conv_wr_kernel's GNB epilogue, C = 128: a lane's 4 channels = one group)
+    const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float stv[4] = {t0.x, t0.y, t0.z, t0.w}, btv[4] = {t1.x, t1.y, t1.z, t1.w}, sav[4] = {a0.x, a0.y, a0.z, a0.w};
+    const bool drop = s.drop && drop_any;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float xv[4] = {__uint_as_float(gxr[i].x << 16), __uint_as_float(gxr[i].x & 0xffff0000u),
+                     __uint_as_float(gxr[i].y << 16), __uint_as_float(gxr[i].y & 0xffff0000u)};
+      float dav[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, du[4];
+      const size_t e0 = (size_t)(b * NPX + i * 16 + fr) * BN + c0;
+      const uint32_t h = drop ? idf_vec_hash(seedv, s.salt, e0 >> 3) : 0u;
+      if (drop) idf_dact_vec_t<4, true, true>(dav, xv, scv, shv, h, (int)(c0 & 7), k_in.thr, k_in.dscale, du);
+      else idf_dact_vec_t<4, true, false>(dav, xv, scv, shv, h, (int)(c0 & 7), k_in.thr, k_in.dscale, du);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] += du[r]; s2[r] += du[r] * xv[r]; acc[i][r] = du[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+    float P1 = 0.f, P2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float D1 = s1[r], D2 = rs * (s2[r] - mu * s1[r]);
+      const float f = (1.f + stv[r]) * (1.f + sav[r]);
+      const float Gf = ga[r] * D2 + be[r] * D1, Ge = D1;
+      if (fr == 0) {
+        const int c = c0 + r;
+        if (s.dfilm_t) { s.dfilm_t[(size_t)b * 2 * BN + c] = Gf * (1.f + sav[r]); s.dfilm_t[(size_t)b * 2 * BN + BN + c] = Ge * (1.f + sav[r]); }
+        if (s.dfilm_a) { s.dfilm_a[(size_t)b * 2 * BN + c] = Gf * (1.f + stv[r]) + Ge * btv[r]; s.dfilm_a[(size_t)b * 2 * BN + BN + c] = Ge; }
+        if (s.dgb) { s.dgb[((size_t)b * 2 + 0) * BN + c] = f * D2; s.dgb[((size_t)b * 2 + 1) * BN + c] = f * D1; }
+        if (s.dgamma_acc) atomicAdd(s.dgamma_acc + c, f * D2);
+        if (s.dbeta_acc) atomicAdd(s.dbeta_acc + c, f * D1);
+      }
+      P1 += ga[r] * f * D1; P2 += ga[r] * f * D2;
+    }
+    const float invN = 1.f / ((float)NPX * 4);
+    const float k1 = -rs * rs * P2 * invN, k0 = (-rs * P1 + rs * rs * mu * P2) * invN;
+    uint2 ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t e0 = (size_t)(b * NPX + i * 16 + fr) * BN + c0;
+      const float xv[4] = {__uint_as_float(gxr[i].x << 16), __uint_as_float(gxr[i].x & 0xffff0000u),
+                           __uint_as_float(gxr[i].y << 16), __uint_as_float(gxr[i].y & 0xffff0000u)};
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = scv[r] * acc[i][r] + k1 * xv[r] + k0;
+      if (st == 0) {          // the residual branch (identity) and the skip alias join at the block input
+        const uint2 rv = *reinterpret_cast<const uint2*>(pdy + e0);
+        o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+        o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+        if (p.dres2) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.dres2) + e0);
+          o[0] += __uint_as_float(r2.x << 16); o[1] += __uint_as_float(r2.x & 0xffff0000u);
+          o[2] += __uint_as_float(r2.y << 16); o[3] += __uint_as_float(r2.y & 0xffff0000u);
+        }
+      }
+      ov[i].x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+      ov[i].y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(s.dx) + e0) = ov[i];
+    }
+    if (!more_stages) return;
+    rb_barrier();            // every wave is past its last read of this stage's dy image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint2*>(a_slot(i * 16 + fr, c0) + (c0 & 4) * 2) = ov[i];
+    rb_barrier();            // the next stage's dy image is in place
+  };
+  run_stage(std::integral_constant<int, 2>{});
+  run_stage(std::integral_constant<int, 1>{});
+  run_stage(std::integral_constant<int, 0>{});
+}
+
+// =====================================================================================================================
 // Per-op 3x3 convs of the small maps (16x16, 8x8) in the same form: a workgroup = 4 waves x 16 couts (a 64-cout tile) over a
 // pixel tile of 64 pixels (4 rows of a 16x16 map / a whole 8x8 map) or 256 pixels (a whole 16x16 map); the weights come
 // fragment-major straight into registers, the activated input of ALL channel chunks lies in LDS (pitch-96 image, immediates
@@ -845,6 +1023,34 @@ extern "C" int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream)
   k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
   if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
   hipLaunchKernelGGL(resblock8_fwd_kernel, dim3(p.B), dim3(NT), lds, (hipStream_t)stream, k);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// Backward of the block's stages nstage-1 .. first in one launch (see resblock8_bwd_kernel): per stage the data-gradient conv with
+// fragment-major weights + the GroupNorm backward of idf_conv_wr_dgrad_gn_bf16; stage i's dx is the gradient of stage i-1's conv
+// output (written for that conv's weight gradient too).  first == 0 needs a one-source block input with an identity residual.
+extern "C" int idf_resblock_small_bwd(const IdfResblockBwdArgs* args, void* stream) {
+  if (!args) IDF_FAIL(IDF_ERR_BADARG, "resblock_small_bwd: null arguments");
+  const IdfResblockBwdArgs& p = *args;
+  if (p.B <= 0 || (p.nstage != 2 && p.nstage != 3) || p.first < 0 || p.first >= p.nstage || (long)p.B * NPX * BN >= (1L << 31))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "resblock_small_bwd: B%d nstage%d first%d not covered", p.B, p.nstage, p.first);
+  if (!p.dy) IDF_FAIL(IDF_ERR_BADARG, "resblock_small_bwd: null dy");
+  for (int i = p.first; i < p.nstage; ++i) {
+    const IdfResblockBwdStage& s = p.s[i];
+    if (!s.w_frag || !s.x || !s.mean || !s.rstd || !s.sc || !s.sh || !s.dx)
+      IDF_FAIL(IDF_ERR_BADARG, "resblock_small_bwd: stage %d: null argument", i);
+  }
+  const size_t lds = (size_t)4 * CHB;
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)resblock8_bwd_kernel, lds, grant); e != hipSuccess)
+    IDF_FAIL(IDF_ERR_HIP, "resblock_small_bwd: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+  RbBK k;
+  k.a = p;
+  k.thr = idf_drop_thresh(p.p_drop);
+  k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
+  if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
+  hipLaunchKernelGGL(resblock8_bwd_kernel, dim3(p.B), dim3(NT), lds, (hipStream_t)stream, k);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -136,6 +136,9 @@ def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device, pro=0):
     return torch.empty((B, T, Cout, 2), dtype=torch.float32, device=device) if T > 0 else None
 
 
+_FEWC = os.environ.get('IDF_CONV_FEWC', '1') != '0'       # the head conv (Cin <= 3) as one MFMA K-step (idf_conv3x3_fewc_bf16)
+
+
 @functools.lru_cache(maxsize=None)
 def fewc_tiles(B, H, W, Cin, Cout):
     return int(_lib.load().idf_conv_fewc_tiles(B, H, W, Cin, Cout))
@@ -164,7 +167,7 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
         M = B * Ho * Wo
         bgemm_raw(x, 0, w_fwd, 0, y, 0, bias, 1, 0, 0, 0, Cin, Cin, Cout, M, Cout, Cin, 0, 0, res=residual)
         return done()
-    if (taps == 9 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin <= 3 and residual is None
+    if (_FEWC and taps == 9 and mode == S1 and act == 0 and x.dtype == torch.bfloat16 and Cin <= 3 and residual is None
             and fewc_tiles(B, Ho, Wo, Cin, Cout) > 0):
         # the head conv: one MFMA K-step, statistics of y for the first GroupNorm on the way out
         if want_stats:
@@ -1230,6 +1233,7 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
 # ------------------------------------------- image-resident ResBlock at the 8x8 maps
 _RB_SMALL = os.environ.get('IDF_RB_SMALL', '1') != '0'
 _RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '64'))     # one workgroup per image: pays while the batch leaves CUs idle
+_RB_SMALL_BWD = os.environ.get('IDF_RB_SMALL_BWD', '1') != '0'      # ... and its backward (idf_resblock_small_bwd)
 _RB_WFRAG = os.environ.get('IDF_RB_WFRAG', '1') != '0'              # fragment-major weights (modules._Shadows.request_frag): 35.5 -> 23.2 us per block
 
 
@@ -1322,6 +1326,68 @@ class _ResBlockSmall(torch.autograd.Function):
         return outs
 
     @staticmethod
+    def _fused_backward(ctx, dy, dskip, grads):
+        """Stages n-1 .. first of the backward pass as ONE launch (idf_resblock_small_bwd) where the data-gradient weights
+        exist fragment-major and the GroupNorm affine gradients can go straight into their arena slots: fills `grads` for those
+        stages (weight gradients deferred as ever) -> (gradient handed to the stage below / the block's dx, dFiLM_t, dFiLM_a,
+        first), or None (the per-stage launches run)."""
+        meta = ctx.meta
+        n, has_sc, cfgs, slots = meta['nstage'], meta['has_sc'], meta['cfgs'], meta['slots']
+        sv = ctx.saved_tensors
+        x, x2, film_t, film_a, seed = sv[:5]
+        keep = sv[5:5 + 6 * n]
+        tensors = sv[5 + 6 * n:]
+        B = x.shape[0]
+        first = 0 if (x2 is None and not has_sc) else 1
+        if not (_RB_SMALL_BWD and n - first >= 2 and B <= _RB_SMALL_MAXB):
+            return None
+        shadows = [cfgs[i]['shadows'](x.dtype, True) for i in range(n)]
+        if any(shadows[i][3] is None for i in range(first, n)):
+            for i in range(first, n):
+                cfgs[i]['shadows'].request_frag()
+            return None
+        accs = []
+        for i in range(first, n):
+            acc = _gn_acc((slots[4 * i + 2], slots[4 * i + 3]))
+            if acc is None:
+                return None         # (a slot taken twice: gradient accumulation without zero_grad -- the stand-alone path adds)
+            accs.append(acc)
+        dev, dt = x.device, x.dtype
+        A = _lib.ResblockBwdArgs()
+        A.dy, A.nstage, A.first = _p(dy), n, first
+        A.dres2 = _p(dskip) if first == 0 else None
+        A.seed, A.p_drop, A.B = _p(seed), float(ctx.p_drop), B
+        dft = dfa = None
+        dxs = {}
+        for i in range(first, n):
+            S = A.s[i]
+            gx = x if i == 0 else keep[6 * (i - 1) + 1]
+            mean, rstd, sc, sh = keep[6 * i + 2:6 * i + 6]
+            gw, gb = tensors[4 * i + 2], tensors[4 * i + 3]
+            ft, fa = (film_t, film_a) if i == meta['film_stage'] else (None, None)
+            S.w_frag, S.x = _p(shadows[i][3]), _p(gx)
+            S.gamma, S.beta, S.film_t, S.film_a, S.ld_t, S.ld_a = _p(gw), _p(gb), _p(ft), _p(fa), _ld(ft), _ld(fa)
+            S.mean, S.rstd, S.sc, S.sh = _p(mean), _p(rstd), _p(sc), _p(sh)
+            S.salt, S.drop = cfgs[i]['salt'], int(bool(meta['drop'][i]) and seed is not None)
+            if ft is not None:
+                dft = torch.empty(ft.shape, dtype=torch.float32, device=dev)
+            if fa is not None:
+                dfa = torch.empty(fa.shape, dtype=torch.float32, device=dev)
+            S.dfilm_t, S.dfilm_a = (_p(dft), _p(dfa)) if (ft is not None or fa is not None) else (None, None)
+            acc = accs[i - first]
+            S.dgb, S.dgamma_acc, S.dbeta_acc = None, _p(acc[0]), _p(acc[1])
+            dxs[i] = torch.empty_like(gx, memory_format=CL)
+            S.dx = _p(dxs[i])
+        call('idf_resblock_small_bwd', ctypes.byref(A), _st())
+        for i in range(n - 1, first - 1, -1):
+            gi = dy if i == n - 1 else dxs[i + 1]          # the gradient of stage i's conv output
+            ws, bs = slots[4 * i], slots[4 * i + 1]
+            dW, db = conv_wgrad_bias_raw(keep[6 * i], gi, S1, 9, True, ws, bs, _grad_free(ws) and _grad_free(bs))
+            acc = accs[i - first]
+            grads[4 * i:4 * i + 4] = [dW, db, acc[0], acc[1]]
+        return dxs[first], dft, dfa, first
+
+    @staticmethod
     def backward(ctx, dy, _dst, *dalias):
         meta = ctx.meta
         n, has_sc, cfgs, slots = meta['nstage'], meta['has_sc'], meta['cfgs'], meta['slots']
@@ -1342,7 +1408,12 @@ class _ResBlockSmall(torch.autograd.Function):
         # the residual branch: an identity joins the first stage's GroupNorm backward as it stands, a 1x1 shortcut first
         # takes its weight gradient (over the raw input, read in place) and its data gradient
         ds = g
-        for i in range(n - 1, 0, -1):
+        fused = _ResBlockSmall._fused_backward(ctx, g, dskip, grads)
+        if fused is not None:
+            g, dft, dfa, first = fused
+            if first == 0:           # the launch went all the way down to the block input
+                return (g, None, dft, dfa, None, None, None, None) + tuple(grads)
+        for i in (range(n - 1, 0, -1) if fused is None else ()):
             a, h_prev = keep[6 * i], keep[6 * (i - 1) + 1]
             mean, rstd, sc, sh = keep[6 * i + 2:6 * i + 6]
             w, b, gw, gb = tensors[4 * i:4 * i + 4]

@@ -58,9 +58,10 @@ def make_args(a):
 
 
 # the oracle's convs stop scaling (and oversubscribe) far below the box's 256 cores: measured on the MI355X host at B = 32,
-# s per train step -- 32 threads 3.9-5.1, 64 threads 8.7-10, 128 threads 18-25 (profiles/r03_cpu_baseline_threads.txt; 8 and
-# 16 threads: profiles/r04_cpu_baseline_threads.txt, tools/cpu_threads_sweep.sh); IDF_CPU_THREADS overrides for such a sweep
-CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '32'))
+# s per train step (steps 2-4) / s per backbone evaluation -- 8 threads 3.8-4.7 / 0.28, 16 threads 3.0-4.6 / 0.16, 32 threads
+# 4.7-5.8 / 0.31 (profiles/r04_cpu_baseline_threads.txt, tools/cpu_threads_sweep.sh); 64 threads 8.7-10, 128 threads 18-25
+# (profiles/r03_cpu_baseline_threads.txt).  16 is the fastest measured: the default.  IDF_CPU_THREADS overrides for a sweep
+CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '16'))
 CPU_BATCH = 32        # the benchmarked batch, 1 warm-up + 3 timed steps; then 3 backbone evaluations
 
 

@@ -306,6 +306,11 @@ int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* 
                         int target_blocks, int blk0, int* blocks_out, int* lds_out);
 int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
                                 void* stream);
+/* the same launch on part of the chip: max_blocks > 0 bounds the grid to max_blocks CUs' worth of workgroups (rounded up to a
+ * multiple of 8), each looping over the table's work items -- for a launch issued on a side stream beside the data-gradient
+ * chain, whose own launches need free CUs.  max_blocks <= 0: one workgroup per work item (idf_conv_wgrad_bf16_batched). */
+int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
+                                       int max_blocks, void* stream);
 
 /* fp32 master weight (logical (o,i,tap) at o*so+i*si+tap*st) -> forward shadow
  * [O][taps][I] and/or data-gradient shadow [I][taps flipped][O], in `dtype`. */

@@ -295,9 +295,11 @@ struct WgDesc {
   int blk0, gx, gy, xcd;   // xcd = 1: blocks [blk0, blk0 + gx * roundup8(gy)) in XCD-major order
 };
 
-template <int KW, int MODE>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16_batched(const WgDesc* __restrict__ tab, int n) {
-  const int bid = blockIdx.x;
+// `total` work items (the 1-D block ids of the table) over a grid of gridDim.x <= total blocks: block b takes items b, b + grid, ...
+// A grid smaller than `total` keeps the launch on part of the chip (idf_conv_wgrad_bf16_batched_capped: weight gradients running
+// on a side stream beside the data-gradient chain must leave CUs free for the chain's launches).
+template <int KW, int MODE, int ROWS>
+__device__ __forceinline__ void wgrad_item(const WgDesc* __restrict__ tab, int n, int bid) {
   int lo = 0, hi = n;
   while (hi - lo > 1) {
     int mid = (lo + hi) >> 1;
@@ -313,32 +315,26 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16_batched(const WgDes
     const int x = local & 7, j = local >> 3;
     const int by = x + 8 * (j / gx);
     if (by >= d->gy) return;
-    wgrad_block<KW, MODE>(p, j % gx, by);
+    wgrad_block<KW, MODE, ROWS>(p, j % gx, by);
   } else {
     if (local >= gx * d->gy) return;      // alignment padding
-    wgrad_block<KW, MODE>(p, local % gx, local / gx);
+    wgrad_block<KW, MODE, ROWS>(p, local % gx, local / gx);
+  }
+}
+
+template <int KW, int MODE>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16_batched(const WgDesc* __restrict__ tab, int n, int total) {
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    if (bid != (int)blockIdx.x) __syncthreads();          // the previous item's last LDS reads
+    wgrad_item<KW, MODE, 1>(tab, n, bid);
   }
 }
 
 // the shared-tile form of the stride-1 3x3 class (768 threads, one block per CU)
-__global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDesc* __restrict__ tab, int n) {
-  const int bid = blockIdx.x;
-  int lo = 0, hi = n;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (tab[mid].blk0 <= bid) lo = mid; else hi = mid;
-  }
-  const WgDesc* d = tab + lo;
-  const WgP p = d->p;
-  const int local = bid - d->blk0, gx = d->gx;
-  if (d->xcd) {
-    const int x = local & 7, j = local >> 3;
-    const int by = x + 8 * (j / gx);
-    if (by >= d->gy) return;
-    wgrad_block<3, 0, 3>(p, j % gx, by);
-  } else {
-    if (local >= gx * d->gy) return;      // alignment padding
-    wgrad_block<3, 0, 3>(p, local % gx, local / gx);
+__global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDesc* __restrict__ tab, int n, int total) {
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    if (bid != (int)blockIdx.x) __syncthreads();
+    wgrad_item<3, 0, 3>(tab, n, bid);
   }
 }
 
@@ -496,8 +492,8 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   return IDF_OK;
 }
 
-extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
-                                           int mode, void* stream) {
+extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
+                                                  int mode, int max_blocks, void* stream) {
   if (n <= 0 || total_blocks <= 0) return IDF_OK;
   const bool rowsplit = (mode & 16) != 0;
   mode &= 15;
@@ -505,17 +501,30 @@ extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int tot
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16_batched: bad arguments (taps %d mode %d)", taps, mode);
   hipStream_t st = (hipStream_t)stream;
   const WgDesc* tab = (const WgDesc*)dev_table;
-  dim3 g(total_blocks);
-  if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n);
-  else if (mode == 0 && g_kr3 && !rowsplit) {
+  const bool kr3 = taps == 9 && mode == 0 && g_kr3 && !rowsplit;
+  // max_blocks counts 768-thread blocks (one per CU); the 256-thread classes fit three to a CU
+  int grid = total_blocks;
+  if (max_blocks > 0) {
+    const int cap = kr3 ? max_blocks : 3 * max_blocks;
+    if (grid > cap) grid = (cap + 7) / 8 * 8;              // whole rounds of the 8 XCDs: item -> XCD stays what the table assumes
+    if (grid > total_blocks) grid = total_blocks;
+  }
+  dim3 g(grid);
+  if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  else if (kr3) {
     static IdfLdsGrant grant;
     if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_tr_bf16_batched_kr3, (size_t)lds_bytes, grant); e != hipSuccess)
       IDF_FAIL(IDF_ERR_HIP, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
-    hipLaunchKernelGGL(conv_wgrad_tr_bf16_batched_kr3, g, dim3(768), lds_bytes, st, tab, n);
+    hipLaunchKernelGGL(conv_wgrad_tr_bf16_batched_kr3, g, dim3(768), lds_bytes, st, tab, n, total_blocks);
   }
-  else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n);
-  else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 1>), g, dim3(256), lds_bytes, st, tab, n);
-  else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n);
+  else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 1>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
+}
+
+extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
+                                           int mode, void* stream) {
+  return idf_conv_wgrad_bf16_batched_capped(dev_table, n, total_blocks, lds_bytes, taps, mode, 0, stream);
 }

@@ -5,6 +5,8 @@ names, constructor / forward / loss_fn signatures, attribute names and state_dic
 keys.  Extra, optional knob: `args.act_dtype` ('fp32' default, or 'bf16') selects
 the activation / weight-shadow storage type of the kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import init
@@ -116,12 +118,20 @@ class _UNetSkeleton(nn.Module):
             first = False
         for layer in self.upblocks:
             if isinstance(layer, UpSample):
+                small = h.shape[-1] <= _WGRAD_POINT_MAXW
                 h = layer(h)
+                if alias_mode and small and h.shape[-1] > _WGRAD_POINT_MAXW:
+                    # the backward pass leaves the big maps here: the weight gradients queued so far start on the side
+                    # stream and fill the CUs the small-map launches leave idle (ops.WgradBatch.flush_async)
+                    h = ops.wgrad_point(h)
             else:
                 h = block_call(layer, (h, skips.pop()))      # the block reads the pair in place (no torch.cat)
         assert len(skips) == 0
         gn, conv = self.tail[0], self.tail[-1]
         return ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias, x_single_use=True)
+
+
+_WGRAD_POINT_MAXW = int(os.environ.get('IDF_WGRAD_POINT_MAXW', '16'))
 
 
 class UNet(_UNetSkeleton):
@@ -433,6 +443,8 @@ class InfoDiff(nn.Module):
             leaf = lat.detach().requires_grad_(True)
             self._latent_cut = (lat, leaf)
             lat = a = leaf
+        elif torch.is_grad_enabled() and lat.requires_grad:
+            lat = ops.wgrad_point(lat)       # the backbone's backward is through: its weight gradients run beside the encoder's
         output = self.backbone(x_tilde, idx, lat)
         return (output, epsilon, a, mu, log_var) if get_target else output
 

@@ -671,11 +671,17 @@ class WgradBatch:
     _LRU = 6
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
-    # Flushes issued DURING backward (`flush_async`: the data-parallel latent hook of InfoDiff.forward) can run on a side
-    # stream next to the data-gradient chain; the end-of-backward flush joins it again.
-    # Off by default: measured on one GPU the chain slows down by more than the weight gradients hide (10.11 -> 10.25 ms
-    # with one early flush, 11.2 ms with a flush every 8 queued convs: profiles/r03_v_ab_wgrad_side.txt).
+    # Flushes issued DURING backward (`flush_async`, from `wgrad_point` hooks the networks plant where the backward pass leaves
+    # the big maps) can run on a side stream next to the data-gradient chain; the end-of-backward flush joins it again.  Such a
+    # launch is CAPPED (`side_cap` CUs' worth of blocks, each looping over the work items), because an uncapped one takes every
+    # CU for ~100 us per block and the chain's launches queue behind it.
+    # OFF by default -- measured three ways, never a gain on one GPU: round 3 uncapped 10.11 -> 10.25 ms (one early flush) and
+    # 11.2 ms (a flush every 8 convs), profiles/r03_v_ab_wgrad_side.txt; round 4 capped at 128 CUs from the two points the
+    # backward pass leaves the big maps: 9.35 -> 9.41 ms (cap 64: 9.50, cap 192: 9.65), profiles/r04_wgrad_side_capped.txt --
+    # the launches do overlap (kernel trace: 2.06 ms of 11.04 ms kernel time concurrent), but the latency-bound chain
+    # launches slow down by as much beside a 3-TB/s neighbour.  IDF_WGRAD_SIDE=1 opts in.
     side_enabled = os.environ.get('IDF_WGRAD_SIDE', '0') != '0'
+    side_cap = int(os.environ.get('IDF_WGRAD_SIDE_CAP', '128'))
     _side = None
     _inflight = []     # operands of side-stream flushes, kept alive until the join
     _cb_queued = False
@@ -712,11 +718,10 @@ class WgradBatch:
 
     @classmethod
     def flush_async(cls):
-        """Launch what is queued so far on the side stream; the current stream carries on with backward."""
-        if not cls.pending:
-            return
-        if not cls.side_enabled or not cls._cb_queued or not cls.pending[0][0].is_cuda:
-            cls._flush_pending()
+        """Launch what is queued so far on the side stream (capped grid); the current stream carries on with backward.
+        Without a side stream (IDF_WGRAD_SIDE=0, CPU tensors, outside a backward pass) nothing happens: the items wait
+        for the end-of-backward flush."""
+        if not cls.pending or not cls.side_enabled or not cls._cb_queued or not cls.pending[0][0].is_cuda:
             return
         cur = torch.cuda.current_stream()
         if cls._side is None:
@@ -724,7 +729,7 @@ class WgradBatch:
         cls._side.wait_stream(cur)
         cls._inflight.extend(cls.pending)       # the caching allocator must not recycle them before the join
         with torch.cuda.stream(cls._side):
-            cls._flush_pending()
+            cls._flush_pending(cls.side_cap)
 
     @classmethod
     def flush(cls):
@@ -736,7 +741,7 @@ class WgradBatch:
             cls._inflight = []
 
     @classmethod
-    def _flush_pending(cls):
+    def _flush_pending(cls, cap=0):
         items, cls.pending = cls.pending, []
         if not items:
             return
@@ -807,7 +812,18 @@ class WgradBatch:
         base = buf[1].data_ptr()
         plan = buf[3]
         for off, n, blk, lds, taps, mode in plan:
-            call('idf_conv_wgrad_bf16_batched', base + off * nb, n, blk, lds, taps, mode, _st())
+            call('idf_conv_wgrad_bf16_batched_capped', base + off * nb, n, blk, lds, taps, mode, cap, _st())
+
+
+def wgrad_point(h):
+    """Mark `h` as a point of the backward pass where the weight gradients queued so far may start on the side stream
+    (`WgradBatch.flush_async`): the hook fires when the gradient of `h` is complete, i.e. when every consumer of `h` --
+    everything downstream of it in the forward pass -- has run its backward."""
+    if WgradBatch.enabled and WgradBatch.side_enabled and h.requires_grad and h.is_cuda:
+        def _go(g):
+            WgradBatch.flush_async()
+        h.register_hook(_go)
+    return h
 
 
 def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, defer=False):

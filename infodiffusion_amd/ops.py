@@ -1248,7 +1248,9 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
 
 # ------------------------------------------- image-resident ResBlock at the 8x8 maps
 _RB_SMALL = os.environ.get('IDF_RB_SMALL', '1') != '0'
-_RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '64'))     # one workgroup per image: pays while the batch leaves CUs idle
+# one workgroup per image.  Measured up to B = 256 (profiles/r04_resblock_small.txt): DDIM-100 at B = 256 291 -> 303 img/s, the
+# B = 128 train step 4958 -> 4994 img/s against a limit of 64; the per-conv fragment-major form (_WR_MAXB) LOSES beyond 64 (276 img/s)
+_RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '256'))
 _RB_SMALL_BWD = os.environ.get('IDF_RB_SMALL_BWD', '1') != '0'      # ... and its backward (idf_resblock_small_bwd)
 _RB_WFRAG = os.environ.get('IDF_RB_WFRAG', '1') != '0'              # fragment-major weights (modules._Shadows.request_frag): 35.5 -> 23.2 us per block
 

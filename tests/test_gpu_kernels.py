@@ -785,7 +785,7 @@ def test_wgrad_batch_survives_a_backward_pass_that_raised():
         assert float((again[k] - clean[k]).abs().max()) <= 1e-5 * max(1.0, float(clean[k].abs().max())), k
 
 
-@pytest.mark.parametrize('split', [0, 5])
+@pytest.mark.parametrize('split', [0, 5, 11])
 def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
     """All weight gradients of a backward pass from ONE table-driven launch per (taps, mode) class
     (idf_conv_wgrad_bf16_batched, accumulating into gradient-arena slots) == the per-conv launches.  `split`: the first
@@ -815,6 +815,9 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
         if split and i + 1 == split:
             assert all(float(o[0].abs().max()) == 0.0 for o in outs)      # nothing launched yet
             monkeypatch.setattr(ops.WgradBatch, 'side_enabled', True)
+            # a grid of 8 (3x3 shared-tile class) / 24 workgroups looping over every work item of its class
+            # (idf_conv_wgrad_bf16_batched_capped): same sums as one workgroup per item
+            monkeypatch.setattr(ops.WgradBatch, 'side_cap', 8)
             ops.WgradBatch.flush_async()
             assert not ops.WgradBatch.pending and ops.WgradBatch.side_stream() is not None
     assert len(ops.WgradBatch.pending) == len(cases) - split

@@ -241,6 +241,50 @@ class LaunchRecorder:
             if a[3]:
                 bufs.append((3, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin + 2.0 * px * Cout * sc_Cin
+        if name == 'idf_conv3x3_fewc_bf16':      # the head conv (Cin <= 3): one MFMA K-step per output tile
+            B, H, W, Cin, Cout = a[4:9]
+            px = B * H * W
+            return 'conv3x3', [(0, px * Cin * 2), (3, px * Cout * 2)], 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_wr_gn_bf16':        # small maps, fragment-major weights: GroupNorm-prologue conv
+            C1 = a[2]
+            B, H, W, Cin, Cout = a[27:32]
+            px = B * H * W
+            bufs = [(0, px * (C1 if a[1] else Cin) * 2), (20, px * Cout * 2)]
+            if a[1]:
+                bufs.append((1, px * (Cin - C1) * 2))
+            if a[19]:
+                bufs.append((19, px * Cout * 2))
+            if a[21]:
+                bufs.append((21, px * Cin * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_wr_dgrad_gn_bf16':  # ... data-gradient conv + GroupNorm backward
+            B, H, W, Cin, Cout = a[24:29]
+            px = B * H * W
+            bufs = [(0, px * Cin * 2), (2, px * Cout * 2), (5, px * Cout * 2)]
+            bufs += [(i, px * Cout * 2) for i in (3, 4) if a[i]]
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_resblock_small_fwd':     # image-resident 8x8 ResBlock: 2-3 convs (+ the 1x1 shortcut) in one launch
+            A = a[0]._obj
+            px, n = A.B * 64, A.nstage
+            bufs = [('x', px * (A.C1 if A.x2 else A.Cin) * 2), ('y', px * 128 * 2)]
+            if A.x2:
+                bufs.append(('x2', px * (A.Cin - A.C1) * 2))
+            for i in range(n):
+                if A.s[i].a_out:
+                    bufs.append((('s', i, 'a_out'), px * (A.Cin if i == 0 else 128) * 2))
+                if A.s[i].h_out and i < n - 1:           # (the last stage's h_out IS y)
+                    bufs.append((('s', i, 'h_out'), px * 128 * 2))
+            work = 2.0 * px * 128 * 9 * (A.Cin + 128 * (n - 1)) + (2.0 * px * 128 * A.Cin if A.w_sc else 0.0)
+            return 'conv3x3', bufs, work
+        if name == 'idf_resblock_small_bwd':     # ... its data-gradient convs + GroupNorm backwards
+            A = a[0]._obj
+            px, n = A.B * 64, A.nstage - A.first
+            bufs = [('dy', px * 128 * 2)]
+            if A.dres2:
+                bufs.append(('dres2', px * 128 * 2))
+            for i in range(A.first, A.nstage):
+                bufs += [(('s', i, 'x'), px * 128 * 2), (('s', i, 'dx'), px * 128 * 2)]
+            return 'conv3x3', bufs, 2.0 * px * 128 * 9 * 128 * n
         if name == 'idf_gn_bwd_apply':
             C1 = a[5]
             B, HW, C = a[24:27]
@@ -281,7 +325,16 @@ class LaunchRecorder:
 
         def recorded(name, *args):
             sp = rec._spec(name, args)
-            if sp is not None:
+            if sp is not None and name.startswith('idf_resblock_small_'):
+                import ctypes
+                A = args[0]._obj
+                key = (name, A.B, A.nstage, getattr(A, 'first', 0), getattr(A, 'Cin', 128), bool(getattr(A, 'w_sc', None)),
+                       tuple(n for _, n in sp[1]))
+                if key in rec.calls:
+                    rec.calls[key][0] += 1
+                else:          # a private copy of the argument block: the caller's goes away with its autograd node
+                    rec.calls[key] = [1, (name, (ctypes.byref(type(A).from_buffer_copy(A)), args[1]))]
+            elif sp is not None:
                 ptr = {i for i, _ in sp[1]}
                 si = rec._stream_idx(name, args)
                 key = (name,) + tuple((v is not None) if (i in ptr or isinstance(v, int) and v > (1 << 32)) else v
@@ -306,7 +359,26 @@ class LaunchRecorder:
             per_set = sum(n for _, n in bufs)
             K = max(4, min(16, -(-(320 << 20) // per_set)))
             sets = []
-            for k in range(K):
+            for k in range(K if name.startswith('idf_resblock_small_') else 0):
+                import ctypes
+                A = type(args[0]._obj).from_buffer_copy(args[0]._obj)
+                keep = [A]
+                for path, n in bufs:
+                    t = torch.randn(n // 2, device=dev, dtype=torch.bfloat16)
+                    keep.append(t)
+                    if isinstance(path, tuple):
+                        setattr(A.s[path[1]], path[2], t.data_ptr())
+                    else:
+                        setattr(A, path, t.data_ptr())
+                if name == 'idf_resblock_small_fwd':
+                    A.s[A.nstage - 1].h_out = A.y
+                if name == 'idf_resblock_small_bwd':     # not into the live gradient arena: per-sample sums to scratch
+                    for i in range(A.first, A.nstage):
+                        t = torch.empty(A.B * 2 * 128, device=dev, dtype=torch.float32)
+                        keep.append(t)
+                        A.s[i].dgb, A.s[i].dgamma_acc, A.s[i].dbeta_acc = t.data_ptr(), None, None
+                sets.append(([ctypes.byref(A), None], keep))
+            for k in range(0 if sets else K):
                 al = list(args)
                 keep = []
                 for i, n in bufs:
@@ -320,6 +392,11 @@ class LaunchRecorder:
                     al[20], al[21], al[22] = t.data_ptr(), None, None
                 if name == 'idf_conv_dgrad_gn_bf16':
                     B_, C_ = al[25], al[29]
+                    t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
+                    keep.append(t)
+                    al[18], al[19], al[20] = t.data_ptr(), None, None
+                if name == 'idf_conv_wr_dgrad_gn_bf16':
+                    B_, C_ = al[24], al[28]
                     t = torch.empty(B_ * 2 * C_, device=dev, dtype=torch.float32)
                     keep.append(t)
                     al[18], al[19], al[20] = t.data_ptr(), None, None
@@ -517,12 +594,14 @@ def main():
         if 'conv3x3' in fam:
             n, ms, fl, by = fam['conv3x3']
             ach = fl / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16: forward incl. '
-                                         'GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
+            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16 / conv3x3_fewc_bf16, and on the '
+                                         'small maps conv_wr_kernel / resblock8_fwd_kernel / resblock8_bwd_kernel, whose launches hold 2-3 convs: '
+                                         'forward incl. GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
                                          'GroupNorm backward (small maps) or its du / partial-sum half (big maps))',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
-                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16']),
+                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel',
+                                                            'resblock8_fwd_kernel', 'resblock8_bwd_kernel']),
                                'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                'timing': 'cold: each replayed launch on its own buffer set, sets > 256 MB together',
                                'algorithmic_gflop_per_step': round(fl / 1e9, 1),

@@ -145,7 +145,7 @@ def cpu_baseline(margs, budget_s=240):
     res = {'value': round(CPU_BATCH / t, 3), 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
            'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
                      '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores; ATen convs do not scale '
-                     'past a few dozen threads: profiles/r03_cpu_baseline_threads.txt): %d timed step(s) after 1 warm-up, '
+                     'past a few dozen threads: profiles/r04_cpu_baseline_threads.txt): %d timed step(s) after 1 warm-up, '
                      '%.2f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0, len(timed), t)}
     if len(evals) > 1:
         te = sum(evals[1:]) / len(evals[1:])

@@ -1841,13 +1841,14 @@ void launch_ps(C3P& p, const PsPlan& pl, hipStream_t st) {
   p.R = pl.R; p.tiles_per_img = pl.T; p.n_tiles = idf_cdiv(p.Cout, 64); p.wh_magic = pl.magic_row;
   p.ps_NI = pl.NI; p.ps_rwshift = pl.rwshift; p.ps_npi = pl.npi; p.ps_magic_img = pl.magic_img;
   p.ps_nptiles = pl.nptiles; p.ps_work = pl.work; p.ps_hbytes = pl.hgroups * 1024; p.aux_off = pl.aux_off;
-  static int ncu = 0;
-  if (!ncu) {
+  // CU count of the current device, read once (a C++11 magic static: initialised exactly once under concurrent first calls;
+  // one process drives one GPU here, so "the current device at first use" is the device)
+  static const int ncu = [] {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ncu = 256;
-    else ncu = prop.multiProcessorCount;
-  }
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
   const int per = idf_cdiv(pl.work, ncu);                  // work items per block, then an even spread
   const int G = idf_cdiv(pl.work, per);
   if (p.res) launch_ps_r<KS, DUAL, PRO, true>(p, pl, G, st);

@@ -2062,7 +2062,9 @@ extern "C" int idf_conv_dgrad_gn_ok(int B, int H, int W, int Cin, int Cout, int 
   int BM;
   (void)B;
   if (!dgrad_gn_plan(H, W, Cin, Cout, taps, &BM)) return 0;
-  static const int one = getenv("IDF_DGRAD_GN_1X1") ? atoi(getenv("IDF_DGRAD_GN_1X1")) : 0;
+  // the attention block's q/k/v data gradient (1x1, 3C -> C) with its GroupNorm backward as the epilogue: 12 launches fewer per
+  // CelebA step, 9.376 -> 9.347 ms (same-box A/B, profiles/r04_conv_wr.txt); IDF_DGRAD_GN_1X1=0: du epilogue + apply pass
+  static const int one = getenv("IDF_DGRAD_GN_1X1") ? atoi(getenv("IDF_DGRAD_GN_1X1")) : 1;
   return ((taps == 9 || one) && H * W <= g_dgn_maxhw) ? 1 : 2;
 }
 

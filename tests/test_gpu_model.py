@@ -666,15 +666,21 @@ def test_bf16_train_step_a_dim_256_at_the_per_gpu_batch():
            'eps': torch.randn(B, *cfg.shape, generator=gen), 'reparam': torch.zeros(B, 256),
            'prior': torch.randn(B, 256, generator=gen)}
     opt = FusedClipAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_norm=1.0)
-    with _ReplayedDraws(fix):
-        loss = model.loss_fn(args_of(cfg), fix['x'].to(DEV))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
     ref_loss, ref_grads, ref_gn = _oracle_step(cfg, sd, fix)
-    assert rel(loss, ref_loss) < 1e-2, (float(loss), float(ref_loss))
-    gn = float(opt.total_norm())
-    assert abs(gn - ref_gn) / ref_gn < 2e-2, (gn, ref_gn)
+    # two passes on the same draws (lr 0): the first runs before the fragment-major weight shadows exist (the small-map convs
+    # still take the register-staged kernels), the second is the steady state the benchmark measures -- image-resident 8x8
+    # blocks, fragment-major 16x16 convs.  Loss and gradient norm are held on both; the per-parameter band on the steady state
+    # (measured worst rel-L2: 0.34 on the first pass -- the encoder's one-element tail bias, a cancelling sum over 131072
+    # bf16 values -- and 0.18 on the second).
+    for steady in (False, True):
+        with _ReplayedDraws(fix):
+            loss = model.loss_fn(args_of(cfg), fix['x'].to(DEV))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        assert rel(loss, ref_loss) < 1e-2, (steady, float(loss), float(ref_loss))
+        gn = float(opt.total_norm())
+        assert abs(gn - ref_gn) / ref_gn < 2e-2, (steady, gn, ref_gn)
     n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)), 'a_dim 256, B=32')
     assert n > 500
 

@@ -429,6 +429,21 @@ int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum,
 int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse, const void* o, void* dqkv, int B, int N, int D,
                    float scale, int dtype, void* stream);
 
+/* The whole attention block (modules.py:145-164) of the N = 256-token level at C = 128 in ONE launch (round 4):
+ *   y = x + proj(softmax(q k^T scale) v),   q | k | v = conv1x1(GroupNorm(x))
+ * one workgroup per image; x [B, N, C] bf16 is the only activation read.  st [B][T][C][2]: the statistics partials x's producer
+ * left behind (the GroupNorm's mean / rstd are folded from them in-kernel, as the GroupNorm-prologue convs do); gamma / beta:
+ * the GroupNorm's affine; wqkv_frag: the q | k | v weights [3C][C] in the fragment-major shadow form
+ * (idf_pack_conv_weights_batched, `wfrag`, taps 1); bqkv [3C]; wp [C][C]: the proj conv's forward shadow; bp [C].
+ * y [B, N, C]; st_out [B][1][C][2] (optional): statistics partials of y.  Training outputs, all or none: qkv [B, N, 3C], h =
+ * GroupNorm(x) [B, N, C] (the q / k / v weight gradient's operand), o [B, N, C], lse [B, N], mean / rstd [B, 32], sc / sh [B, C] --
+ * exactly what idf_conv_gn_bf16 + idf_attn_fwd leave behind, so the backward pass is the existing launches. */
+int idf_attnblock_ok(int N, int C, int dtype);
+int idf_attnblock_fwd(const void* x, const float* st, int T, const float* gamma, const float* beta, float eps,
+                      const void* wqkv_frag, const float* bqkv, const void* wp, const float* bp, void* y, float* st_out,
+                      void* qkv, void* h, void* o, float* lse, float* mean, float* rstd, float* sc, float* sh, float scale,
+                      int B, int N, int C, void* stream);
+
 /* ---- elementwise / reductions */
 /* Input pipeline on the device (reference data.py:149-171, ToTensor -> RandomHorizontalFlip -> Normalize):
  * uint8 NHWC image bytes -> fp32 NHWC-dense (x / 255 - 0.5) / 0.5, bit-identical to the torchvision chain;

@@ -19,6 +19,7 @@
 //   bwd-B : LDS = Q, dO      rows = keys      P^T, dS^T from the saved row statistics
 //                                             dV = P^T dO, dK = dS^T Q
 #include "idf_common.h"
+#include "idf_gnfold.h"
 #include <atomic>
 #include <stdlib.h>
 
@@ -320,6 +321,331 @@ __global__ __launch_bounds__(ANT) void attn_bwd_kernel(const bf16_t* __restrict_
   else attn_bwd_kv_body<D, AN>(qkv, dO, lse, nullptr, o, dqkv, scale, smem);
 }
 
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends with the total)
+__device__ __forceinline__ float row16_sum_ab(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// ---------------------------------------------------------------- the whole attention block in ONE launch
+// modules.py:145-164 for the N = 256-token level at C = 128:  y = x + proj(softmax(q k^T C^-1/2) v),  q | k | v = conv1x1(GroupNorm(x)).
+// One 8-wave workgroup per image, K and V of the image in LDS (as attn_fwd_kernel keeps them), nothing but x read:
+//   fold   GroupNorm coefficients (sc, sh) per channel from the statistics partials x's producer left behind
+//   K | V  eight slabs of 32 pixels: h = x * sc + sh staged as bf16 (four 32-channel chunk images, pixel pitch 96 B: conflict-free
+//          ds_read_b128), each wave owns 64 of the 256 K | V couts with its 16 weight fragments in registers (fragment-major
+//          shadow: 1 KB per wave instruction), results + bias rounded to bf16 straight into the K / V tiles
+//   Q      per 16-row block of a wave, from x's rows (registers) and the 32 q fragments in registers; the MFMA result leaves a
+//          lane holding 4 consecutive channels of ITS row per 16-channel tile -- which IS a B operand of the score product once
+//          the contraction's channel order is permuted the same way on the K side (two ds_read_b64 instead of one b128)
+//   P V    scores, softmax and the output product exactly as attn_fwd_kernel (same functions)
+//   proj   O of a row block stays in registers as B fragments (the same permutation); after the last score product the K
+//          tile's LDS takes the proj weights with their channels permuted to match; epilogue: + bias + x (residual), bf16,
+//          per-channel statistics of y for the next GroupNorm
+// Training additionally stores what the backward pass reads (q | k | v, h for the weight gradient, O, the row logsumexp, the
+// GroupNorm's mean / rstd / sc / sh): the data-gradient side stays the existing launches.
+struct AbP {
+  const bf16_t* x; const float* st; int T;
+  const float* gamma; const float* beta; float eps;
+  const bf16_t* wqkv; const float* bqkv; const bf16_t* wp; const float* bp;
+  bf16_t* y; float* st_out;
+  bf16_t* qkv; bf16_t* h; bf16_t* o; float* lse; float* mean; float* rstd; float* sc; float* sh;
+  float scale;
+};
+constexpr int AB_SLAB = 32, AB_PPB = 96;
+constexpr size_t AB_LDS = (size_t)2 * 256 * ACfg<128>::PITCH * sizeof(bf16_t) + (size_t)4 * AB_SLAB * AB_PPB + 128 * 2 * sizeof(float);
+
+__device__ __forceinline__ void ab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ s16x4_t ab_read8(const bf16_t* p) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) s16x4_t*>(
+      (const __attribute__((address_space(3))) unsigned char*)(p));
+}
+__device__ __forceinline__ void ab_unpack(const uint4& r, float* o) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint32_t ab_pack2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+// the B fragments of a product contracting over channels, from accumulator tiles that hold channels 16 c + 4 (lane >> 4) + r:
+// k slot (g, e) of step s = channel 32 s + 4 g + e (e < 4) / 32 s + 16 + 4 g + e - 4
+__device__ __forceinline__ void ab_frags(const f32x4_t (&t)[8], const float4* bias, bf16x8_t (&f)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf16x8_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b0 = bias ? (&bias[2 * s].x)[r] : 0.f, b1 = bias ? (&bias[2 * s + 1].x)[r] : 0.f;
+      v[r] = (__bf16)(t[2 * s][r] + b0); v[4 + r] = (__bf16)(t[2 * s + 1][r] + b1);
+    }
+    f[s] = v;
+  }
+}
+
+// NW waves per workgroup (4 or 8): each owns 16 / NW of the 16 K | V cout fragments and 16 / NW of the 16 query-row blocks
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attnblock_fwd_kernel(const AbP p) {
+  constexpr int D = 128, AN = 256, PITCH = ACfg<D>::PITCH;
+  constexpr int NT = 64 * NW, KVF = 16 / NW, RBW = 16 / NW, SVT = 512 / NT;     // threads; K | V fragments, row blocks per wave; staged vectors per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vs = Ks + AN * PITCH;
+  unsigned char* slab = reinterpret_cast<unsigned char*>(Vs + AN * PITCH);
+  float* cof = reinterpret_cast<float*>(slab + 4 * AB_SLAB * AB_PPB);      // [128][2] (sc, sh)
+  float* scr = reinterpret_cast<float*>(slab);                             // fold scratch [128][2]; at the end statistics [NW][128][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int b = blockIdx.x;
+  const bf16_t* xb = p.x + (size_t)b * AN * D;
+  const bool train = p.qkv != nullptr;
+
+  // ---- GroupNorm coefficients (the arithmetic of idf_conv3x3.hip's pro_coefficients: same partials, same order, same bits)
+  if (tid < D) {
+    const float2 S = idf_sum_partials(reinterpret_cast<const float2*>(p.st) + (size_t)b * p.T * D + tid, p.T, (size_t)D);
+    scr[2 * tid] = S.x; scr[2 * tid + 1] = S.y;
+  }
+  __syncthreads();
+  if (tid < D) {
+    const int c = tid, g0 = c & ~3;
+    double a = 0.0, d = 0.0;
+    for (int k = g0; k < g0 + 4; ++k) { a += scr[2 * k]; d += scr[2 * k + 1]; }
+    const double n = (double)AN * 4.0;
+    double mu = a / n, var = d / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    const float sc = r * ga, sh = be - mf * sc;
+    cof[2 * c] = sc; cof[2 * c + 1] = sh;
+    if (p.sc) {
+      p.sc[(size_t)b * D + c] = sc; p.sh[(size_t)b * D + c] = sh;
+      if (c == g0) { p.mean[b * 32 + (c >> 2)] = mf; p.rstd[b * 32 + (c >> 2)] = r; }
+    }
+  }
+  __syncthreads();
+
+  // ---- K | V: slabs of 32 pixels
+  {
+    const int sv = tid & 15, spx = tid >> 4;       // this thread stages channel vector sv of pixels spx (+ 16 with four waves) of a slab
+    float scv[8], shv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { scv[e] = cof[2 * (sv * 8 + e)]; shv[e] = cof[2 * (sv * 8 + e) + 1]; }
+    const int soff = (sv >> 2) * (AB_SLAB * AB_PPB) + (sv & 3) * 16;
+    uint4 xr[SVT];
+#pragma unroll
+    for (int j = 0; j < SVT; ++j) xr[j] = *reinterpret_cast<const uint4*>(xb + (size_t)(spx + 16 * j) * D + sv * 8);
+    bf16x8_t wkv[KVF][4];
+    float4 bkv[KVF];
+#pragma unroll
+    for (int j = 0; j < KVF; ++j) {
+      const int nf = 8 + KVF * wave + j;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        wkv[j][s] = *reinterpret_cast<const bf16x8_t*>(p.wqkv + ((size_t)((((s >> 1) * 24 + nf) * 2 + (s & 1)) * 64 + lane)) * 8);
+      bkv[j] = *reinterpret_cast<const float4*>(p.bqkv + 16 * nf + 4 * g);
+    }
+    bf16_t* dstT = wave < NW / 2 ? Ks : Vs;
+    const int part = 1 + wave / (NW / 2);          // 1: k, 2: v (the q | k | v tensor's channel third)
+#pragma unroll 1
+    for (int i = 0; i < AN / AB_SLAB; ++i) {
+#pragma unroll
+      for (int j = 0; j < SVT; ++j) {
+        float f[8];
+        ab_unpack(xr[j], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * scv[e] + shv[e];
+        const uint4 hv = make_uint4(ab_pack2(f[0], f[1]), ab_pack2(f[2], f[3]), ab_pack2(f[4], f[5]), ab_pack2(f[6], f[7]));
+        *reinterpret_cast<uint4*>(slab + soff + (spx + 16 * j) * AB_PPB) = hv;
+        if (train) *reinterpret_cast<uint4*>(p.h + ((size_t)b * AN + i * AB_SLAB + spx + 16 * j) * D + sv * 8) = hv;
+      }
+      if (i + 1 < AN / AB_SLAB) {
+#pragma unroll
+        for (int j = 0; j < SVT; ++j)
+          xr[j] = *reinterpret_cast<const uint4*>(xb + (size_t)((i + 1) * AB_SLAB + spx + 16 * j) * D + sv * 8);
+      }
+      ab_barrier();
+      f32x4_t acc[KVF][2];
+#pragma unroll
+      for (int j = 0; j < KVF; ++j)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) acc[j][pf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8_t hf = *reinterpret_cast<const bf16x8_t*>(slab + s * (AB_SLAB * AB_PPB) + (pf * 16 + r16) * AB_PPB + g * 16);
+#pragma unroll
+          for (int j = 0; j < KVF; ++j) acc[j][pf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wkv[j][s], hf, acc[j][pf], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < KVF; ++j)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+          const int row = i * AB_SLAB + pf * 16 + r16, col = 16 * (KVF * (wave % (NW / 2)) + j) + 4 * g;
+          const uint2 u = make_uint2(ab_pack2(acc[j][pf][0] + bkv[j].x, acc[j][pf][1] + bkv[j].y),
+                                     ab_pack2(acc[j][pf][2] + bkv[j].z, acc[j][pf][3] + bkv[j].w));
+          *reinterpret_cast<uint2*>(dstT + row * PITCH + col) = u;
+          if (train) *reinterpret_cast<uint2*>(p.qkv + ((size_t)b * AN + row) * 3 * D + part * D + col) = u;
+        }
+      ab_barrier();
+    }
+  }
+
+  // ---- Q of this wave's 16-row blocks (row block wave + NW k)
+  bf16x8_t qp[RBW][4];
+  {
+    bf16x8_t wq[8][4];
+    float4 bq[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        wq[f][s] = *reinterpret_cast<const bf16x8_t*>(p.wqkv + ((size_t)((((s >> 1) * 24 + f) * 2 + (s & 1)) * 64 + lane)) * 8);
+      bq[f] = *reinterpret_cast<const float4*>(p.bqkv + 16 * f + 4 * g);
+    }
+#pragma unroll
+    for (int k = 0; k < RBW; ++k) {
+      const int r0 = 16 * (wave + NW * k);
+      bf16x8_t hf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)(r0 + r16) * D + s * 32 + g * 8);
+        float f[8];
+        ab_unpack(raw, f);
+        bf16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float4 c4 = *reinterpret_cast<const float4*>(cof + 2 * (s * 32 + g * 8 + e));
+          v[e] = (__bf16)(f[e] * c4.x + c4.y); v[e + 1] = (__bf16)(f[e + 1] * c4.z + c4.w);
+        }
+        hf[s] = v;
+      }
+      f32x4_t acc[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[f][s], hf[s], acc[f], 0, 0, 0);
+      }
+      ab_frags(acc, bq, qp[k]);
+      if (train) {
+        bf16_t* qrow = p.qkv + ((size_t)b * AN + r0 + r16) * 3 * D + 4 * g;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+          *reinterpret_cast<uint2*>(qrow + 16 * f) = make_uint2(ab_pack2(acc[f][0] + bq[f].x, acc[f][1] + bq[f].y),
+                                                                ab_pack2(acc[f][2] + bq[f].z, acc[f][3] + bq[f].w));
+      }
+    }
+  }
+
+  // ---- softmax(Q K^T) V per row block; O stays in registers as the proj product's B fragments
+  bf16x8_t po[RBW][4];
+#pragma unroll
+  for (int k = 0; k < RBW; ++k) {
+    const int r0 = 16 * (wave + NW * k);
+    f32x4_t sc_[AN / 16];
+    {
+      const bf16_t* kb = Ks + r16 * PITCH + 4 * g;
+#pragma unroll
+      for (int t = 0; t < AN / 16; ++t) {
+        sc_[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8_t a = amk(ab_read8(kb + t * 16 * PITCH + s * 32), ab_read8(kb + t * 16 * PITCH + s * 32 + 16));
+          sc_[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qp[k][s], sc_[t], 0, 0, 0);
+        }
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc_[t][r] *= p.scale; mx = fmaxf(mx, sc_[t][r]); }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc_[t][r] = __expf(sc_[t][r] - mx); sum += sc_[t][r]; }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc_[t][r] *= inv;
+    bf16x8_t pk[AN / 32];
+    pack_w<AN>(sc_, pk);
+    f32x4_t out[ACfg<D>::CT];
+    outprod<D, AN>(out, Vs, pk, lane);
+    if (train) {
+      store_out<D>(p.o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
+      if (lane < 16) p.lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
+    }
+    ab_frags(out, nullptr, po[k]);
+  }
+
+  // ---- proj + residual; statistics of y
+  __syncthreads();                                   // every wave is through with K and V
+  for (int idx = tid; idx < D * (D / 8); idx += NT) {
+    const int cout = idx >> 4, k8 = idx & 15;
+    const uint4 w = *reinterpret_cast<const uint4*>(p.wp + (size_t)cout * D + k8 * 8);
+    const int s = k8 >> 2, kk = k8 & 3, hh = kk >> 1, g2 = 2 * (kk & 1);
+    bf16_t* row = Ks + cout * PITCH + s * 32 + 4 * hh;
+    *reinterpret_cast<uint2*>(row + g2 * 8) = make_uint2(w.x, w.y);
+    *reinterpret_cast<uint2*>(row + (g2 + 1) * 8) = make_uint2(w.z, w.w);
+  }
+  __syncthreads();
+  float s1[8][4], s2[8][4];
+  float4 bpv[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    bpv[f] = *reinterpret_cast<const float4*>(p.bp + 16 * f + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
+  }
+#pragma unroll
+  for (int k = 0; k < RBW; ++k) {
+    const int row = 16 * (wave + NW * k) + r16;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      f32x4_t ya = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * f + r16) * PITCH + s * 32 + g * 8);
+        ya = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, po[k][s], ya, 0, 0, 0);
+      }
+      const uint2 rs = *reinterpret_cast<const uint2*>(xb + (size_t)row * D + 16 * f + 4 * g);
+      const float v0 = ya[0] + bpv[f].x + __uint_as_float(rs.x << 16), v1 = ya[1] + bpv[f].y + __uint_as_float(rs.x & 0xffff0000u);
+      const float v2 = ya[2] + bpv[f].z + __uint_as_float(rs.y << 16), v3 = ya[3] + bpv[f].w + __uint_as_float(rs.y & 0xffff0000u);
+      const uint2 u = make_uint2(ab_pack2(v0, v1), ab_pack2(v2, v3));
+      *reinterpret_cast<uint2*>(p.y + ((size_t)b * AN + row) * D + 16 * f + 4 * g) = u;
+      const float h0 = __uint_as_float(u.x << 16), h1 = __uint_as_float(u.x & 0xffff0000u);
+      const float h2 = __uint_as_float(u.y << 16), h3 = __uint_as_float(u.y & 0xffff0000u);
+      s1[f][0] += h0; s1[f][1] += h1; s1[f][2] += h2; s1[f][3] += h3;
+      s2[f][0] += h0 * h0; s2[f][1] += h1 * h1; s2[f][2] += h2 * h2; s2[f][3] += h3 * h3;
+    }
+  }
+  if (p.st_out) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum_ab(s1[f][r]), q = row16_sum_ab(s2[f][r]);
+        if (r16 == 0) { scr[(wave * D + 16 * f + 4 * g + r) * 2] = a; scr[(wave * D + 16 * f + 4 * g + r) * 2 + 1] = q; }
+      }
+    __syncthreads();
+    if (tid < D) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { a += scr[(w * D + tid) * 2]; q += scr[(w * D + tid) * 2 + 1]; }
+      p.st_out[((size_t)b * D + tid) * 2] = a; p.st_out[((size_t)b * D + tid) * 2 + 1] = q;
+    }
+  }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: raised once per (kernel set, device), not per
 // launch; a failure is reported to the caller (the launch would otherwise run without the LDS opt-in).
 template <int D, int AN>
@@ -409,4 +735,31 @@ extern "C" int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse,
                               int D, float scale, int dtype, void* stream) {
   if (!o) IDF_FAIL(IDF_ERR_BADARG, "attn_bwd_o: the forward output is missing");
   return attn_bwd_impl(qkv, dO, lse, nullptr, o, dqkv, B, N, D, scale, dtype, stream);
+}
+
+// ---- the attention block of the N = 256, C = 128 level in one launch (attnblock_fwd_kernel)
+extern "C" int idf_attnblock_ok(int N, int C, int dtype) { return (N == 256 && C == 128 && dtype == IDF_BF16) ? 1 : 0; }
+
+extern "C" int idf_attnblock_fwd(const void* x, const float* st, int T, const float* gamma, const float* beta, float eps,
+                                 const void* wqkv_frag, const float* bqkv, const void* wp, const float* bp, void* y,
+                                 float* st_out, void* qkv, void* h, void* o, float* lse, float* mean, float* rstd, float* sc,
+                                 float* sh, float scale, int B, int N, int C, void* stream) {
+  if (!idf_attnblock_ok(N, C, IDF_BF16)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attnblock_fwd: N=%d C=%d not covered", N, C);
+  if (!x || !st || T < 1 || !wqkv_frag || !bqkv || !wp || !bp || !y) IDF_FAIL(IDF_ERR_BADARG, "attnblock_fwd: null argument");
+  const bool any = qkv || h || o || lse || mean || rstd || sc || sh, all = qkv && h && o && lse && mean && rstd && sc && sh;
+  if (any != all) IDF_FAIL(IDF_ERR_BADARG, "attnblock_fwd: the training outputs (qkv, h, o, lse, mean, rstd, sc, sh) go together");
+  if (B == 0) return IDF_OK;
+  // eight waves (two per SIMD): the four-wave form of the same kernel, one wave per SIMD with every LDS / memory latency exposed,
+  // measured 302 - 307 against 307 - 312 img/s on DDIM-100 at B = 256 (profiles/r04_attn_block.txt)
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)attnblock_fwd_kernel<8>, AB_LDS, grant); e != hipSuccess)
+    IDF_FAIL(IDF_ERR_HIP, "attnblock_fwd: %d bytes of LDS refused: %s", (int)AB_LDS, hipGetErrorString(e));
+  AbP p;
+  p.x = (const bf16_t*)x; p.st = st; p.T = T; p.gamma = gamma; p.beta = beta; p.eps = eps;
+  p.wqkv = (const bf16_t*)wqkv_frag; p.bqkv = bqkv; p.wp = (const bf16_t*)wp; p.bp = bp;
+  p.y = (bf16_t*)y; p.st_out = st_out; p.qkv = (bf16_t*)qkv; p.h = (bf16_t*)h; p.o = (bf16_t*)o; p.lse = lse;
+  p.mean = mean; p.rstd = rstd; p.sc = sc; p.sh = sh; p.scale = scale;
+  hipLaunchKernelGGL(attnblock_fwd_kernel<8>, dim3(B), dim3(512), AB_LDS, (hipStream_t)stream, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
 }

@@ -82,9 +82,12 @@ class _Shadows:
 
     def request_frag(self):
         """The fragment-major shadows (forward: O % 16 == 0, I % 64 == 0; data gradient: I % 16 == 0, O % 64 == 0), from the
-        next re-pack on (3x3, one conv)."""
+        next re-pack on (one 3x3 conv, or the attention block's three 1x1 convs as one)."""
         w = self.convs[0].weight
-        if not self.want_frag and len(self.convs) == 1 and w.shape[2:] == (3, 3) and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+        O = sum(c.weight.shape[0] for c in self.convs)
+        plain = len(self.convs) == 1 and w.shape[2:] == (3, 3)
+        qkv = len(self.convs) == 3 and w.shape[2:] == (1, 1)       # the attention block's q | k | v (ops.attn_block_fwd_raw)
+        if not self.want_frag and (plain or qkv) and O % 16 == 0 and w.shape[1] % 16 == 0:
             self.want_frag = True
             self.key = None
 
@@ -304,10 +307,26 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         gn = self.group_norm
-        qkv, x = ops.fused_conv(x, self._qkv.weight(), self._qkv.bias(), self._cfg_qkv, gn.weight, gn.bias,
-                                passthrough=1)      # the residual branch's gradient joins the GN backward
-        o = ops.attention(qkv)
-        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x, want_stats=True)
+        wq, bq = self._qkv.weight(), self._qkv.bias()
+        pre_q = pre_a = pre_p = None
+        if ops.attn_block_ok(x):
+            # 256 tokens x 128 channels in bf16: the whole block is ONE launch (idf_attnblock_fwd); while gradients are recorded
+            # it also leaves what the three ops below would have saved, and they only record their backward passes
+            train = torch.is_grad_enabled() and x.requires_grad
+            val = self._qkv(x.dtype, train)
+            if val[2] is None:
+                self._qkv.request_frag()          # fragment-major q | k | v weights come with the next re-pack
+            else:
+                wp = self._cfg_proj['shadows'](x.dtype, train)[0]
+                y, st, qkv, h, o, lse, mean, rstd, sc, sh = ops.attn_block_fwd_raw(
+                    x, ops.stats_of(x), gn.weight, gn.bias, val[2], bq, wp, self.proj.bias, train)
+                if not train:
+                    return ops._tag(y, st)
+                pre_q, pre_a, pre_p = (qkv, h, mean, rstd, sc, sh, None), (o, lse), (y, None, None, None, None, None, st)
+        qkv, x = ops.fused_conv(x, wq, bq, self._cfg_qkv, gn.weight, gn.bias, passthrough=1,
+                                pre=pre_q)          # the residual branch's gradient joins the GN backward
+        o = ops.attention(qkv, pre=pre_a)
+        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x, want_stats=True, pre=pre_p)
 
 
 class CrossAttnBlock(nn.Module):

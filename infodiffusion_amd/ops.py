@@ -890,7 +890,7 @@ class _FusedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train=False, slots=None,
-                passthrough=False, xst=None, want_stats=False, lazy_out=False):
+                passthrough=False, xst=None, want_stats=False, lazy_out=False, pre=None):
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the statistics output / unused aliases
         x = _nhwc(x)
         residual = _nhwc(residual) if residual is not None else None
@@ -902,7 +902,13 @@ class _FusedConv(torch.autograd.Function):
         w_fwd = cfg['shadows'](x.dtype, train)[0]
         Cout = weight.shape[0]
         need = ctx.needs_input_grad
-        if act and mode == S1 and xst is not None and conv_gn_ok(x, None, taps, Cout):
+        if pre is not None:
+            # the launch that computed this conv already ran (the one-launch attention block, attn_block_fwd_raw): `pre` is
+            # what conv_gn_raw / conv_raw would have returned; this node only records the backward pass
+            y, a, mean, rstd, sc, sh, st = pre
+            if not act:
+                a = x
+        elif act and mode == S1 and xst is not None and conv_gn_ok(x, None, taps, Cout):
             y, a, mean, rstd, sc, sh, st = conv_gn_raw(
                 x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias, residual,
                 Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats,
@@ -1047,7 +1053,7 @@ class _FusedConv(torch.autograd.Function):
             db = colsum_raw(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
         if ctx.has_res and need[7]:
             dres = dy
-        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None, None, None, None
+        return dx, dW, db, dgw, dgb, dft, dfa, dres, None, None, None, None, None, None, None, None, None
 
 
 def _tag(t, st):
@@ -1058,7 +1064,7 @@ def _tag(t, st):
 
 
 def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=None, residual=None, seed=None,
-               passthrough=False, want_stats=False, x_single_use=False):
+               passthrough=False, want_stats=False, x_single_use=False, pre=None):
     """passthrough = 1 / 2 returns (y, x') / (y, x', x''): the extra outputs alias x, and gradients sent to
     them (the residual / shortcut branch of a ResBlock, a skip connection) are added to dx inside this
     op's GroupNorm backward kernel (or its data-gradient epilogue).
@@ -1082,7 +1088,7 @@ def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=N
         xst = stats_of(x)
         in_st = xst
     out = _FusedConv.apply(x, weight, bias, gn_w, gn_b, film_t, film_a, residual, seed, cfg, train, slots, int(passthrough),
-                           xst, want_stats, lazy_out)
+                           xst, want_stats, lazy_out, pre)
     if not isinstance(out, tuple):
         return out
     y, rest = out[0], list(out[1:])
@@ -1540,12 +1546,16 @@ class _Attention(torch.autograd.Function):
     """qkv [B, 3C, H, W] (NHWC-dense: [B, N, 3C]) -> softmax(q k^T C^-1/2) v as [B, C, H, W]."""
 
     @staticmethod
-    def forward(ctx, qkv):
+    def forward(ctx, qkv, pre=None):
         qkv = _nhwc(qkv)
         B, C3, H, W = qkv.shape
         C, N = C3 // 3, H * W
         dev, dt = qkv.device, qkv.dtype
         ctx.fused = bool(_lib.load().idf_attn_fused_ok(N, C, _dt(qkv)))
+        if pre is not None:         # (o, lse) of the one-launch attention block: record the backward pass only
+            o, lse = pre
+            ctx.save_for_backward(qkv, lse, o)
+            return o
         if ctx.fused:       # one launch, scores and probabilities never leave the registers
             o = empty_nhwc(B, C, H, W, dt, dev)
             lse = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -1575,7 +1585,7 @@ class _Attention(torch.autograd.Function):
             else:
                 dsum = torch.empty_like(P)
                 call('idf_attn_bwd', _p(qkv), _p(do), _p(P), _p(dsum), _p(dqkv), B, N, C, scale, _dt(qkv), _st())
-            return dqkv
+            return dqkv, None
         # dV = P^T dO
         bgemm_raw(P, 0, do, 0, dqkv, 2 * C, None, B, N * N, N * C, N * C3, N, C, C3, N, C, N, 1, 1)
         # dP = dO V^T
@@ -1585,11 +1595,48 @@ class _Attention(torch.autograd.Function):
         # dQ = scale * dS K ; dK = scale * dS^T Q
         bgemm_raw(dP, 0, qkv, C, dqkv, 0, None, B, N * N, N * C3, N * C3, N, C3, C3, N, C, N, 0, 1, alpha=scale)
         bgemm_raw(dP, 0, qkv, 0, dqkv, C, None, B, N * N, N * C3, N * C3, N, C3, C3, N, C, N, 1, 1, alpha=scale)
-        return dqkv
+        return dqkv, None
 
 
-def attention(qkv):
-    return _Attention.apply(qkv)
+def attention(qkv, pre=None):
+    return _Attention.apply(qkv, pre)
+
+
+# ------------------------------------------------- the attention block in one launch
+_ATTN_BLOCK = os.environ.get('IDF_ATTN_BLOCK', '1') != '0'
+# One 4-wave workgroup per image: a win only once the batch alone fills the chip (DDIM-100 at B = 256: 306 -> 310.5 img/s).  At
+# B = 32 the launch is 32 workgroups of one wave per SIMD -- every LDS and memory latency exposed -- and the block costs ~70 us
+# against 30 us for the three per-op launches (train step 9.35 -> 9.74 ms with it at every batch; profiles/r04_attn_block.txt)
+_ATTN_BLOCK_MINB = int(os.environ.get('IDF_ATTN_BLOCK_MINB', '256'))
+
+
+def attn_block_ok(x, policy=True):
+    """The one-launch attention block (idf_attnblock_fwd) covers this input: bf16, 256 tokens, 128 channels -- and, with
+    `policy`, the batch is one the launch pays at."""
+    return bool(_ATTN_BLOCK and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+                and (not policy or x.shape[0] >= _ATTN_BLOCK_MINB)
+                and _lib.load().idf_attnblock_ok(x.shape[2] * x.shape[3], x.shape[1], BF16))
+
+
+def attn_block_fwd_raw(x, xst, gn_w, gn_b, wqkv_frag, bqkv, wp_fwd, bp, train):
+    """y = x + proj(attention(q | k | v)), q | k | v = conv1x1(GroupNorm(x)) in one launch
+    -> (y, st_y, qkv, h, o, lse, mean, rstd, sc, sh); everything after st_y is None unless `train` (what the backward reads)."""
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    dev = x.device
+    y = empty_nhwc(B, C, H, W, x.dtype, dev)
+    st = torch.empty((B, 1, C, 2), dtype=torch.float32, device=dev)
+    qkv = h = o = lse = mean = rstd = sc = sh = None
+    if train:
+        qkv = empty_nhwc(B, 3 * C, H, W, x.dtype, dev)
+        h, o = empty_nhwc(B, C, H, W, x.dtype, dev), empty_nhwc(B, C, H, W, x.dtype, dev)
+        lse = torch.empty((B, H * W), dtype=torch.float32, device=dev)
+        mean, rstd = (torch.empty((B, 32), dtype=torch.float32, device=dev) for _ in range(2))
+        sc, sh = (torch.empty((B, C), dtype=torch.float32, device=dev) for _ in range(2))
+    call('idf_attnblock_fwd', _p(x), _p(xst), xst.shape[1], _p(gn_w), _p(gn_b), GN_EPS, _p(wqkv_frag), _p(bqkv), _p(wp_fwd),
+         _p(bp), _p(y), _p(st), _p(qkv), _p(h), _p(o), _p(lse), _p(mean), _p(rstd), _p(sc), _p(sh), float(int(C) ** (-0.5)),
+         B, H * W, C, _st())
+    return y, st, qkv, h, o, lse, mean, rstd, sc, sh
 
 
 # ------------------------------------------------- concatenated parameter views

@@ -844,6 +844,89 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
         assert float((ob.float() - b0.grad).abs().max()) <= 1e-4 * float(b0.grad.abs().max()), (B, Cin, H, W, Cout, taps, mode)
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_attention_block_one_launch(train, monkeypatch):
+    """The whole AttnBlock (modules.py:145-164) at 16x16 x 128 channels as ONE launch (idf_attnblock_fwd: GroupNorm fold from the
+    producer's partials, q | k | v from fragment-major weights, softmax(q k^T) v, proj + residual, statistics of y):
+    (a) against fp32 PyTorch of the same block on the same bf16-valued input and parameters (2e-2 of the output's range:
+        the bf16 intermediates q, k, v, P, O, as the per-op path), the statistics partials against the output's own sums;
+    (b) against the per-op path of the same module: output within a few bf16 ulps, and -- training -- the SAME backward pass
+        (the three autograd nodes only record): input gradient and every parameter gradient within the per-op path's own
+        run-to-run band."""
+    import torch.nn.functional as F
+    from infodiffusion_amd import modules
+    from infodiffusion_amd.optim import FusedClipAdamW
+    torch.manual_seed(5)
+    blk = modules.AttnBlock(128).to(DEV)
+    with torch.no_grad():
+        blk.proj.weight.mul_(1e5 * 0.5)               # (the reference initialises proj with gain 1e-5: give the branch a voice)
+        for name, prm in blk.named_parameters():
+            if prm.dim() == 1:
+                prm.add_(0.2 * rnd(hash(name) % 1000, *prm.shape).to(DEV))
+    blk.train(train)
+    opt = FusedClipAdamW(blk.parameters(), lr=0.0, weight_decay=0.0)
+    B = 3
+    x0 = (0.2 + rnd(1, B, 128, 16, 16)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dyw = rnd(2, B, 128, 16, 16).to(DEV)
+    names = []
+    orig_call = ops.call
+
+    def counted(name, *a):
+        names.append(name)
+        return orig_call(name, *a)
+    monkeypatch.setattr(ops, 'call', counted)
+
+    def run(fused):
+        monkeypatch.setattr(ops, '_ATTN_BLOCK', fused)
+        monkeypatch.setattr(ops, '_ATTN_BLOCK_MINB', 1)          # coverage, not the policy (B >= 256)
+        del names[:]
+        x = x0.clone().requires_grad_(train)
+        opt.zero_grad()
+        with torch.set_grad_enabled(train):
+            y = blk(x)
+        fwd = list(names)
+        st = getattr(y, '_gn', None)
+        g = {}
+        if train:
+            (y.float() * dyw).sum().backward()
+            torch.cuda.synchronize()
+            g = {'x': x.grad.detach().float().clone()}
+            g.update({k: prm.grad.detach().float().clone() for k, prm in blk.named_parameters() if prm.grad is not None})
+        return y.detach().float().clone(), st, g, fwd
+
+    y_ref, st_ref, g_ref, fwd_ref = run(False)
+    assert 'idf_attnblock_fwd' not in fwd_ref and 'idf_attn_fwd' in fwd_ref
+    run(True)                                         # asks for the fragment-major q | k | v weights (next re-pack)
+    y, st, g, fwd = run(True)
+    assert fwd.count('idf_attnblock_fwd') == 1 and 'idf_attn_fwd' not in fwd and not any(n.startswith('idf_conv') for n in fwd), fwd
+    # (a) fp32 PyTorch
+    with torch.no_grad():
+        xf = x0.float()
+        hn = F.group_norm(xf, 32, blk.group_norm.weight, blk.group_norm.bias, eps=1e-5)
+        q, k, v = (F.conv2d(hn, m.weight, m.bias) for m in (blk.proj_q, blk.proj_k, blk.proj_v))
+        q, k, v = (t.permute(0, 2, 3, 1).reshape(B, 256, 128) for t in (q, k, v))
+        w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * 128 ** -0.5, dim=-1)
+        hh = torch.bmm(w, v).view(B, 16, 16, 128).permute(0, 3, 1, 2)
+        want = xf + F.conv2d(hh, blk.proj.weight, blk.proj.bias)
+    assert rel(y, want) < 2e-2, rel(y, want)
+    assert rel(y_ref, want) < 2e-2
+    assert st is not None and st.shape == (B, 1, 128, 2)
+    yb = y.permute(0, 2, 3, 1).reshape(B, 256, 128)
+    assert rel(st[:, 0, :, 0], yb.sum(1)) < 1e-5 and rel(st[:, 0, :, 1], (yb * yb).sum(1)) < 1e-5
+    # (b) the per-op path
+    assert rel(y, y_ref) < 1e-2, rel(y, y_ref)
+    if train:
+        assert set(g) == set(g_ref)
+        for kname in g_ref:
+            if kname == 'proj_k.bias':
+                # mathematically zero (a bias on k shifts every score of a row alike: softmax does not see it) -- what both
+                # paths hold is rounding noise, compared against the scale of a live gradient instead of against each other
+                top = float(g_ref['proj_v.bias'].abs().max())
+                assert float(g[kname].abs().max()) < 0.1 * top and float(g_ref[kname].abs().max()) < 0.1 * top
+                continue
+            assert rel(g[kname], g_ref[kname]) < 3e-2, (kname, rel(g[kname], g_ref[kname]))
+
+
 @pytest.mark.parametrize('C1,C2,H', [(128, 128, 16), (128, 64, 32), (64, 64, 64), (128, 64, 64), (256, 256, 8)])
 def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     """The (x, x2) pair read in place == the same kernels on the materialised concatenation: one-launch

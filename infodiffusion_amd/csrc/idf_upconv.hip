@@ -1,0 +1,212 @@
+// UpSample (modules.py:78-93: nearest x2, then conv3x3 pad 1) as FOUR 2x2 convolutions on the low-resolution input -- the
+// sub-pixel form of the same sum.  With oy = 2 y + py the three kernel rows of output row oy read the up-sampled rows
+// oy - 1, oy, oy + 1, i.e. the low-resolution rows
+//     py = 0:  y - 1 (kernel row 0),  y (kernel rows 1 + 2)          py = 1:  y (kernel rows 0 + 1),  y + 1 (kernel row 2)
+// and the same along x: each output parity (py, px) is a 2x2-tap conv whose weights are sums of the 3x3 weights
+//     W'[py][px][ty][tx] = sum_{ky in S(py, ty)} sum_{kx in S(px, tx)} W[ky][kx],   S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+// reading low-resolution pixel (y + ty + py - 1, x + tx + px - 1); the zero padding of the low-resolution image is exactly the zero
+// padding of the up-sampled one.  16 MFMA tap-products per four outputs instead of 36: the conv that held the nearest-x2 image in
+// LDS and ran all nine taps over it (conv3x3_halo_bf16 MODE 2) spent 572 us per DDIM evaluation at B = 256 on three such layers.
+// The sums are formed in fp32 from the master weights and rounded to bf16 once (the host packs them fragment-major: 1 KB per
+// wave instruction, straight into registers): inference path -- the training step keeps MODE 2 and its data / weight gradients.
+//
+// One 512-thread workgroup = 256 output pixels (R rows x W columns of one image) x 64 couts.  Wave w owns parity w & 3 and the
+// cout half w >> 2: 64 pixels of its parity x 32 couts, 4 x 2 accumulator tiles; per 32-channel chunk 4 taps x 8 MFMAs.  The
+// low-resolution halo tile of a chunk -- (R / 2 + 2) x (W / 2 + 2) pixels, pixel pitch 96 B (conflict-free ds_read_b128) -- is
+// double-buffered: one barrier per chunk.  Epilogue: bias, bf16, the tile through LDS in pixel order, full-line stores, the
+// statistics partials of y for the next GroupNorm in a fixed order.
+#include "idf_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct UpP {
+  const bf16_t* x;        // [B][Hl][Wl][Cin]
+  const bf16_t* w;        // fragment-major [Cin / 64][Cout / 16][16 taps = (py, px, ty, tx)][2][64][8]
+  const float* bias;      // [Cout] or null
+  bf16_t* y;              // [B][2 Hl][2 Wl][Cout]
+  float* st_out;          // [B][tiles_per_img][Cout][2] or null
+  int B, Hl, Wl, Cin, Cout;
+  int R, tiles_per_img, n_tiles, wlshift;     // output rows per tile (even), 2 Hl / R, Cout / 64, log2(Wl)
+};
+
+constexpr int UP_PPB = 96;                    // bytes per low-resolution pixel of a 32-channel chunk image
+constexpr int UP_TP = 72;                     // bf16 per pixel row of the output tile in LDS (64 couts + 8: 144 B, 16-byte aligned)
+
+__device__ __forceinline__ void up_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Wl = p.Wl, W = 2 * Wl, RL = p.R >> 1, WH = Wl + 2, npl = (RL + 2) * WH;
+  const int img_bytes = ((npl * UP_PPB + 15) >> 4) << 4;
+  unsigned char* img0 = smem;                                   // two chunk images
+  bf16_t* tileo = reinterpret_cast<bf16_t*>(smem + 2 * img_bytes);             // [256][UP_TP]
+  float* part = reinterpret_cast<float*>(smem);                                 // [512][16] statistics partials (over the images and the tile, once they are read)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
+  const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, oy0 = t_in * p.R, ly0 = oy0 >> 1;
+  const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
+  const int nchunks = p.Cin >> 5;
+
+  // staging plan: this thread's (up to two) 16-byte vectors of a chunk image
+  int goff[2], loff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * 512;
+    goff[k] = -1; loff[k] = -1;
+    if (idx < npl * 4) {
+      const int pix = idx >> 2, q = idx & 3;
+      const int hy = pix / WH, hx = pix - hy * WH;
+      const int iy = ly0 + hy - 1, ix = hx - 1;
+      loff[k] = pix * UP_PPB + q * 16;
+      if ((unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)Wl) goff[k] = ((b * p.Hl + iy) * Wl + ix) * p.Cin + q * 8;
+    }
+  }
+  // this lane's pixel of every fragment: q = i * 16 + r16 over the RL x Wl low-resolution positions of the tile
+  int pbase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 16 + r16, ly = q >> p.wlshift, lx = q & (Wl - 1);
+    pbase[i] = ((ly + py) * WH + lx + px) * UP_PPB + g * 16;
+  }
+  const bf16_t* wb = p.w + ((size_t)((n0 >> 4) + 2 * ch) * 16 + (py * 2 + px) * 4) * 2 * 512 + lane * 8;
+  // element offset of (pair, cout fragment a, tap t, half): ((pair * (Cout / 16) + nf) * 16 + tap) * 2 + half) * 512
+  const size_t pair_stride = (size_t)(p.Cout >> 4) * 16 * 2 * 512;
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t xr[2];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      xr[k] = goff[k] >= 0 ? *reinterpret_cast<const u32x4_t*>(p.x + goff[k] + c * 32) : u32x4_t{0u, 0u, 0u, 0u};
+  };
+  auto store_chunk = [&](int c) {
+    unsigned char* img = img0 + (c & 1) * img_bytes;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (loff[k] >= 0) *reinterpret_cast<u32x4_t*>(img + loff[k]) = xr[k];
+  };
+  load_chunk(0);
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    // the chunk's weights: 4 taps x 2 cout fragments, 1 KB per wave instruction
+    bf16x8_t wf[4][2];
+    const bf16_t* wc = wb + (size_t)(c >> 1) * pair_stride + (c & 1) * 512;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        wf[t][a] = *reinterpret_cast<const bf16x8_t*>(wc + ((size_t)a * 16 + t) * 2 * 512);
+    store_chunk(c);
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    up_barrier();                 // image c complete; image c - 1's readers are past it (they stored image c after reading it)
+    const unsigned char* img = img0 + (c & 1) * img_bytes;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int toff = ((t >> 1) * WH + (t & 1)) * UP_PPB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(img + pbase[i] + toff);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][a], xf, acc[a][i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, bf16, tile in pixel order through LDS
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int col = 32 * ch + 16 * a + 4 * g;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 16 + r16, ly = q >> p.wlshift, lx = q & (Wl - 1);
+      const int pl = (2 * ly + py) * W + 2 * lx + px;
+      const uint32_t lo = (uint32_t)f32_to_bf16(acc[a][i][0] + bv.x) | ((uint32_t)f32_to_bf16(acc[a][i][1] + bv.y) << 16);
+      const uint32_t hi = (uint32_t)f32_to_bf16(acc[a][i][2] + bv.z) | ((uint32_t)f32_to_bf16(acc[a][i][3] + bv.w) << 16);
+      *reinterpret_cast<uint2*>(tileo + pl * UP_TP + col) = make_uint2(lo, hi);
+    }
+  }
+  __syncthreads();
+  const int v = tid & 7;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pl = (tid >> 3) + 64 * k;
+    const uint4 o = *reinterpret_cast<const uint4*>(tileo + pl * UP_TP + v * 8);
+    const int oy = oy0 + pl / W, ox = pl - (pl / W) * W;
+    *reinterpret_cast<uint4*>(p.y + ((size_t)(b * 2 * p.Hl + oy) * W + ox) * p.Cout + n0 + v * 8) = o;
+    const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = __uint_as_float(w4[j] << 16), hi = __uint_as_float(w4[j] & 0xffff0000u);
+      s1[2 * j] += lo; s2[2 * j] += lo * lo; s1[2 * j + 1] += hi; s2[2 * j + 1] += hi * hi;
+    }
+  }
+  if (p.st_out) {
+    __syncthreads();              // every thread has read its tile vectors
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[tid * 16 + e] = s1[e]; part[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid >> 1, which = tid & 1, cv = c >> 3, e = c & 7;
+      float s = 0.f;
+      for (int t = 0; t < 64; ++t) s += part[(t * 8 + cv) * 16 + which * 8 + e];      // the 64 threads of cout vector cv, fixed order
+      p.st_out[(((size_t)b * p.tiles_per_img + t_in) * p.Cout + n0 + c) * 2 + which] = s;
+    }
+  }
+}
+
+inline bool up_plan(int Hl, int Wl, int Cin, int Cout, int* R) {
+  if (Wl < 8 || Wl > 32 || (Wl & (Wl - 1)) || Hl < 1 || (Cin % 64) || (Cout % 64)) return false;
+  const int W = 2 * Wl, r = 256 / W;            // output rows per 256-pixel tile: 4 / 8 / 16
+  if (r < 2 || (r & 1) || (2 * Hl) % r) return false;
+  *R = r;
+  return true;
+}
+
+}  // namespace
+
+// tiles per image of idf_upconv_bf16's statistics partials (st_out [B][tiles][Cout][2]); 0: shape not covered
+// (low-resolution width 8, 16 or 32; Cin, Cout multiples of 64)
+extern "C" int idf_upconv_tiles(int Hl, int Wl, int Cin, int Cout) {
+  int R;
+  return up_plan(Hl, Wl, Cin, Cout, &R) ? 2 * Hl / R : 0;
+}
+
+extern "C" int idf_upconv_bf16(const void* x, const void* w_sub_frag, const float* bias, void* y, float* st_out, int B, int Hl,
+                               int Wl, int Cin, int Cout, void* stream) {
+  int R;
+  if (!up_plan(Hl, Wl, Cin, Cout, &R)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "upconv_bf16: Hl%d Wl%d Cin%d Cout%d not covered", Hl, Wl, Cin, Cout);
+  if (!x || !w_sub_frag || !y) IDF_FAIL(IDF_ERR_BADARG, "upconv_bf16: null argument");
+  if (B == 0) return IDF_OK;
+  if ((long)B * 4 * Hl * Wl * (Cin > Cout ? Cin : Cout) >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "upconv_bf16: tensor too large for 32-bit offsets");
+  UpP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_sub_frag; p.bias = bias; p.y = (bf16_t*)y; p.st_out = st_out;
+  p.B = B; p.Hl = Hl; p.Wl = Wl; p.Cin = Cin; p.Cout = Cout;
+  p.R = R; p.tiles_per_img = 2 * Hl / R; p.n_tiles = Cout / 64;
+  int ws = 0;
+  while ((1 << ws) < Wl) ++ws;
+  p.wlshift = ws;
+  const int npl = (R / 2 + 2) * (Wl + 2);
+  const size_t img = (((size_t)npl * UP_PPB + 15) / 16) * 16;
+  size_t lds = 2 * img + (size_t)256 * UP_TP * 2;
+  if (lds < (size_t)512 * 16 * sizeof(float)) lds = (size_t)512 * 16 * sizeof(float);
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)upconv_bf16_kernel, lds, grant); e != hipSuccess)
+    IDF_FAIL(IDF_ERR_HIP, "upconv_bf16: %d bytes of LDS refused: %s", (int)lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(upconv_bf16_kernel, dim3((unsigned)(B * p.tiles_per_img * p.n_tiles)), dim3(512), lds, (hipStream_t)stream, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

@@ -280,7 +280,17 @@ class UpSample(nn.Module):
         self._cfg = _cfg(_Shadows(self.main), ops.UP2, 9, _ACT_NONE)
 
     def forward(self, x, temb=None, aemb=None):
-        return ops.fused_conv(x, self.main.weight, self.main.bias, self._cfg, want_stats=True)
+        w = self.main.weight
+        tiles = ops.upconv_tiles(x, w.shape[0]) if not torch.is_grad_enabled() else 0
+        if tiles:
+            # inference: four 2x2 convs on the low-resolution input with summed weights (idf_upconv_bf16; 16 tap products per
+            # four outputs instead of 36) -- packed once per weight version
+            key = (w.data_ptr(), w._version, w.device)
+            if getattr(self, '_sub', (None, None))[0] != key:
+                self._sub = (key, ops.upconv_pack(w))
+            y, st = ops.upconv_raw(x, self._sub[1], self.main.bias, w.shape[0], tiles)
+            return ops._tag(y, st)
+        return ops.fused_conv(x, w, self.main.bias, self._cfg, want_stats=True)
 
 
 class AttnBlock(nn.Module):

@@ -1602,6 +1602,48 @@ def attention(qkv, pre=None):
     return _Attention.apply(qkv, pre)
 
 
+# ------------------------------------------------- UpSample at inference: four 2x2 convs on the low-resolution input
+_UPCONV = os.environ.get('IDF_UPCONV', '1') != '0'
+_UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))          # S(parity, tap): the 3x3 kernel rows / columns a low-resolution tap stands for
+
+
+def upconv_tiles(x, Cout):
+    """Statistics tiles per image of idf_upconv_bf16 for this (low-resolution) input; 0: shape not covered."""
+    if not (_UPCONV and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
+        return 0
+    return int(_lib.load().idf_upconv_tiles(x.shape[2], x.shape[3], x.shape[1], Cout))
+
+
+def upconv_pack(weight):
+    """[O, I, 3, 3] master weights -> the summed sub-pixel weights W'[py][px][ty][tx] (fp32 sums, one bf16 rounding) as
+    [O][16][I], fragment-major (the layout of idf_pack_conv_weights_batched's `wfrag`)."""
+    with torch.no_grad():
+        w = weight.detach().float()
+        O, I = w.shape[:2]
+        taps = []
+        for py in range(2):
+            for px in range(2):
+                for ty in range(2):
+                    for tx in range(2):
+                        acc = torch.zeros((O, I), dtype=torch.float32, device=w.device)
+                        for ky in _UP_SETS[py][ty]:
+                            for kx in _UP_SETS[px][tx]:
+                                acc = acc + w[:, :, ky, kx]
+                        taps.append(acc)
+        m = torch.stack(taps, dim=1).to(torch.bfloat16)                  # [O][16][I]
+        return m.view(O // 16, 16, 16, I // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1).contiguous()
+
+
+def upconv_raw(x, w_sub_frag, bias, Cout, tiles):
+    """y = conv3x3(nearest_x2(x)) + bias from the low-resolution x -> (y, statistics partials of y)."""
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    y = empty_nhwc(B, Cout, 2 * H, 2 * W, x.dtype, x.device)
+    st = torch.empty((B, tiles, Cout, 2), dtype=torch.float32, device=x.device)
+    call('idf_upconv_bf16', _p(x), _p(w_sub_frag), _p(bias), _p(y), _p(st), B, H, W, C, Cout, _st())
+    return y, st
+
+
 # ------------------------------------------------- the attention block in one launch
 _ATTN_BLOCK = os.environ.get('IDF_ATTN_BLOCK', '1') != '0'
 # One 4-wave workgroup per image: a win only once the batch alone fills the chip (DDIM-100 at B = 256: 306 -> 310.5 img/s).  At

@@ -927,6 +927,55 @@ def test_attention_block_one_launch(train, monkeypatch):
             assert rel(g[kname], g_ref[kname]) < 3e-2, (kname, rel(g[kname], g_ref[kname]))
 
 
+@pytest.mark.parametrize('B,C,Co,Hl', [(3, 128, 128, 8), (2, 128, 128, 16), (2, 128, 128, 32), (2, 256, 256, 16), (5, 64, 192, 8)])
+def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl):
+    """UpSample at inference (idf_upconv_bf16: nearest x2 + conv3x3 as four 2x2 convs on the low-resolution input with summed
+    weights) against fp32 PyTorch of interpolate + conv2d on the same bf16-valued input and fp32 weights (1e-2 of the output's
+    range: bf16 operands, one rounding of each summed weight), against the training-path kernel (the up-sampling read fused
+    into the 3x3 conv), and its statistics partials against the output's own sums.  Borders included: the zero padding of
+    the low-resolution tile must be the zero padding of the up-sampled image."""
+    import torch.nn.functional as F
+    from infodiffusion_amd import modules
+    torch.manual_seed(3)
+    up = modules.UpSample(C).to(DEV)
+    if Co != C:
+        up.main = torch.nn.Conv2d(C, Co, 3, stride=1, padding=1).to(DEV)
+        up._cfg = modules._cfg(modules._Shadows(up.main), ops.UP2, 9, modules._ACT_NONE)
+    with torch.no_grad():
+        up.main.bias.add_(0.3 * rnd(1, Co).to(DEV))
+    x = rnd(2, B, C, Hl, Hl).to(DEV).bfloat16().contiguous(memory_format=CL)
+    names = []
+    orig_call = ops.call
+
+    def counted(name, *a):
+        names.append(name)
+        return orig_call(name, *a)
+    ops.call = counted
+    try:
+        with torch.no_grad():
+            y = up(x)
+        assert names.count('idf_upconv_bf16') == 1 and not any(n.startswith('idf_conv') for n in names), names
+        del names[:]
+        y_train = up(x.clone().requires_grad_(True)).detach()
+        assert 'idf_upconv_bf16' not in names
+    finally:
+        ops.call = orig_call
+    with torch.no_grad():
+        want = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode='nearest'), up.main.weight, up.main.bias, padding=1)
+    assert y.shape == want.shape
+    assert rel(y, want) < 1e-2, rel(y, want)
+    assert rel(y, y_train) < 1e-2, rel(y, y_train)
+    # the border rows / columns separately (a wrong halo shows there first)
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), -1)):
+        assert rel(y[sl], want[sl]) < 1e-2, sl
+    st = getattr(y, '_gn', None)
+    assert st is not None and st.shape[0] == B and st.shape[2:] == (Co, 2)
+    T = st.shape[1]
+    yb = y.float().permute(0, 2, 3, 1).reshape(B, T, (4 * Hl * Hl) // T, Co)
+    assert rel(st[..., 0], yb.sum(2)) < 1e-5 and rel(st[..., 1], (yb * yb).sum(2)) < 1e-5
+
+
 @pytest.mark.parametrize('C1,C2,H', [(128, 128, 16), (128, 64, 32), (64, 64, 64), (128, 64, 64), (256, 256, 8)])
 def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     """The (x, x2) pair read in place == the same kernels on the materialised concatenation: one-launch

@@ -8,7 +8,8 @@
 // padding of the up-sampled one.  16 MFMA tap-products per four outputs instead of 36: the conv that held the nearest-x2 image in
 // LDS and ran all nine taps over it (conv3x3_halo_bf16 MODE 2) spent 572 us per DDIM evaluation at B = 256 on three such layers.
 // The sums are formed in fp32 from the master weights and rounded to bf16 once (the host packs them fragment-major: 1 KB per
-// wave instruction, straight into registers): inference path -- the training step keeps MODE 2 and its data / weight gradients.
+// wave instruction, straight into registers; upconv_pack_kernel re-packs them with the other weight shadows).  Forward only: the
+// backward pass stays the 3x3 conv's (data gradient through the fused up-sampling read, weight gradient of the UP2 class).
 //
 // One 512-thread workgroup = 256 output pixels (R rows x W columns of one image) x 64 couts.  Wave w owns parity w & 3 and the
 // cout half w >> 2: 64 pixels of its parity x 32 couts, 4 x 2 accumulator tiles; per 32-channel chunk 4 taps x 8 MFMAs.  The
@@ -168,6 +169,46 @@ __global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
   }
 }
 
+// Summed sub-pixel weights of every UpSample conv of a network in ONE launch (the training step re-packs them with the other
+// weight shadows after each optimizer step).  One thread per (cout, cin) pair: nine master weights in, sixteen sums out.
+struct UpPackDesc {
+  const float* src;       // master weight, logical (o, i, tap) at o * so + i * si + tap * st
+  bf16_t* dst;            // fragment-major [I / 64][O / 16][16][2][64][8]
+  long so, si, st;
+  int O, I;
+};
+__global__ __launch_bounds__(256) void upconv_pack_kernel(const UpPackDesc* __restrict__ tab) {
+  const UpPackDesc d = tab[blockIdx.y];
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)d.O * d.I) return;
+  const int o = (int)(idx / d.I), i = (int)(idx - (long)o * d.I);
+  float w[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = d.src[o * d.so + i * d.si + t * d.st];
+  // rows / columns a low-resolution tap stands for: S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+  float rs[2][2][3];      // [py][ty][kx]: kernel rows summed
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    rs[0][0][kx] = w[0][kx]; rs[0][1][kx] = w[1][kx] + w[2][kx];
+    rs[1][0][kx] = w[0][kx] + w[1][kx]; rs[1][1][kx] = w[2][kx];
+  }
+  const size_t base = ((size_t)(i >> 6) * (d.O >> 4) + (o >> 4)) * 16;
+  const int inner = (((i >> 3) & 3) * 16 + (o & 15)) * 8 + (i & 7), half = (i >> 5) & 1;
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          const float* r = rs[py][ty];
+          const float v = px == 0 ? (tx == 0 ? r[0] : r[1] + r[2]) : (tx == 0 ? r[0] + r[1] : r[2]);
+          const int tap = (py * 2 + px) * 4 + ty * 2 + tx;
+          d.dst[((base + tap) * 2 + half) * 512 + inner] = f32_to_bf16(v);
+        }
+}
+
 inline bool up_plan(int Hl, int Wl, int Cin, int Cout, int* R) {
   if (Wl < 8 || Wl > 32 || (Wl & (Wl - 1)) || Hl < 1 || (Cin % 64) || (Cout % 64)) return false;
   const int W = 2 * Wl, r = 256 / W;            // output rows per 256-pixel tile: 4 / 8 / 16
@@ -207,6 +248,18 @@ extern "C" int idf_upconv_bf16(const void* x, const void* w_sub_frag, const floa
   if (hipError_t e = idf_ensure_lds((const void*)upconv_bf16_kernel, lds, grant); e != hipSuccess)
     IDF_FAIL(IDF_ERR_HIP, "upconv_bf16: %d bytes of LDS refused: %s", (int)lds, hipGetErrorString(e));
   hipLaunchKernelGGL(upconv_bf16_kernel, dim3((unsigned)(B * p.tiles_per_img * p.n_tiles)), dim3(512), lds, (hipStream_t)stream, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// table (device): nrows x {src*, dst*, long so, si, st, int O, I} (48 bytes), one row per UpSample conv; max_pairs = the largest
+// O * I of the rows.  dst: the w_sub_frag operand of idf_upconv_bf16.
+extern "C" int idf_upconv_pack_batched(const void* table, int nrows, long max_pairs, void* stream) {
+  if (nrows <= 0 || max_pairs <= 0) return IDF_OK;
+  if (!table) IDF_FAIL(IDF_ERR_BADARG, "upconv_pack_batched: null table");
+  static_assert(sizeof(UpPackDesc) == 48, "the host builds 48-byte rows");
+  hipLaunchKernelGGL(upconv_pack_kernel, dim3((unsigned)((max_pairs + 255) / 256), (unsigned)nrows), dim3(256), 0, (hipStream_t)stream,
+                     (const UpPackDesc*)table);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

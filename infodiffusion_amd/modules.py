@@ -45,6 +45,9 @@ class _Shadows:
         # the image-resident ResBlock kernel (ops.resblock_small) reads its weights fragment-major; a conv it has met once
         # gets that third shadow from the next re-pack on
         self.want_frag = False
+        # UpSample's conv: the summed sub-pixel weights of idf_upconv_bf16 (bf16 only), re-packed with the other shadows
+        self.want_sub = False
+        self.sub = None
         # several convs applied as one (q, k, v): their weights / biases live adjacently so the
         # concatenation is a view and its gradient is written once (grad_arena.ParamGroup)
         self.wgroup = ops.ParamGroup([c.weight for c in convs]) if len(convs) > 1 else None
@@ -74,6 +77,10 @@ class _Shadows:
             if v is None or v.dtype != dtype or v.device != dev:
                 self.val[j] = torch.empty(shape, dtype=dtype, device=dev)
                 self.key = None
+        if self.want_sub and dtype == torch.bfloat16 and O % 16 == 0 and I % 64 == 0 and (kh, kw) == (3, 3) and (
+                self.sub is None or self.sub.device != dev):
+            self.sub = torch.empty((O * 16 * I,), dtype=dtype, device=dev)
+            self.key = None
         if self.want_frag:
             for j, fits, on in ((2, O % 16 == 0 and I % 64 == 0, True), (3, I % 16 == 0 and O % 64 == 0, need_dgrad)):
                 if fits and on and (self.val[j] is None or self.val[j].dtype != dtype or self.val[j].device != dev):
@@ -92,6 +99,10 @@ class _Shadows:
             self.key = None
 
     def stale(self, dtype, need_dgrad):
+        if self.want_sub and self.sub is None and dtype == torch.bfloat16:
+            w = self.convs[0].weight
+            if w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0 and w.shape[2:] == (3, 3):
+                return True
         if self.want_frag:
             O, I = sum(c.weight.shape[0] for c in self.convs), self.convs[0].weight.shape[1]
             if (O % 16 == 0 and I % 64 == 0 and self.val[2] is None) or (need_dgrad and I % 16 == 0 and O % 64 == 0
@@ -112,6 +123,8 @@ class _Shadows:
                     if self.val[j] is not None and m is not None:
                         N, taps, K = m.shape
                         self.val[j].copy_(m.view(N // 16, 16, taps, K // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1))
+                if self.sub is not None:
+                    self.sub.copy_(ops.upconv_pack(self.convs[0].weight))
             self.key = self.current_key(dtype)
         return self.val
 
@@ -147,6 +160,8 @@ class ShadowSet:
         self.tkey = None
         self.table = None
         self.pinned = None
+        self.up_key = None          # the UpSample convs' summed sub-pixel weights: their own table, one more launch
+        self.up_table = None
 
     def refresh(self, dtype, need_dgrad):
         if not any(s.stale(dtype, need_dgrad) for s in self.items):
@@ -196,6 +211,24 @@ class ShadowSet:
         from ._lib import call, F32, BF16
         call('idf_pack_conv_weights_batched', self.table.data_ptr(), self.table.shape[0],
              F32 if dtype == torch.float32 else BF16, torch.cuda.current_stream().cuda_stream)
+        ups = [s for s in self.items if s.sub is not None]
+        if ups:
+            ukey = tuple((s.convs[0].weight.data_ptr(), s.sub.data_ptr()) for s in ups)
+            if ukey != self.up_key:
+                rows = []
+                for s in ups:
+                    w = s.convs[0].weight
+                    rows.append((w.data_ptr(), s.sub.data_ptr(), w.stride(0), w.stride(1), w.stride(3), w.shape[0], w.shape[1]))
+                    if w.stride(2) != 3 * w.stride(3):
+                        raise RuntimeError('conv weight layout not packable in place')
+                dt = np.dtype([('src', '<i8'), ('dst', '<i8'), ('so', '<i8'), ('si', '<i8'), ('st', '<i8'), ('O', '<i4'), ('I', '<i4')])
+                host = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).reshape(len(rows), -1).copy())
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('ShadowSet: run one eager forward before graph capture')
+                self.up_table = host.to(self.items[0].val[0].device)
+                self.up_key = ukey
+                self.up_pairs = max(s.convs[0].weight.shape[0] * s.convs[0].weight.shape[1] for s in ups)
+            call('idf_upconv_pack_batched', self.up_table.data_ptr(), len(ups), self.up_pairs, torch.cuda.current_stream().cuda_stream)
         for s in self.items:
             s.key = s.current_key(dtype)
 
@@ -278,18 +311,23 @@ class UpSample(nn.Module):
         self.main = nn.Conv2d(in_ch, in_ch, 3, stride=1, padding=1)
         _xavier_all(self)
         self._cfg = _cfg(_Shadows(self.main), ops.UP2, 9, _ACT_NONE)
+        self._cfg['shadows'].want_sub = True
 
     def forward(self, x, temb=None, aemb=None):
         w = self.main.weight
-        tiles = ops.upconv_tiles(x, w.shape[0]) if not torch.is_grad_enabled() else 0
+        tiles = ops.upconv_tiles(x, w.shape[0])
         if tiles:
-            # inference: four 2x2 convs on the low-resolution input with summed weights (idf_upconv_bf16; 16 tap products per
-            # four outputs instead of 36) -- packed once per weight version
-            key = (w.data_ptr(), w._version, w.device)
-            if getattr(self, '_sub', (None, None))[0] != key:
-                self._sub = (key, ops.upconv_pack(w))
-            y, st = ops.upconv_raw(x, self._sub[1], self.main.bias, w.shape[0], tiles)
-            return ops._tag(y, st)
+            # bf16: four 2x2 convs on the low-resolution input with summed weights (idf_upconv_bf16: 16 tap products per four
+            # outputs instead of 36); the summed weights are one more shadow, re-packed with the others.  The backward pass is
+            # the 3x3 conv's (data gradient through the fused up-sampling read, weight gradient of the UP2 class).
+            train = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+            sh = self._cfg['shadows']
+            sh(x.dtype, train)
+            if sh.sub is not None:
+                y, st = ops.upconv_raw(x, sh.sub, self.main.bias, w.shape[0], tiles)
+                if not train:
+                    return ops._tag(y, st)
+                return ops.fused_conv(x, w, self.main.bias, self._cfg, want_stats=True, pre=(y, None, None, None, None, None, st))
         return ops.fused_conv(x, w, self.main.bias, self._cfg, want_stats=True)
 
 

@@ -1625,11 +1625,12 @@ def upconv_pack(weight):
             for px in range(2):
                 for ty in range(2):
                     for tx in range(2):
-                        acc = torch.zeros((O, I), dtype=torch.float32, device=w.device)
-                        for ky in _UP_SETS[py][ty]:
-                            for kx in _UP_SETS[px][tx]:
-                                acc = acc + w[:, :, ky, kx]
-                        taps.append(acc)
+                        # kernel rows first, then columns, left to right: the order of upconv_pack_kernel (same bits)
+                        cols = []
+                        for kx in _UP_SETS[px][tx]:
+                            rows = [w[:, :, ky, kx] for ky in _UP_SETS[py][ty]]
+                            cols.append(rows[0] if len(rows) == 1 else rows[0] + rows[1])
+                        taps.append(cols[0] if len(cols) == 1 else cols[0] + cols[1])
         m = torch.stack(taps, dim=1).to(torch.bfloat16)                  # [O][16][I]
         return m.view(O // 16, 16, 16, I // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1).contiguous()
 

@@ -928,12 +928,14 @@ def test_attention_block_one_launch(train, monkeypatch):
 
 
 @pytest.mark.parametrize('B,C,Co,Hl', [(3, 128, 128, 8), (2, 128, 128, 16), (2, 128, 128, 32), (2, 256, 256, 16), (5, 64, 192, 8)])
-def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl):
-    """UpSample at inference (idf_upconv_bf16: nearest x2 + conv3x3 as four 2x2 convs on the low-resolution input with summed
+def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl, monkeypatch):
+    """UpSample's forward (idf_upconv_bf16: nearest x2 + conv3x3 as four 2x2 convs on the low-resolution input with summed
     weights) against fp32 PyTorch of interpolate + conv2d on the same bf16-valued input and fp32 weights (1e-2 of the output's
-    range: bf16 operands, one rounding of each summed weight), against the training-path kernel (the up-sampling read fused
-    into the 3x3 conv), and its statistics partials against the output's own sums.  Borders included: the zero padding of
-    the low-resolution tile must be the zero padding of the up-sampled image."""
+    range: bf16 operands, one rounding of each summed weight), against the kernel it replaces (the up-sampling read fused into
+    the 3x3 conv), its statistics partials against the output's own sums, borders included (the zero padding of the
+    low-resolution tile must be the zero padding of the up-sampled image); the summed weights packed by the batched kernel
+    (idf_upconv_pack_batched, through a ShadowSet) against the torch restatement bit for bit; and -- training -- the backward
+    pass (the 3x3 conv's own kernels) against fp32 PyTorch autograd."""
     import torch.nn.functional as F
     from infodiffusion_amd import modules
     torch.manual_seed(3)
@@ -941,30 +943,50 @@ def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl):
     if Co != C:
         up.main = torch.nn.Conv2d(C, Co, 3, stride=1, padding=1).to(DEV)
         up._cfg = modules._cfg(modules._Shadows(up.main), ops.UP2, 9, modules._ACT_NONE)
+        up._cfg['shadows'].want_sub = True
+    up.main.weight.data = up.main.weight.data.contiguous(memory_format=CL)
     with torch.no_grad():
         up.main.bias.add_(0.3 * rnd(1, Co).to(DEV))
     x = rnd(2, B, C, Hl, Hl).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dyw = rnd(4, B, Co, 2 * Hl, 2 * Hl).to(DEV)
     names = []
     orig_call = ops.call
 
     def counted(name, *a):
         names.append(name)
         return orig_call(name, *a)
-    ops.call = counted
-    try:
-        with torch.no_grad():
-            y = up(x)
-        assert names.count('idf_upconv_bf16') == 1 and not any(n.startswith('idf_conv') for n in names), names
-        del names[:]
-        y_train = up(x.clone().requires_grad_(True)).detach()
-        assert 'idf_upconv_bf16' not in names
-    finally:
-        ops.call = orig_call
+    monkeypatch.setattr(ops, 'call', counted)
     with torch.no_grad():
-        want = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode='nearest'), up.main.weight, up.main.bias, padding=1)
+        y = up(x)
+    assert names.count('idf_upconv_bf16') == 1 and not any(n.startswith('idf_conv') for n in names), names
+    # the batched pack kernel == the torch restatement of the sums
+    sset = modules.ShadowSet(up)
+    ref_sub = ops.upconv_pack(up.main.weight)
+    up._cfg['shadows'].sub.zero_()
+    up._cfg['shadows'].key = None
+    sset.refresh(torch.bfloat16, True)
+    assert torch.equal(up._cfg['shadows'].sub.view(torch.int16), ref_sub.view(torch.int16))
+    # training: same forward launch, the 3x3 conv's backward
+    del names[:]
+    xg = x.clone().requires_grad_(True)
+    up.zero_grad()
+    yt = up(xg)
+    assert names.count('idf_upconv_bf16') == 1
+    (yt.float() * dyw).sum().backward()
+    assert torch.equal(yt.detach(), y)
+    monkeypatch.setattr(ops, '_UPCONV', False)
+    del names[:]
+    with torch.no_grad():
+        y_old = up(x)
+    assert 'idf_upconv_bf16' not in names
+    xr = x.float().clone().requires_grad_(True)
+    wr, br = up.main.weight.detach().clone().requires_grad_(True), up.main.bias.detach().clone().requires_grad_(True)
+    want = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, br, padding=1)
+    (want * dyw.bfloat16().float()).sum().backward()
+    want = want.detach()
     assert y.shape == want.shape
     assert rel(y, want) < 1e-2, rel(y, want)
-    assert rel(y, y_train) < 1e-2, rel(y, y_train)
+    assert rel(y, y_old) < 1e-2, rel(y, y_old)
     # the border rows / columns separately (a wrong halo shows there first)
     for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
                (slice(None), slice(None), slice(None), -1)):
@@ -974,6 +996,8 @@ def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl):
     T = st.shape[1]
     yb = y.float().permute(0, 2, 3, 1).reshape(B, T, (4 * Hl * Hl) // T, Co)
     assert rel(st[..., 0], yb.sum(2)) < 1e-5 and rel(st[..., 1], (yb * yb).sum(2)) < 1e-5
+    assert rel(xg.grad, xr.grad) < 2e-2, rel(xg.grad, xr.grad)
+    assert rel(up.main.weight.grad, wr.grad) < 2e-2 and rel(up.main.bias.grad, br.grad) < 2e-2
 
 
 @pytest.mark.parametrize('C1,C2,H', [(128, 128, 16), (128, 64, 32), (64, 64, 64), (128, 64, 64), (256, 256, 8)])

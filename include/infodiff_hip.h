@@ -313,17 +313,23 @@ int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_b
                                        int max_blocks, void* stream);
 
 /* UpSample's forward (modules.py:78-93: nearest x2, then conv3x3 pad 1) as four 2x2 convs on the LOW-resolution input -- the
- * sub-pixel form of the same sum, 16 tap products per four outputs instead of 36 (round 4; the backward pass stays the 3x3
- * conv's: data gradient through the fused up-sampling read, weight gradient of the UP2 class).  x [B, Hl, Wl, Cin] bf16; y [B, 2 Hl, 2 Wl, Cout];
+ * sub-pixel form of the same sum, 16 tap products per four outputs instead of 36 (round 4; data gradient:
+ * idf_upconv_dgrad_bf16 below; the weight gradient stays the UP2 class of idf_conv_wgrad_bf16_batched).  x [B, Hl, Wl, Cin] bf16; y [B, 2 Hl, 2 Wl, Cout];
  * w_sub_frag: the summed weights W'[py][px][ty][tx] = sum_{ky in S(py,ty), kx in S(px,tx)} W[ky][kx] (S(0,0) = {0}, S(0,1) = {1,2},
  * S(1,0) = {0,1}, S(1,1) = {2}; summed in fp32, rounded to bf16 once) as [Cout][16 taps = (py, px, ty, tx)][Cin] in the
  * fragment-major form [Cin/64][Cout/16][16][2][64 lanes = (k group, cout row)][8]; st_out [B][idf_upconv_tiles()][Cout][2]
  * (optional): statistics partials of y.  idf_upconv_tiles == 0: shape not covered (Wl in {8, 16, 32}; Cin, Cout % 64 == 0). */
 int idf_upconv_tiles(int Hl, int Wl, int Cin, int Cout);
 /* the summed weights of every UpSample conv of a network in one launch: table (device) = nrows x {const float* src; void* dst;
- * long so, si, st; int O, I} (48 bytes; src = the fp32 master weight, logical (o, i, tap) at o*so + i*si + tap*st; dst = that
- * conv's w_sub_frag), max_pairs = the largest O * I of the rows. */
+ * void* dstd; long so, si, st; int O, I} (56 bytes; src = the fp32 master weight, logical (o, i, tap) at o*so + i*si + tap*st;
+ * dst = that conv's w_sub_frag; dstd (optional) = its w_sub_dgrad_frag: the same sums with rows = cins, k = couts),
+ * max_pairs = the largest O * I of the rows. */
 int idf_upconv_pack_batched(const void* table, int nrows, long max_pairs, void* stream);
+/* The data gradient of the same layer in the same form: dx [B, Hl, Wl, Cin] from dy [B, 2 Hl, 2 Wl, Cout] -- 16 tap products per
+ * low-resolution pixel instead of a 3x3 conv over the 4x larger dy and a 2x2 sum-pool pass.  idf_upconv_dgrad_ok: shape covered. */
+int idf_upconv_dgrad_ok(int Hl, int Wl, int Cin, int Cout);
+int idf_upconv_dgrad_bf16(const void* dy, const void* w_sub_dgrad_frag, void* dx, int B, int Hl, int Wl, int Cin, int Cout,
+                          void* stream);
 int idf_upconv_bf16(const void* x, const void* w_sub_frag, const float* bias, void* y, float* st_out, int B, int Hl, int Wl,
                     int Cin, int Cout, void* stream);
 

@@ -8,8 +8,8 @@
 // padding of the up-sampled one.  16 MFMA tap-products per four outputs instead of 36: the conv that held the nearest-x2 image in
 // LDS and ran all nine taps over it (conv3x3_halo_bf16 MODE 2) spent 572 us per DDIM evaluation at B = 256 on three such layers.
 // The sums are formed in fp32 from the master weights and rounded to bf16 once (the host packs them fragment-major: 1 KB per
-// wave instruction, straight into registers; upconv_pack_kernel re-packs them with the other weight shadows).  Forward only: the
-// backward pass stays the 3x3 conv's (data gradient through the fused up-sampling read, weight gradient of the UP2 class).
+// wave instruction, straight into registers; upconv_pack_kernel re-packs them with the other weight shadows).  Forward and data
+// gradient (upconv_dgrad_bf16_kernel below); the weight gradient stays the UP2 class of the batched weight-gradient kernel.
 //
 // One 512-thread workgroup = 256 output pixels (R rows x W columns of one image) x 64 couts.  Wave w owns parity w & 3 and the
 // cout half w >> 2: 64 pixels of its parity x 32 couts, 4 x 2 accumulator tiles; per 32-channel chunk 4 taps x 8 MFMAs.  The
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
 // weight shadows after each optimizer step).  One thread per (cout, cin) pair: nine master weights in, sixteen sums out.
 struct UpPackDesc {
   const float* src;       // master weight, logical (o, i, tap) at o * so + i * si + tap * st
-  bf16_t* dst;            // fragment-major [I / 64][O / 16][16][2][64][8]
+  bf16_t* dst;            // fragment-major [I / 64][O / 16][16][2][64][8]: rows = couts, k = cin (forward)
+  bf16_t* dstd;           // optional, fragment-major [O / 64][I / 16][16][2][64][8]: rows = cins, k = cout (data gradient; O % 64 == 0)
   long so, si, st;
   int O, I;
 };
@@ -194,6 +195,8 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(const UpPackDesc* __re
   }
   const size_t base = ((size_t)(i >> 6) * (d.O >> 4) + (o >> 4)) * 16;
   const int inner = (((i >> 3) & 3) * 16 + (o & 15)) * 8 + (i & 7), half = (i >> 5) & 1;
+  const size_t based = ((size_t)(o >> 6) * (d.I >> 4) + (i >> 4)) * 16;
+  const int innerd = (((o >> 3) & 3) * 16 + (i & 15)) * 8 + (o & 7), halfd = (o >> 5) & 1;
 #pragma unroll
   for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -206,7 +209,134 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(const UpPackDesc* __re
           const float v = px == 0 ? (tx == 0 ? r[0] : r[1] + r[2]) : (tx == 0 ? r[0] + r[1] : r[2]);
           const int tap = (py * 2 + px) * 4 + ty * 2 + tx;
           d.dst[((base + tap) * 2 + half) * 512 + inner] = f32_to_bf16(v);
+          if (d.dstd) d.dstd[((based + tap) * 2 + halfd) * 512 + innerd] = f32_to_bf16(v);
         }
+}
+
+// ---- the data gradient of the same layer, in the same form: dx (low resolution) = sum over the four output parities of a 2x2-tap
+// product of dy's parity plane with the transposed summed weights -- 16 tap products per low-resolution pixel instead of a 3x3 conv
+// over the 4x larger dy followed by a 2x2 sum-pool pass:
+//   dx[Y][X] = sum_{py,px,ty,tx} W'[py][px][ty][tx]^T dy[2 (Y + 1 - ty - py) + py][2 (X + 1 - tx - px) + px]
+// One 512-thread workgroup = 64 low-resolution pixels (RL rows x Wl columns) x 64 cins.  Wave w takes parity w & 3 and the cin half
+// w >> 2: its 4 taps over all 64 pixels x 32 cins (4 x 2 accumulator tiles, the forward kernel's shape), and the four parity waves'
+// partial sums meet in LDS at the end.  The dy tile of a 32-cout chunk -- (2 RL + 2) x (2 Wl + 2) pixels, pitch 96 B -- is staged once
+// per chunk (two barriers: the tile is 38 KB, not double-buffered).
+struct UpDP {
+  const bf16_t* dy;       // [B][2 Hl][2 Wl][Cout]
+  const bf16_t* w;        // fragment-major [Cout / 64][Cin / 16][16][2][64][8]
+  bf16_t* dx;             // [B][Hl][Wl][Cin]
+  int B, Hl, Wl, Cin, Cout;
+  int RL, tiles_per_img, n_tiles, wlshift;
+};
+
+__global__ __launch_bounds__(512) void upconv_dgrad_bf16_kernel(const UpDP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Wl = p.Wl, RL = p.RL, WH = 2 * Wl + 2, nph = (2 * RL + 2) * WH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
+  const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, Y0 = t_in * RL;
+  const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
+  const int nchunks = p.Cout >> 5, H2 = 2 * p.Hl, W2 = 2 * Wl;
+
+  constexpr int NV = 4;           // staged vectors per thread: (2 RL + 2)(2 Wl + 2) x 4 <= 2048 (planned on the host)
+  int goff[NV], loff[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int idx = tid + k * 512;
+    goff[k] = -1; loff[k] = -1;
+    if (idx < nph * 4) {
+      const int pix = idx >> 2, q = idx & 3;
+      const int hy = pix / WH, hx = pix - hy * WH;
+      const int iy = 2 * Y0 - 1 + hy, ix = hx - 1;
+      loff[k] = pix * UP_PPB + q * 16;
+      if ((unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2) goff[k] = ((b * H2 + iy) * W2 + ix) * p.Cout + q * 8;
+    }
+  }
+  int pbase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 16 + r16, Yl = q >> p.wlshift, Xl = q & (Wl - 1);
+    pbase[i] = ((2 * Yl + 3 - py) * WH + 2 * Xl + 3 - px) * UP_PPB + g * 16;      // tap (0, 0); tap (ty, tx): - 2 (ty WH + tx) pixels
+  }
+  const bf16_t* wb = p.w + ((size_t)((n0 >> 4) + 2 * ch) * 16 + (py * 2 + px) * 4) * 2 * 512 + lane * 8;
+  const size_t pair_stride = (size_t)(p.Cin >> 4) * 16 * 2 * 512;
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t xr[NV];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      xr[k] = goff[k] >= 0 ? *reinterpret_cast<const u32x4_t*>(p.dy + goff[k] + c * 32) : u32x4_t{0u, 0u, 0u, 0u};
+  };
+  load_chunk(0);
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    bf16x8_t wf[4][2];
+    const bf16_t* wc = wb + (size_t)(c >> 1) * pair_stride + (c & 1) * 512;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        wf[t][a] = *reinterpret_cast<const bf16x8_t*>(wc + ((size_t)a * 16 + t) * 2 * 512);
+    if (c > 0) up_barrier();        // the previous chunk's reads are done
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (loff[k] >= 0) *reinterpret_cast<u32x4_t*>(smem + loff[k]) = xr[k];
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    up_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int toff = -2 * ((t >> 1) * WH + (t & 1)) * UP_PPB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(smem + pbase[i] + toff);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][a], xf, acc[a][i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four parities' partial sums meet in LDS: red [8 waves][64 pixels][32 cins + 4] fp32
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int RP = 36;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(red + ((size_t)wave * 64 + i * 16 + r16) * RP + 16 * a + 4 * g) =
+          make_float4(acc[a][i][0], acc[a][i][1], acc[a][i][2], acc[a][i][3]);
+  __syncthreads();
+  {
+    // 64 pixels x 64 cins = 512 vectors of 8 cins: one per thread
+    const int pxl = tid >> 3, v = tid & 7, half = v >> 2, c8 = (v & 3) * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* src = red + ((size_t)(half * 4 + w) * 64 + pxl) * RP + c8;
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      o[0] += lo.x; o[1] += lo.y; o[2] += lo.z; o[3] += lo.w; o[4] += hi.x; o[5] += hi.y; o[6] += hi.z; o[7] += hi.w;
+    }
+    const int Yl = pxl >> p.wlshift, Xl = pxl & (Wl - 1);
+    uint32_t w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)f32_to_bf16(o[2 * j]) | ((uint32_t)f32_to_bf16(o[2 * j + 1]) << 16);
+    *reinterpret_cast<uint4*>(p.dx + ((size_t)(b * p.Hl + Y0 + Yl) * Wl + Xl) * p.Cin + n0 + v * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+  }
+}
+
+inline bool up_dgrad_plan(int Hl, int Wl, int Cin, int Cout, int* RL) {
+  if (Wl < 8 || Wl > 32 || (Wl & (Wl - 1)) || Hl < 1 || (Cin % 64) || (Cout % 64)) return false;
+  const int r = 64 / Wl;                          // low-resolution rows per 64-pixel tile: 8 / 4 / 2
+  if (r < 1 || Hl % r || (2 * r + 2) * (2 * Wl + 2) * 4 > 2048) return false;
+  *RL = r;
+  return true;
 }
 
 inline bool up_plan(int Hl, int Wl, int Cin, int Cout, int* R) {
@@ -252,14 +382,46 @@ extern "C" int idf_upconv_bf16(const void* x, const void* w_sub_frag, const floa
   return IDF_OK;
 }
 
-// table (device): nrows x {src*, dst*, long so, si, st, int O, I} (48 bytes), one row per UpSample conv; max_pairs = the largest
-// O * I of the rows.  dst: the w_sub_frag operand of idf_upconv_bf16.
+// table (device): nrows x {src*, dst*, dstd*, long so, si, st, int O, I} (56 bytes), one row per UpSample conv; max_pairs = the
+// largest O * I of the rows.  dst: the w_sub_frag operand of idf_upconv_bf16; dstd (optional): that of idf_upconv_dgrad_bf16.
 extern "C" int idf_upconv_pack_batched(const void* table, int nrows, long max_pairs, void* stream) {
   if (nrows <= 0 || max_pairs <= 0) return IDF_OK;
   if (!table) IDF_FAIL(IDF_ERR_BADARG, "upconv_pack_batched: null table");
-  static_assert(sizeof(UpPackDesc) == 48, "the host builds 48-byte rows");
+  static_assert(sizeof(UpPackDesc) == 56, "the host builds 56-byte rows");
   hipLaunchKernelGGL(upconv_pack_kernel, dim3((unsigned)((max_pairs + 255) / 256), (unsigned)nrows), dim3(256), 0, (hipStream_t)stream,
                      (const UpPackDesc*)table);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// dx [B, Hl, Wl, Cin] = the data gradient of idf_upconv_bf16's layer w.r.t. its low-resolution input, from dy [B, 2 Hl, 2 Wl, Cout];
+// w_sub_dgrad_frag: the summed weights with rows = cins, k = couts (idf_upconv_pack_batched's `dstd`).  idf_upconv_dgrad_ok: 1 when
+// the shape is covered (Wl in {8, 16, 32}; Cin, Cout % 64 == 0; Hl a multiple of 64 / Wl).
+extern "C" int idf_upconv_dgrad_ok(int Hl, int Wl, int Cin, int Cout) {
+  int RL;
+  return up_dgrad_plan(Hl, Wl, Cin, Cout, &RL) ? 1 : 0;
+}
+
+extern "C" int idf_upconv_dgrad_bf16(const void* dy, const void* w_sub_dgrad_frag, void* dx, int B, int Hl, int Wl, int Cin,
+                                     int Cout, void* stream) {
+  int RL;
+  if (!up_dgrad_plan(Hl, Wl, Cin, Cout, &RL)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "upconv_dgrad_bf16: Hl%d Wl%d Cin%d Cout%d not covered", Hl, Wl, Cin, Cout);
+  if (!dy || !w_sub_dgrad_frag || !dx) IDF_FAIL(IDF_ERR_BADARG, "upconv_dgrad_bf16: null argument");
+  if (B == 0) return IDF_OK;
+  if ((long)B * 4 * Hl * Wl * (Cin > Cout ? Cin : Cout) >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "upconv_dgrad_bf16: tensor too large for 32-bit offsets");
+  UpDP p;
+  p.dy = (const bf16_t*)dy; p.w = (const bf16_t*)w_sub_dgrad_frag; p.dx = (bf16_t*)dx;
+  p.B = B; p.Hl = Hl; p.Wl = Wl; p.Cin = Cin; p.Cout = Cout;
+  p.RL = RL; p.tiles_per_img = Hl / RL; p.n_tiles = Cin / 64;
+  int ws = 0;
+  while ((1 << ws) < Wl) ++ws;
+  p.wlshift = ws;
+  size_t lds = (size_t)(2 * RL + 2) * (2 * Wl + 2) * UP_PPB, red = (size_t)8 * 64 * 36 * sizeof(float);
+  if (lds < red) lds = red;
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)upconv_dgrad_bf16_kernel, lds, grant); e != hipSuccess)
+    IDF_FAIL(IDF_ERR_HIP, "upconv_dgrad_bf16: %d bytes of LDS refused: %s", (int)lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(upconv_dgrad_bf16_kernel, dim3((unsigned)(B * p.tiles_per_img * p.n_tiles)), dim3(512), lds, (hipStream_t)stream, p);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -48,6 +48,7 @@ class _Shadows:
         # UpSample's conv: the summed sub-pixel weights of idf_upconv_bf16 (bf16 only), re-packed with the other shadows
         self.want_sub = False
         self.sub = None
+        self.subd = None            # ... and their data-gradient form (rows = cins), idf_upconv_dgrad_bf16
         # several convs applied as one (q, k, v): their weights / biases live adjacently so the
         # concatenation is a view and its gradient is written once (grad_arena.ParamGroup)
         self.wgroup = ops.ParamGroup([c.weight for c in convs]) if len(convs) > 1 else None
@@ -80,6 +81,7 @@ class _Shadows:
         if self.want_sub and dtype == torch.bfloat16 and O % 16 == 0 and I % 64 == 0 and (kh, kw) == (3, 3) and (
                 self.sub is None or self.sub.device != dev):
             self.sub = torch.empty((O * 16 * I,), dtype=dtype, device=dev)
+            self.subd = torch.empty((O * 16 * I,), dtype=dtype, device=dev) if (O % 64 == 0 and I % 16 == 0) else None
             self.key = None
         if self.want_frag:
             for j, fits, on in ((2, O % 16 == 0 and I % 64 == 0, True), (3, I % 16 == 0 and O % 64 == 0, need_dgrad)):
@@ -125,6 +127,8 @@ class _Shadows:
                         self.val[j].copy_(m.view(N // 16, 16, taps, K // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1))
                 if self.sub is not None:
                     self.sub.copy_(ops.upconv_pack(self.convs[0].weight))
+                    if self.subd is not None:
+                        self.subd.copy_(ops.upconv_pack(self.convs[0].weight, dgrad=True))
             self.key = self.current_key(dtype)
         return self.val
 
@@ -213,15 +217,16 @@ class ShadowSet:
              F32 if dtype == torch.float32 else BF16, torch.cuda.current_stream().cuda_stream)
         ups = [s for s in self.items if s.sub is not None]
         if ups:
-            ukey = tuple((s.convs[0].weight.data_ptr(), s.sub.data_ptr()) for s in ups)
+            ukey = tuple((s.convs[0].weight.data_ptr(), s.sub.data_ptr(), s.subd.data_ptr() if s.subd is not None else 0) for s in ups)
             if ukey != self.up_key:
                 rows = []
                 for s in ups:
                     w = s.convs[0].weight
-                    rows.append((w.data_ptr(), s.sub.data_ptr(), w.stride(0), w.stride(1), w.stride(3), w.shape[0], w.shape[1]))
+                    rows.append((w.data_ptr(), s.sub.data_ptr(), s.subd.data_ptr() if s.subd is not None else 0, w.stride(0), w.stride(1),
+                                 w.stride(3), w.shape[0], w.shape[1]))
                     if w.stride(2) != 3 * w.stride(3):
                         raise RuntimeError('conv weight layout not packable in place')
-                dt = np.dtype([('src', '<i8'), ('dst', '<i8'), ('so', '<i8'), ('si', '<i8'), ('st', '<i8'), ('O', '<i4'), ('I', '<i4')])
+                dt = np.dtype([('src', '<i8'), ('dst', '<i8'), ('dstd', '<i8'), ('so', '<i8'), ('si', '<i8'), ('st', '<i8'), ('O', '<i4'), ('I', '<i4')])
                 host = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).reshape(len(rows), -1).copy())
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError('ShadowSet: run one eager forward before graph capture')

@@ -284,10 +284,17 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
     return y, a, mean, rstd, sc, sh, st
 
 
-def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape, residual=None):
+def conv_dgrad_raw(dy, w_dgrad, mode_fwd, taps, x_shape, residual=None, shadows=None):
     """Data gradient w.r.t. the (activated) conv input of logical shape x_shape (+ residual: a gradient
     arriving over another branch of the same input, added in the epilogue)."""
     B, Cin, Hs, Ws = x_shape
+    subd = getattr(shadows, 'subd', None) if mode_fwd == UP2 else None
+    if (subd is not None and _UPCONV and _UPCONV_DGRAD and dy.dtype == torch.bfloat16 and dy.is_cuda
+            and _lib.load().idf_upconv_dgrad_ok(Hs, Ws, Cin, dy.shape[1])):
+        # UpSample: 16 tap products per low-resolution pixel (summed sub-pixel weights) instead of the 3x3 conv over dy + pool pass
+        out = empty_nhwc(B, Cin, Hs, Ws, dy.dtype, dy.device)
+        call('idf_upconv_dgrad_bf16', _p(_nhwc(dy)), _p(subd), _p(out), B, Hs, Ws, Cin, dy.shape[1], _st())
+        return out if residual is None else out + residual
     if mode_fwd == S2:
         return conv_raw(dy, w_dgrad, None, residual, None, None, None, 0, 0.0, T2, taps, 0, Cin, (Hs, Ws))
     if mode_fwd == UP2:
@@ -1023,10 +1030,10 @@ class _FusedConv(torch.autograd.Function):
                                                            shadows=cfg['shadows'])
             else:
                 if not act and dres_in is not None and dres2_in is None and x.dtype == torch.bfloat16:
-                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in)   # joined in the epilogue
+                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, residual=dres_in, shadows=cfg['shadows'])   # joined in the epilogue
                     dres_in = None
                 else:
-                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape)
+                    dA = conv_dgrad_raw(dy, w_dgrad, mode, taps, x.shape, shadows=cfg['shadows'])
                 if act and gn_small_ok(x):
                     dx, dgw, dgb, dft, dfa = gn_fused_bwd_raw(dA, x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh,
                                                               seed, salt, p_drop, act, gslots, dres_in, dres2=dres2_in)
@@ -1604,6 +1611,7 @@ def attention(qkv, pre=None):
 
 # ------------------------------------------------- UpSample at inference: four 2x2 convs on the low-resolution input
 _UPCONV = os.environ.get('IDF_UPCONV', '1') != '0'
+_UPCONV_DGRAD = os.environ.get('IDF_UPCONV_DGRAD', '1') != '0'
 _UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))          # S(parity, tap): the 3x3 kernel rows / columns a low-resolution tap stands for
 
 
@@ -1614,9 +1622,10 @@ def upconv_tiles(x, Cout):
     return int(_lib.load().idf_upconv_tiles(x.shape[2], x.shape[3], x.shape[1], Cout))
 
 
-def upconv_pack(weight):
+def upconv_pack(weight, dgrad=False):
     """[O, I, 3, 3] master weights -> the summed sub-pixel weights W'[py][px][ty][tx] (fp32 sums, one bf16 rounding) as
-    [O][16][I], fragment-major (the layout of idf_pack_conv_weights_batched's `wfrag`)."""
+    [O][16][I] (dgrad: [I][16][O], the data gradient's rows = cins), fragment-major (the layout of
+    idf_pack_conv_weights_batched's `wfrag`)."""
     with torch.no_grad():
         w = weight.detach().float()
         O, I = w.shape[:2]
@@ -1632,7 +1641,10 @@ def upconv_pack(weight):
                             cols.append(rows[0] if len(rows) == 1 else rows[0] + rows[1])
                         taps.append(cols[0] if len(cols) == 1 else cols[0] + cols[1])
         m = torch.stack(taps, dim=1).to(torch.bfloat16)                  # [O][16][I]
-        return m.view(O // 16, 16, 16, I // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1).contiguous()
+        if dgrad:
+            m = m.permute(2, 1, 0).contiguous()                          # [I][16][O]
+        N, _, K = m.shape
+        return m.view(N // 16, 16, 16, K // 64, 2, 4, 8).permute(3, 0, 2, 4, 5, 1, 6).reshape(-1).contiguous()
 
 
 def upconv_raw(x, w_sub_frag, bias, Cout, tiles):

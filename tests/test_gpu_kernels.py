@@ -966,6 +966,8 @@ def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl, monkeypatch):
     up._cfg['shadows'].key = None
     sset.refresh(torch.bfloat16, True)
     assert torch.equal(up._cfg['shadows'].sub.view(torch.int16), ref_sub.view(torch.int16))
+    if Co % 64 == 0:
+        assert torch.equal(up._cfg['shadows'].subd.view(torch.int16), ops.upconv_pack(up.main.weight, dgrad=True).view(torch.int16))
     # training: same forward launch, the 3x3 conv's backward
     del names[:]
     xg = x.clone().requires_grad_(True)
@@ -974,6 +976,9 @@ def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl, monkeypatch):
     assert names.count('idf_upconv_bf16') == 1
     (yt.float() * dyw).sum().backward()
     assert torch.equal(yt.detach(), y)
+    # the data gradient in the same sub-pixel form (no 3x3 conv over dy, no pool pass) where the shape is covered
+    if Co % 64 == 0:
+        assert names.count('idf_upconv_dgrad_bf16') == 1 and 'idf_pool2_sum' not in names, names
     monkeypatch.setattr(ops, '_UPCONV', False)
     del names[:]
     with torch.no_grad():

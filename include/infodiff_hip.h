@@ -327,6 +327,13 @@ int idf_upconv_tiles(int Hl, int Wl, int Cin, int Cout);
 int idf_upconv_pack_batched(const void* table, int nrows, long max_pairs, void* stream);
 /* The data gradient of the same layer in the same form: dx [B, Hl, Wl, Cin] from dy [B, 2 Hl, 2 Wl, Cout] -- 16 tap products per
  * low-resolution pixel instead of a 3x3 conv over the 4x larger dy and a 2x2 sum-pool pass.  idf_upconv_dgrad_ok: shape covered. */
+/* DownSample's data gradient (modules.py:63-75: conv3x3 stride 2, pad 1) by output parity: per parity of the high-resolution pixel
+ * only the taps that land on a dy pixel (1, 2, 2, 4 of the 9) instead of a 3x3 conv over the zero-stuffed dy.  dy [B, Hl, Wl, Cout];
+ * w_dgrad_frag: the conv's data-gradient weights fragment-major (idf_pack_conv_weights_batched's `wdfrag`); res (optional): a
+ * gradient arriving over another branch of the same input, added before the rounding; dx [B, 2 Hl, 2 Wl, Cin]. */
+int idf_downconv_dgrad_ok(int Hl, int Wl, int Cin, int Cout);
+int idf_downconv_dgrad_bf16(const void* dy, const void* w_dgrad_frag, const void* res, void* dx, int B, int Hl, int Wl, int Cin,
+                            int Cout, void* stream);
 int idf_upconv_dgrad_ok(int Hl, int Wl, int Cin, int Cout);
 int idf_upconv_dgrad_bf16(const void* dy, const void* w_sub_dgrad_frag, void* dx, int B, int Hl, int Wl, int Cin, int Cout,
                           void* stream);

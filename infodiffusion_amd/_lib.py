@@ -103,6 +103,8 @@ SIGNATURES = {
     'idf_upconv_tiles': ([_i, _i, _i, _i], C.c_int),
     'idf_upconv_pack_batched': ([_p, _i, _l, _p], C.c_int),
     'idf_upconv_dgrad_ok': ([_i, _i, _i, _i], C.c_int),
+    'idf_downconv_dgrad_ok': ([_i, _i, _i, _i], C.c_int),
+    'idf_downconv_dgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_upconv_dgrad_bf16': ([_p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_upconv_bf16': ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_attnblock_fwd': ([_p, _p, _i, _p, _p, _f] + [_p] * 14 + [_f, _i, _i, _i, _p], C.c_int),

@@ -331,6 +331,132 @@ __global__ __launch_bounds__(512) void upconv_dgrad_bf16_kernel(const UpDP p) {
   }
 }
 
+// ---- DownSample's data gradient (modules.py:63-75: conv3x3 stride 2, pad 1) by output parity.  The transposed stride-2 conv over a
+// zero-stuffed dy multiplies three zeros out of four; per parity of the high-resolution pixel only the taps that land on a dy pixel
+// remain:  i = 2 Y + py needs ky = 1 (dy row Y) for py = 0 and ky = 0 (row Y + 1), ky = 2 (row Y) for py = 1 -- 1, 2, 2 and 4 taps for
+// the four parities, the 3x3 weights used as they are (the data-gradient fragment-major shadow, taps stored flipped).
+// The workgroup shape is upconv_bf16_kernel's: 256 high-resolution pixels x 64 cins, wave = (parity, cin half).
+struct DnP {
+  const bf16_t* dy;       // [B][Hl][Wl][Cout]
+  const bf16_t* w;        // data-gradient fragment-major shadow [Cout / 64][Cin / 16][9 taps flipped][2][64][8]
+  const bf16_t* res;      // [B][2 Hl][2 Wl][Cin] or null: a gradient arriving over another branch of the same input
+  bf16_t* dx;             // [B][2 Hl][2 Wl][Cin]
+  int B, Hl, Wl, Cin, Cout;
+  int R, tiles_per_img, n_tiles, wlshift;
+};
+
+__global__ __launch_bounds__(512) void downconv_dgrad_bf16_kernel(const DnP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Wl = p.Wl, W = 2 * Wl, RL = p.R >> 1, WH = Wl + 2, npl = (RL + 2) * WH;
+  const int img_bytes = ((npl * UP_PPB + 15) >> 4) << 4;
+  unsigned char* img0 = smem;
+  bf16_t* tileo = reinterpret_cast<bf16_t*>(smem + 2 * img_bytes);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
+  const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, oy0 = t_in * p.R, ly0 = oy0 >> 1;
+  const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
+  const int nchunks = p.Cout >> 5;
+
+  int goff[2], loff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * 512;
+    goff[k] = -1; loff[k] = -1;
+    if (idx < npl * 4) {
+      const int pix = idx >> 2, q = idx & 3;
+      const int hy = pix / WH, hx = pix - hy * WH;
+      const int iy = ly0 + hy - 1, ix = hx - 1;
+      loff[k] = pix * UP_PPB + q * 16;
+      if ((unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)Wl) goff[k] = ((b * p.Hl + iy) * Wl + ix) * p.Cout + q * 8;
+    }
+  }
+  int pbase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 16 + r16, ly = q >> p.wlshift, lx = q & (Wl - 1);
+    pbase[i] = ((ly + 1) * WH + lx + 1) * UP_PPB + g * 16;        // dy pixel (Y, X) of this lane's output; taps add (dY WH + dX) pixels
+  }
+  const bf16_t* wb = p.w + ((size_t)((n0 >> 4) + 2 * ch) * 9) * 2 * 512 + lane * 8;
+  const size_t pair_stride = (size_t)(p.Cin >> 4) * 9 * 2 * 512;
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[a][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t xr[2];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      xr[k] = goff[k] >= 0 ? *reinterpret_cast<const u32x4_t*>(p.dy + goff[k] + c * 32) : u32x4_t{0u, 0u, 0u, 0u};
+  };
+  load_chunk(0);
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    bf16x8_t wf[2][2][2];           // [row tap][column tap][cin fragment]; a parity-0 axis has one tap
+    const bf16_t* wc = wb + (size_t)(c >> 1) * pair_stride + (c & 1) * 512;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        if (ti > py || tj > px) continue;                       // (wave-uniform)
+        const int ky = py ? 2 * ti : 1, kx = px ? 2 * tj : 1, tf = 8 - (ky * 3 + kx);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          wf[ti][tj][a] = *reinterpret_cast<const bf16x8_t*>(wc + ((size_t)a * 9 + tf) * 2 * 512);
+      }
+    unsigned char* img = img0 + (c & 1) * img_bytes;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (loff[k] >= 0) *reinterpret_cast<u32x4_t*>(img + loff[k]) = xr[k];
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    up_barrier();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        if (ti > py || tj > px) continue;
+        // ky = 0 reads dy row Y + 1, ky = 2 (and the lone ky = 1) row Y
+        const int dY = (py && ti == 0) ? 1 : 0, dX = (px && tj == 0) ? 1 : 0;
+        const int toff = (dY * WH + dX) * UP_PPB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(img + pbase[i] + toff);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][tj][a], xf, acc[a][i], 0, 0, 0);
+        }
+      }
+  }
+  // ---- epilogue: (+ res), bf16, the tile in pixel order through LDS, full-line stores
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int col = 32 * ch + 16 * a + 4 * g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 16 + r16, ly = q >> p.wlshift, lx = q & (Wl - 1);
+      const int pl = (2 * ly + py) * W + 2 * lx + px;
+      float v0 = acc[a][i][0], v1 = acc[a][i][1], v2 = acc[a][i][2], v3 = acc[a][i][3];
+      if (p.res) {
+        const uint2 rs = *reinterpret_cast<const uint2*>(p.res + ((size_t)(b * 2 * p.Hl + oy0) * W + pl) * p.Cin + n0 + col);
+        v0 += __uint_as_float(rs.x << 16); v1 += __uint_as_float(rs.x & 0xffff0000u);
+        v2 += __uint_as_float(rs.y << 16); v3 += __uint_as_float(rs.y & 0xffff0000u);
+      }
+      const uint32_t lo = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+      const uint32_t hi = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+      *reinterpret_cast<uint2*>(tileo + pl * UP_TP + col) = make_uint2(lo, hi);
+    }
+  }
+  __syncthreads();
+  const int v = tid & 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pl = (tid >> 3) + 64 * k;
+    const uint4 o = *reinterpret_cast<const uint4*>(tileo + pl * UP_TP + v * 8);
+    *reinterpret_cast<uint4*>(p.dx + ((size_t)(b * 2 * p.Hl + oy0) * W + pl) * p.Cin + n0 + v * 8) = o;
+  }
+}
+
 inline bool up_dgrad_plan(int Hl, int Wl, int Cin, int Cout, int* RL) {
   if (Wl < 8 || Wl > 32 || (Wl & (Wl - 1)) || Hl < 1 || (Cin % 64) || (Cout % 64)) return false;
   const int r = 64 / Wl;                          // low-resolution rows per 64-pixel tile: 8 / 4 / 2
@@ -422,6 +548,39 @@ extern "C" int idf_upconv_dgrad_bf16(const void* dy, const void* w_sub_dgrad_fra
   if (hipError_t e = idf_ensure_lds((const void*)upconv_dgrad_bf16_kernel, lds, grant); e != hipSuccess)
     IDF_FAIL(IDF_ERR_HIP, "upconv_dgrad_bf16: %d bytes of LDS refused: %s", (int)lds, hipGetErrorString(e));
   hipLaunchKernelGGL(upconv_dgrad_bf16_kernel, dim3((unsigned)(B * p.tiles_per_img * p.n_tiles)), dim3(512), lds, (hipStream_t)stream, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// dx [B, 2 Hl, 2 Wl, Cin] (+ res) = the data gradient of a stride-2 3x3 conv (pad 1) w.r.t. its input, from dy [B, Hl, Wl, Cout]:
+// w_dgrad_frag = the conv's data-gradient weights fragment-major (idf_pack_conv_weights_batched's `wdfrag`).
+// idf_downconv_dgrad_ok: 1 when covered (Wl in {8, 16, 32}; Cin, Cout % 64 == 0; 256-pixel tiles of whole rows).
+extern "C" int idf_downconv_dgrad_ok(int Hl, int Wl, int Cin, int Cout) {
+  int R;
+  return up_plan(Hl, Wl, Cout, Cin, &R) ? 1 : 0;
+}
+
+extern "C" int idf_downconv_dgrad_bf16(const void* dy, const void* w_dgrad_frag, const void* res, void* dx, int B, int Hl, int Wl,
+                                       int Cin, int Cout, void* stream) {
+  int R;
+  if (!up_plan(Hl, Wl, Cout, Cin, &R)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "downconv_dgrad_bf16: Hl%d Wl%d Cin%d Cout%d not covered", Hl, Wl, Cin, Cout);
+  if (!dy || !w_dgrad_frag || !dx) IDF_FAIL(IDF_ERR_BADARG, "downconv_dgrad_bf16: null argument");
+  if (B == 0) return IDF_OK;
+  if ((long)B * 4 * Hl * Wl * (Cin > Cout ? Cin : Cout) >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "downconv_dgrad_bf16: tensor too large for 32-bit offsets");
+  DnP p;
+  p.dy = (const bf16_t*)dy; p.w = (const bf16_t*)w_dgrad_frag; p.res = (const bf16_t*)res; p.dx = (bf16_t*)dx;
+  p.B = B; p.Hl = Hl; p.Wl = Wl; p.Cin = Cin; p.Cout = Cout;
+  p.R = R; p.tiles_per_img = 2 * Hl / R; p.n_tiles = Cin / 64;
+  int ws = 0;
+  while ((1 << ws) < Wl) ++ws;
+  p.wlshift = ws;
+  const int npl = (R / 2 + 2) * (Wl + 2);
+  const size_t img = (((size_t)npl * UP_PPB + 15) / 16) * 16;
+  const size_t lds = 2 * img + (size_t)256 * UP_TP * 2;
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)downconv_dgrad_bf16_kernel, lds, grant); e != hipSuccess)
+    IDF_FAIL(IDF_ERR_HIP, "downconv_dgrad_bf16: %d bytes of LDS refused: %s", (int)lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(downconv_dgrad_bf16_kernel, dim3((unsigned)(B * p.tiles_per_img * p.n_tiles)), dim3(512), lds, (hipStream_t)stream, p);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -1005,6 +1005,57 @@ def test_upsample_conv_as_four_subpixel_convs(B, C, Co, Hl, monkeypatch):
     assert rel(up.main.weight.grad, wr.grad) < 2e-2 and rel(up.main.bias.grad, br.grad) < 2e-2
 
 
+@pytest.mark.parametrize('B,C,H', [(3, 64, 64), (2, 128, 32), (2, 128, 16), (2, 256, 32)])
+@pytest.mark.parametrize('alias', [False, True])
+def test_downsample_data_gradient_by_output_parity(B, C, H, alias, monkeypatch):
+    """DownSample's data gradient (idf_downconv_dgrad_bf16: per parity of the high-resolution pixel only the taps that land on a dy
+    pixel -- 1, 2, 2, 4 of the 9 -- with the conv's fragment-major data-gradient weights) against fp32 PyTorch autograd of
+    conv2d(stride 2, pad 1) on the same bf16-valued operands (2e-2: bf16 operands), borders separately, and against the kernel
+    it replaces (the 3x3 conv over the zero-stuffed dy); `alias`: the skip connection's gradient joins in the epilogue."""
+    import torch.nn.functional as F
+    from infodiffusion_amd import modules
+    torch.manual_seed(9)
+    dn = modules.DownSample(C).to(DEV)
+    dn.main.weight.data = dn.main.weight.data.contiguous(memory_format=CL)
+    x = rnd(1, B, C, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dyw = rnd(2, B, C, H // 2, H // 2).to(DEV)
+    dsk = rnd(3, B, C, H, H).to(DEV)
+    names = []
+    orig_call = ops.call
+
+    def counted(name, *a):
+        names.append(name)
+        return orig_call(name, *a)
+    monkeypatch.setattr(ops, 'call', counted)
+
+    def run():
+        del names[:]
+        xg = x.clone().requires_grad_(True)
+        dn.zero_grad()
+        if alias:
+            y, xa = dn(xg, want_alias=True)
+            ((y.float() * dyw).sum() + (xa.float() * dsk).sum()).backward()
+        else:
+            (dn(xg).float() * dyw).sum().backward()
+        return xg.grad.detach().float().clone(), list(names)
+
+    run()                                   # asks for the fragment-major data-gradient weights (next re-pack)
+    g, used = run()
+    assert used.count('idf_downconv_dgrad_bf16') == 1, used
+    monkeypatch.setattr(ops, '_DOWN_DGRAD', False)
+    g_old, used_old = run()
+    assert 'idf_downconv_dgrad_bf16' not in used_old
+    xr = x.float().clone().requires_grad_(True)
+    yr = F.conv2d(xr, dn.main.weight.detach(), dn.main.bias.detach(), stride=2, padding=1)
+    ((yr * dyw.bfloat16().float()).sum() + ((xr * dsk.bfloat16().float()).sum() if alias else 0.0)).backward()
+    want = xr.grad
+    assert rel(g, want) < 2e-2, rel(g, want)
+    assert rel(g, g_old) < 2e-2, rel(g, g_old)
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), -1)):
+        assert rel(g[sl], want[sl]) < 2e-2, sl
+
+
 @pytest.mark.parametrize('C1,C2,H', [(128, 128, 16), (128, 64, 32), (64, 64, 64), (128, 64, 64), (256, 256, 8)])
 def test_two_source_groupnorm_conv1x1_wgrad(C1, C2, H):
     """The (x, x2) pair read in place == the same kernels on the materialised concatenation: one-launch

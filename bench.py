@@ -241,6 +241,21 @@ class LaunchRecorder:
             if a[3]:
                 bufs.append((3, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin + 2.0 * px * Cout * sc_Cin
+        # UpSample / DownSample in their sub-pixel forms: the ALGORITHMIC work stays the reference's (a 3x3 conv over the up-sampled
+        # image, its data gradient, the transposed stride-2 conv) -- the launches execute 4/9, 4/9 and all of it respectively
+        if name == 'idf_upconv_bf16':
+            B, Hl, Wl, Cin, Cout = a[5:10]
+            px = B * 4 * Hl * Wl
+            return 'conv3x3', [(0, B * Hl * Wl * Cin * 2), (3, px * Cout * 2)], 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_upconv_dgrad_bf16':
+            B, Hl, Wl, Cin, Cout = a[3:8]
+            px = B * 4 * Hl * Wl
+            return 'conv3x3', [(0, px * Cout * 2), (2, B * Hl * Wl * Cin * 2)], 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_downconv_dgrad_bf16':
+            B, Hl, Wl, Cin, Cout = a[4:9]
+            px = B * Hl * Wl
+            bufs = [(0, px * Cout * 2), (3, 4 * px * Cin * 2)] + ([(2, 4 * px * Cin * 2)] if a[2] else [])
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
         if name == 'idf_conv3x3_fewc_bf16':      # the head conv (Cin <= 3): one MFMA K-step per output tile
             B, H, W, Cin, Cout = a[4:9]
             px = B * H * W
@@ -594,13 +609,14 @@ def main():
         if 'conv3x3' in fam:
             n, ms, fl, by = fam['conv3x3']
             ach = fl / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16 / conv3x3_fewc_bf16, and on the '
+            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16 / conv3x3_fewc_bf16, the sub-pixel UpSample / DownSample kernels upconv_bf16 / '
+                                         'upconv_dgrad_bf16 / downconv_dgrad_bf16 -- counted with the reference\'s 3x3 FLOPs, of which they execute 4/9, 4/9 and 1/1 --, and on the '
                                          'small maps conv_wr_kernel / resblock8_fwd_kernel / resblock8_bwd_kernel, whose launches hold 2-3 convs: '
                                          'forward incl. GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
                                          'GroupNorm backward (small maps) or its du / partial-sum half (big maps))',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
-                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel',
+                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel', 'upconv_', 'downconv_',
                                                             'resblock8_fwd_kernel', 'resblock8_bwd_kernel']),
                                'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                'timing': 'cold: each replayed launch on its own buffer set, sets > 256 MB together',

@@ -493,6 +493,13 @@ def _oracle_step(cfg, sd, fix, masks=None):
 # long before any single parameter reaches the 0.40 cap).
 GRAD_TOL_MAX, GRAD_TOL_L2, GRAD_TOL_MEDIAN = 0.40, 0.35, 0.10
 GRAD_TOL_P90, GRAD_TOL_TAIL, GRAD_TOL_TAIL_SHARE = 0.15, 0.20, 0.02
+# The distribution statistics (p90, share above GRAD_TOL_TAIL) measure a parameter's error against max(its own largest entry,
+# GRAD_FLOOR x the step's largest gradient entry).  Measured (a_dim 256, B = 32, 676 parameters): every parameter above 0.20 but the
+# one-element encoder tail bias has a largest entry <= 1.1e-3 of the step's -- encoder biases whose gradient is a cancelling sum of
+# bf16 values -- and WHICH of them cross 0.20 moves with any re-ordering of roundings upstream (3 with the 3x3 UpSample conv, 12
+# with its sub-pixel form, whose own error against fp32 is the same 2.36e-3 vs 2.34e-3 rel-L2).  The cap (GRAD_TOL_MAX), the rel-L2
+# bound and the median keep each parameter's own scale.
+GRAD_FLOOR = 1e-3
 
 
 def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD_TOL_L2, tol_median=GRAD_TOL_MEDIAN):
@@ -509,7 +516,8 @@ def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD
         if scale < 1e-4 * top:
             assert float(got.abs().max()) < 1e-3 * top, (what, k, float(got.abs().max()), top)
             continue
-        worst.append((float((got - gr).abs().max()) / scale, float((got - gr).norm() / gr.norm()), k))
+        err = float((got - gr).abs().max())
+        worst.append((err / scale, float((got - gr).norm() / gr.norm()), k, err / max(scale, GRAD_FLOOR * top)))
         n += 1
     worst.sort(reverse=True)
     assert worst[0][0] < tol_max, (what, worst[:8])
@@ -519,8 +527,9 @@ def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD
     med = errs[len(errs) // 2]
     assert med < tol_median, (what, med)
     if len(errs) >= 50:        # whole-model checks: the upper tail of the distribution, not only its cap
-        p90 = errs[int(0.9 * (len(errs) - 1))]
-        tail = sum(e > GRAD_TOL_TAIL for e in errs) / len(errs)
+        ferrs = sorted(w[3] for w in worst)
+        p90 = ferrs[int(0.9 * (len(ferrs) - 1))]
+        tail = sum(e > GRAD_TOL_TAIL for e in ferrs) / len(ferrs)
         assert p90 <= GRAD_TOL_P90, (what, p90)
         assert tail <= GRAD_TOL_TAIL_SHARE, (what, tail, worst[:8])
     return n, worst[:3]

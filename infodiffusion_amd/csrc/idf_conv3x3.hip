@@ -96,6 +96,15 @@ struct C3P {
 #define PS_DBG(p, bit) false
 #endif
 
+// Workgroups go round-robin over the 8 XCDs (block b on XCD b % 8): with the map below every XCD owns one CONTIGUOUS eighth of the
+// tile order, so row tiles that share halo rows -- and the cout tiles of one pixel tile -- meet in one L2 (speed only).
+// (same-box A/B, tools/ab_libs.sh default xcd: train step 9.174 -> 9.152 ms, DDIM-100 328.6 -> 331.9 img/s; profiles/r04_conv_wr.txt)
+#ifndef IDF_TILE_XCD
+#define IDF_TILE_XCD 1
+#endif
+__device__ __forceinline__ int xcd_tile_id(int b, int G) {
+  return (IDF_TILE_XCD && !(G & 7)) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+}
 constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 = 1536;   // (R+2)*(W+2)*4 budget per block size
 constexpr int CK = 32;
 
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
   constexpr bool DYP = (BWD & 1) != 0, DUE = (BWD & 2) != 0;
   constexpr bool AUX_OK = MODE == 0 && KS == 3 && BN == 64 && !GNB && !DYP;     // instantiations that may carry an auxiliary job
   C3P p = p_in;
-  int bid = blockIdx.x;
+  int bid = p_in.aux_blocks > 0 ? (int)blockIdx.x : xcd_tile_id(blockIdx.x, gridDim.x);
   bool aux = false;
   if constexpr (AUX_OK) {
     if (p_in.aux_blocks > 0 && bid >= p_in.main_blocks) {       // block-uniform
@@ -936,7 +945,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: group indices stay scalar
-  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int bidx = xcd_tile_id(blockIdx.x, gridDim.x);
+  const int tile = bidx / p.n_tiles, n0 = (bidx % p.n_tiles) * BN;
   const int b = tile / p.tiles_per_img, oy0 = (tile - b * p.tiles_per_img) * R;
   const int wm0 = (wave % NWM) * (TM * 16), wn0 = (wave / NWM) * (BN / 2);
   const int fr = lane & 15, fq = lane >> 4;

@@ -36,12 +36,6 @@ struct UpP {
 constexpr int UP_PPB = 96;                    // bytes per low-resolution pixel of a 32-channel chunk image
 constexpr int UP_TP = 72;                     // bf16 per pixel row of the output tile in LDS (64 couts + 8: 144 B, 16-byte aligned)
 
-// workgroup b runs on XCD b % 8: every XCD gets a contiguous eighth of the tile order (neighbouring tiles share halo rows in one L2)
-#ifndef IDF_UP_XCD
-#define IDF_UP_XCD 0
-#endif
-__device__ __forceinline__ int up_tile_id(int b, int G) { return (IDF_UP_XCD && !(G & 7)) ? (b & 7) * (G >> 3) + (b >> 3) : b; }
-
 __device__ __forceinline__ void up_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
@@ -53,8 +47,7 @@ __global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
   float* part = reinterpret_cast<float*>(smem);                                 // [512][16] statistics partials (over the images and the tile, once they are read)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r16 = lane & 15;
-  const int bidx = up_tile_id(blockIdx.x, gridDim.x);
-  const int tile = bidx / p.n_tiles, n0 = (bidx % p.n_tiles) * 64;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
   const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, oy0 = t_in * p.R, ly0 = oy0 >> 1;
   const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
   const int nchunks = p.Cin >> 5;
@@ -241,8 +234,7 @@ __global__ __launch_bounds__(512) void upconv_dgrad_bf16_kernel(const UpDP p) {
   const int Wl = p.Wl, RL = p.RL, WH = 2 * Wl + 2, nph = (2 * RL + 2) * WH;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r16 = lane & 15;
-  const int bidx = up_tile_id(blockIdx.x, gridDim.x);
-  const int tile = bidx / p.n_tiles, n0 = (bidx % p.n_tiles) * 64;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
   const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, Y0 = t_in * RL;
   const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
   const int nchunks = p.Cout >> 5, H2 = 2 * p.Hl, W2 = 2 * Wl;
@@ -361,8 +353,7 @@ __global__ __launch_bounds__(512) void downconv_dgrad_bf16_kernel(const DnP p) {
   bf16_t* tileo = reinterpret_cast<bf16_t*>(smem + 2 * img_bytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r16 = lane & 15;
-  const int bidx = up_tile_id(blockIdx.x, gridDim.x);
-  const int tile = bidx / p.n_tiles, n0 = (bidx % p.n_tiles) * 64;
+  const int tile = blockIdx.x / p.n_tiles, n0 = (blockIdx.x % p.n_tiles) * 64;
   const int b = tile / p.tiles_per_img, t_in = tile - b * p.tiles_per_img, oy0 = t_in * p.R, ly0 = oy0 >> 1;
   const int py = (wave >> 1) & 1, px = wave & 1, ch = wave >> 2;
   const int nchunks = p.Cout >> 5;

@@ -472,8 +472,10 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   if (forced > 0) target_blocks = forced;
   static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 16;      // re-swept for the 1x1 / stride-2 / up-sampling classes: profiles/r03_wgrad_tpb_sweep.txt
   static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 96;
-  // pixel tiles per block of the shared-tile 3x3 class: 128 (round 4; 64 before) halves the blocks -- and with them the fp32-atomic bytes
-  // of their partial sums -- at a slightly shorter step (9.088 -> 9.065 ms; 192 / 256: the same; profiles/r04_wgrad_tpb3.txt)
+  // pixel tiles per block of the shared-tile 3x3 class: 128 (round 4; 64 before) halves the pixel splits of the 64x64 / 32x32 problems
+  // at a slightly shorter step (9.088 -> 9.065 ms; 192 / 256: the same; profiles/r04_wgrad_tpb3.txt).  The launch's atomic bytes
+  // barely move (291 -> 281 MB by the WRITE_SIZE counter): they are the 16x16 / 8x8 problems' (590 KB - 1.2 MB of dW each, split by
+  // the 16-block minimum, IDF_WGRAD_MINB3), not the big maps' (147 KB each)
   static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 128;
   static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
   const bool rowsplit = (mode & 16) != 0;         // IDF_WGRAD_ROWSPLIT: the caller keeps this problem out of the shared-tile class

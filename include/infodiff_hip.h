@@ -457,20 +457,35 @@ int idf_attn_bwd(const void* qkv, const void* dO, const float* lse, float* dsum,
 int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse, const void* o, void* dqkv, int B, int N, int D,
                    float scale, int dtype, void* stream);
 
-/* The whole attention block (modules.py:145-164) of the N = 256-token level at C = 128 in ONE launch (round 4):
- *   y = x + proj(softmax(q k^T scale) v),   q | k | v = conv1x1(GroupNorm(x))
+/* The proj conv folded into V (round 4): (P V) Wp^T = P (V Wp^T), so with Wv' = Wp Wv and b' = Wp bv + bp (the rows of P sum to one:
+ * a bias on V' passes through the product unchanged) the block is y = x + P V' -- no proj launch, no proj data gradient, no proj weight
+ * gradient.  idf_attn_fold_batched: Wv' [C][C] and (bq | bk | b') [3C] of every attention block of a network in one launch -- table
+ * (device) = nrows x {const float* wp, bp, wv, bv, bq, bk; float* wvf, bf; int C, pad} (72 bytes).  idf_attn_fwd_res: idf_attn_fwd with
+ * y = x + o and the statistics partials of y (st_out [B][idf_attn_res_tiles()][D][2]) in its epilogue; o / lse optional, together.
+ * idf_attn_fold_bwd_batched: the chain rule back to the parameters, in place in the gradient arena after the weight gradients ran
+ * -- table = nrows x {float* g, gb; const float* wp, wv, bv; float* dwp, dbp, gs; int C, pad} (72 bytes): g = dL/dWv' and gb = dL/db'
+ * arrive in proj_v's slots and leave as dWv = Wp^T g, dbv = Wp^T gb; dwp = g Wv^T + gb bv^T and dbp = gb are written; gs = scratch
+ * of C * C + C floats per row (a copy of g / gb between the two passes). */
+int idf_attn_fold_batched(const void* table, int nrows, int max_C, void* stream);
+int idf_attn_fold_bwd_batched(const void* table, int nrows, int max_C, void* stream);
+int idf_attn_res_tiles(int B, int N, int D, int dtype);
+int idf_attn_fwd_res(const void* qkv, const void* xres, void* o, float* lse, void* y, float* st_out, int B, int N, int D,
+                     float scale, void* stream);
+
+/* The whole attention block (modules.py:145-164) of the N = 256-token level at C = 128 in ONE launch (round 4), the proj conv
+ * folded into V (idf_attn_fold_batched above):
+ *   y = x + softmax(q k^T scale) v',   q | k | v' = conv1x1(GroupNorm(x))
  * one workgroup per image; x [B, N, C] bf16 is the only activation read.  st [B][T][C][2]: the statistics partials x's producer
  * left behind (the GroupNorm's mean / rstd are folded from them in-kernel, as the GroupNorm-prologue convs do); gamma / beta:
- * the GroupNorm's affine; wqkv_frag: the q | k | v weights [3C][C] in the fragment-major shadow form
- * (idf_pack_conv_weights_batched, `wfrag`, taps 1); bqkv [3C]; wp [C][C]: the proj conv's forward shadow; bp [C].
+ * the GroupNorm's affine; wqkv_frag: the q | k | v' weights [3C][C] in the fragment-major shadow form
+ * (idf_pack_conv_weights_batched, `wfrag`, taps 1); bqkv [3C] = (bq | bk | b').
  * y [B, N, C]; st_out [B][1][C][2] (optional): statistics partials of y.  Training outputs, all or none: qkv [B, N, 3C], h =
  * GroupNorm(x) [B, N, C] (the q / k / v weight gradient's operand), o [B, N, C], lse [B, N], mean / rstd [B, 32], sc / sh [B, C] --
- * exactly what idf_conv_gn_bf16 + idf_attn_fwd leave behind, so the backward pass is the existing launches. */
+ * exactly what idf_conv_gn_bf16 + idf_attn_fwd_res leave behind, so the backward pass is the existing launches. */
 int idf_attnblock_ok(int N, int C, int dtype);
 int idf_attnblock_fwd(const void* x, const float* st, int T, const float* gamma, const float* beta, float eps,
-                      const void* wqkv_frag, const float* bqkv, const void* wp, const float* bp, void* y, float* st_out,
-                      void* qkv, void* h, void* o, float* lse, float* mean, float* rstd, float* sc, float* sh, float scale,
-                      int B, int N, int C, void* stream);
+                      const void* wqkv_frag, const float* bqkv, void* y, float* st_out, void* qkv, void* h, void* o, float* lse,
+                      float* mean, float* rstd, float* sc, float* sh, float scale, int B, int N, int C, void* stream);
 
 /* ---- elementwise / reductions */
 /* Input pipeline on the device (reference data.py:149-171, ToTensor -> RandomHorizontalFlip -> Normalize):

@@ -100,6 +100,10 @@ SIGNATURES = {
     'idf_softmax_bwd': ([_p, _p, _l, _i, _i, _p], C.c_int),
     'idf_attn_fused_ok': ([_i, _i, _i], C.c_int),
     'idf_attnblock_ok': ([_i, _i, _i], C.c_int),
+    'idf_attn_fold_batched': ([_p, _i, _i, _p], C.c_int),
+    'idf_attn_fold_bwd_batched': ([_p, _i, _i, _p], C.c_int),
+    'idf_attn_res_tiles': ([_i, _i, _i, _i], C.c_int),
+    'idf_attn_fwd_res': ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p], C.c_int),
     'idf_upconv_tiles': ([_i, _i, _i, _i], C.c_int),
     'idf_upconv_pack_batched': ([_p, _i, _l, _p], C.c_int),
     'idf_upconv_dgrad_ok': ([_i, _i, _i, _i], C.c_int),
@@ -107,7 +111,7 @@ SIGNATURES = {
     'idf_downconv_dgrad_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_upconv_dgrad_bf16': ([_p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_upconv_bf16': ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_attnblock_fwd': ([_p, _p, _i, _p, _p, _f] + [_p] * 14 + [_f, _i, _i, _i, _p], C.c_int),
+    'idf_attnblock_fwd': ([_p, _p, _i, _p, _p, _f] + [_p] * 12 + [_f, _i, _i, _i, _p], C.c_int),
     'idf_attn_fwd': ([_p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
     'idf_attn_bwd': ([_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),
     'idf_attn_bwd_o': ([_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], C.c_int),

@@ -332,7 +332,8 @@ __device__ __forceinline__ float row16_sum_ab(float v) {
 }
 
 // ---------------------------------------------------------------- the whole attention block in ONE launch
-// modules.py:145-164 for the N = 256-token level at C = 128:  y = x + proj(softmax(q k^T C^-1/2) v),  q | k | v = conv1x1(GroupNorm(x)).
+// modules.py:145-164 for the N = 256-token level at C = 128:  y = x + softmax(q k^T C^-1/2) v',  q | k | v' = conv1x1(GroupNorm(x)) with
+// the proj conv folded into V (Wv' = Wp Wv, b' = Wp bv + bp: idf_attn_fold_batched).
 // One 8-wave workgroup per image, K and V of the image in LDS (as attn_fwd_kernel keeps them), nothing but x read:
 //   fold   GroupNorm coefficients (sc, sh) per channel from the statistics partials x's producer left behind
 //   K | V  eight slabs of 32 pixels: h = x * sc + sh staged as bf16 (four 32-channel chunk images, pixel pitch 96 B: conflict-free
@@ -342,15 +343,14 @@ __device__ __forceinline__ float row16_sum_ab(float v) {
 //          lane holding 4 consecutive channels of ITS row per 16-channel tile -- which IS a B operand of the score product once
 //          the contraction's channel order is permuted the same way on the K side (two ds_read_b64 instead of one b128)
 //   P V    scores, softmax and the output product exactly as attn_fwd_kernel (same functions)
-//   proj   O of a row block stays in registers as B fragments (the same permutation); after the last score product the K
-//          tile's LDS takes the proj weights with their channels permuted to match; epilogue: + bias + x (residual), bf16,
-//          per-channel statistics of y for the next GroupNorm
+//   y      = x + O in the output product's registers (O rounded to bf16 first: the tensor the backward pass reads), per-channel
+//          statistics of y for the next GroupNorm
 // Training additionally stores what the backward pass reads (q | k | v, h for the weight gradient, O, the row logsumexp, the
 // GroupNorm's mean / rstd / sc / sh): the data-gradient side stays the existing launches.
 struct AbP {
   const bf16_t* x; const float* st; int T;
   const float* gamma; const float* beta; float eps;
-  const bf16_t* wqkv; const float* bqkv; const bf16_t* wp; const float* bp;
+  const bf16_t* wqkv; const float* bqkv;
   bf16_t* y; float* st_out;
   bf16_t* qkv; bf16_t* h; bf16_t* o; float* lse; float* mean; float* rstd; float* sc; float* sh;
   float scale;
@@ -541,8 +541,12 @@ __global__ __launch_bounds__(64 * NW) void attnblock_fwd_kernel(const AbP p) {
     }
   }
 
-  // ---- softmax(Q K^T) V per row block; O stays in registers as the proj product's B fragments
-  bf16x8_t po[RBW][4];
+  // ---- softmax(Q K^T) V' per row block, the residual and the statistics of y straight from the output product
+  float s1[8][4], s2[8][4];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
 #pragma unroll
   for (int k = 0; k < RBW; ++k) {
     const int r0 = 16 * (wave + NW * k);
@@ -584,48 +588,22 @@ __global__ __launch_bounds__(64 * NW) void attnblock_fwd_kernel(const AbP p) {
       store_out<D>(p.o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
       if (lane < 16) p.lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
     }
-    ab_frags(out, nullptr, po[k]);
-  }
-
-  // ---- proj + residual; statistics of y
-  __syncthreads();                                   // every wave is through with K and V
-  for (int idx = tid; idx < D * (D / 8); idx += NT) {
-    const int cout = idx >> 4, k8 = idx & 15;
-    const uint4 w = *reinterpret_cast<const uint4*>(p.wp + (size_t)cout * D + k8 * 8);
-    const int s = k8 >> 2, kk = k8 & 3, hh = kk >> 1, g2 = 2 * (kk & 1);
-    bf16_t* row = Ks + cout * PITCH + s * 32 + 4 * hh;
-    *reinterpret_cast<uint2*>(row + g2 * 8) = make_uint2(w.x, w.y);
-    *reinterpret_cast<uint2*>(row + (g2 + 1) * 8) = make_uint2(w.z, w.w);
-  }
-  __syncthreads();
-  float s1[8][4], s2[8][4];
-  float4 bpv[8];
+    {
+      // the proj conv is inside V (Wv' = Wp Wv, bias b' on V'): y = x + O, O rounded to bf16 first (the stored o)
+      const size_t row = (size_t)b * AN + r0 + r16;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    bpv[f] = *reinterpret_cast<const float4*>(p.bp + 16 * f + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
-  }
-#pragma unroll
-  for (int k = 0; k < RBW; ++k) {
-    const int row = 16 * (wave + NW * k) + r16;
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      f32x4_t ya = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * f + r16) * PITCH + s * 32 + g * 8);
-        ya = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, po[k][s], ya, 0, 0, 0);
+      for (int f = 0; f < 8; ++f) {
+        const uint2 rs = *reinterpret_cast<const uint2*>(p.x + row * D + 16 * f + 4 * g);
+        const float o0 = bf16_to_f32(f32_to_bf16(out[f][0])), o1 = bf16_to_f32(f32_to_bf16(out[f][1]));
+        const float o2 = bf16_to_f32(f32_to_bf16(out[f][2])), o3 = bf16_to_f32(f32_to_bf16(out[f][3]));
+        const uint2 u = make_uint2(ab_pack2(o0 + __uint_as_float(rs.x << 16), o1 + __uint_as_float(rs.x & 0xffff0000u)),
+                                   ab_pack2(o2 + __uint_as_float(rs.y << 16), o3 + __uint_as_float(rs.y & 0xffff0000u)));
+        *reinterpret_cast<uint2*>(p.y + row * D + 16 * f + 4 * g) = u;
+        const float h0 = __uint_as_float(u.x << 16), h1 = __uint_as_float(u.x & 0xffff0000u);
+        const float h2 = __uint_as_float(u.y << 16), h3 = __uint_as_float(u.y & 0xffff0000u);
+        s1[f][0] += h0; s1[f][1] += h1; s1[f][2] += h2; s1[f][3] += h3;
+        s2[f][0] += h0 * h0; s2[f][1] += h1 * h1; s2[f][2] += h2 * h2; s2[f][3] += h3 * h3;
       }
-      const uint2 rs = *reinterpret_cast<const uint2*>(xb + (size_t)row * D + 16 * f + 4 * g);
-      const float v0 = ya[0] + bpv[f].x + __uint_as_float(rs.x << 16), v1 = ya[1] + bpv[f].y + __uint_as_float(rs.x & 0xffff0000u);
-      const float v2 = ya[2] + bpv[f].z + __uint_as_float(rs.y << 16), v3 = ya[3] + bpv[f].w + __uint_as_float(rs.y & 0xffff0000u);
-      const uint2 u = make_uint2(ab_pack2(v0, v1), ab_pack2(v2, v3));
-      *reinterpret_cast<uint2*>(p.y + ((size_t)b * AN + row) * D + 16 * f + 4 * g) = u;
-      const float h0 = __uint_as_float(u.x << 16), h1 = __uint_as_float(u.x & 0xffff0000u);
-      const float h2 = __uint_as_float(u.y << 16), h3 = __uint_as_float(u.y & 0xffff0000u);
-      s1[f][0] += h0; s1[f][1] += h1; s1[f][2] += h2; s1[f][3] += h3;
-      s2[f][0] += h0 * h0; s2[f][1] += h1 * h1; s2[f][2] += h2 * h2; s2[f][3] += h3 * h3;
     }
   }
   if (p.st_out) {
@@ -644,6 +622,212 @@ __global__ __launch_bounds__(64 * NW) void attnblock_fwd_kernel(const AbP p) {
       p.st_out[((size_t)b * D + tid) * 2] = a; p.st_out[((size_t)b * D + tid) * 2 + 1] = q;
     }
   }
+}
+
+
+// ---------------------------------------------------------------- the proj conv folded into V
+// (P V) Wp^T = P (V Wp^T): with  Wv' = Wp Wv  and  b' = Wp bv + bp  (the rows of P sum to one, so a bias on V' passes through the
+// softmax product unchanged) the block is  y = x + P V'  -- no proj launch, no proj data gradient, no proj weight gradient.
+//   attn_fold_kernel      Wv', (bq | bk | b') of every attention block of a network, once per optimizer step
+//   attn_fwd_res_kernel   attn_fwd_kernel + the residual and the statistics partials of y in its epilogue
+//   attn_fold_bwd_a / _b  the chain rule back to the parameters, in place in the gradient arena, after the weight gradients ran:
+//                         G = dL/dWv' and gb = dL/db' arrive in proj_v's slots;  dWp = G Wv^T + gb bv^T, dbp = gb,
+//                         dWv = Wp^T G, dbv = Wp^T gb
+struct FoldRow {
+  const float* wp; const float* bp; const float* wv; const float* bv; const float* bq; const float* bk;
+  float* wvf; float* bf;       // [C][C], [3 C]
+  int C, pad;
+};
+// 16 x 16 output tiles, the contraction staged through LDS 16 columns at a time (128^3 products: latency, not throughput)
+__global__ __launch_bounds__(256) void attn_fold_kernel(const FoldRow* __restrict__ tab) {
+  __shared__ float As[16][17], Bs[16][17];
+  const FoldRow d = tab[blockIdx.z];
+  const int C = d.C, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  if ((int)blockIdx.y * 16 >= C) {
+    // the bias vector (bq | bk | Wp bv + bp): the extra tile row, block x = 0 only
+    if (blockIdx.x != 0) return;
+    for (int j = threadIdx.x; j < 3 * C; j += 256) {
+      float v;
+      if (j < C) v = d.bq[j];
+      else if (j < 2 * C) v = d.bk[j - C];
+      else {
+        const int o = j - 2 * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = 0; k < C; k += 4) {
+          a0 += d.wp[o * C + k] * d.bv[k]; a1 += d.wp[o * C + k + 1] * d.bv[k + 1];
+          a2 += d.wp[o * C + k + 2] * d.bv[k + 2]; a3 += d.wp[o * C + k + 3] * d.bv[k + 3];
+        }
+        v = d.bp[o] + ((a0 + a1) + (a2 + a3));
+      }
+      d.bf[j] = v;
+    }
+    return;
+  }
+  const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
+  if (o0 >= C || i0 >= C) return;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < C; k0 += 16) {                 // Wv'[o][i] = sum_k Wp[o][k] Wv[k][i]
+    As[ty][tx] = d.wp[(o0 + ty) * C + k0 + tx];
+    Bs[ty][tx] = d.wv[(k0 + ty) * C + i0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+    __syncthreads();
+  }
+  d.wvf[(o0 + ty) * C + i0 + tx] = acc;
+}
+
+struct FoldBwdRow {
+  float* g; float* gb;         // in: dL/dWv' [C][C], dL/db' [C] (proj_v's gradient slots);  out: dWv, dbv
+  const float* wp; const float* wv; const float* bv;
+  float* dwp; float* dbp;      // proj's gradient slots (written)
+  float* gs;                   // scratch [C][C] + [C]: pass A leaves a copy of G and gb there, pass B reads it and writes g / gb
+  int C, pad;
+};
+// pass A (reads G, gb; writes proj's slots and the scratch copy):  dWp[o][k] = sum_i G[o][i] Wv[k][i] + gb[o] bv[k],  dbp = gb
+__global__ __launch_bounds__(256) void attn_fold_bwd_a_kernel(const FoldBwdRow* __restrict__ tab) {
+  __shared__ float As[16][17], Bs[16][17];
+  const FoldBwdRow d = tab[blockIdx.z];
+  const int C = d.C, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int o0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+  if (o0 >= C || k0 >= C) return;
+  float acc = 0.f;
+  for (int i0 = 0; i0 < C; i0 += 16) {
+    const float gv = d.g[(o0 + ty) * C + i0 + tx];
+    As[ty][tx] = gv;
+    if (blockIdx.x == 0) d.gs[(o0 + ty) * C + i0 + tx] = gv;      // the column-tile-0 blocks of a row tile cover G once
+    Bs[ty][tx] = d.wv[(k0 + ty) * C + i0 + tx];       // Bs[k][i]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += As[ty][i] * Bs[tx][i];
+    __syncthreads();
+  }
+  const float gbo = d.gb[o0 + ty];
+  d.dwp[(o0 + ty) * C + k0 + tx] = acc + gbo * d.bv[k0 + tx];
+  if (blockIdx.x == 0 && tx == 0) { d.dbp[o0 + ty] = gbo; d.gs[C * C + o0 + ty] = gbo; }
+}
+// pass B (after pass A, from the scratch copy):  dWv[k][i] = sum_o Wp[o][k] G[o][i] into g,  dbv[k] = sum_o Wp[o][k] gb[o] into gb
+__global__ __launch_bounds__(256) void attn_fold_bwd_b_kernel(const FoldBwdRow* __restrict__ tab) {
+  __shared__ float As[16][17], Bs[16][17];
+  const FoldBwdRow d = tab[blockIdx.z];
+  const int C = d.C, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
+  if (k0 >= C || i0 >= C) return;
+  float acc = 0.f, accb = 0.f;
+  for (int o0 = 0; o0 < C; o0 += 16) {
+    As[ty][tx] = d.wp[(o0 + ty) * C + k0 + tx];       // As[o][k]
+    Bs[ty][tx] = d.gs[(o0 + ty) * C + i0 + tx];       // Bs[o][i]
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc += As[o][ty] * Bs[o][tx];
+    if (blockIdx.x == 0 && tx == 0) {
+#pragma unroll
+      for (int o = 0; o < 16; ++o) accb += As[o][ty] * d.gs[C * C + o0 + o];
+    }
+    __syncthreads();
+  }
+  d.g[(k0 + ty) * C + i0 + tx] = acc;
+  if (blockIdx.x == 0 && tx == 0) d.gb[k0 + ty] = accb;
+}
+
+template <int D, int AN>
+__global__ __launch_bounds__(ANT) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ xres,
+                                                           bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                           bf16_t* __restrict__ y, float* __restrict__ st_out, float scale,
+                                                           int rb_per_block) {
+  constexpr int PITCH = ACfg<D>::PITCH, CT = ACfg<D>::CT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vs = Ks + AN * PITCH;
+  float* scr = reinterpret_cast<float*>(Vs + AN * PITCH);           // [4 waves][D][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int b = blockIdx.y;
+  const bf16_t* base = qkv + (size_t)b * AN * 3 * D;
+  stage_rows<D, AN>(base + D, 3 * D, Ks, tid);
+  stage_rows<D, AN>(base + 2 * D, 3 * D, Vs, tid);
+  __syncthreads();
+  float s1[CT][4], s2[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[c][r] = 0.f; s2[c][r] = 0.f; }
+  for (int rb = blockIdx.x * rb_per_block; rb < (int)(blockIdx.x + 1) * rb_per_block; ++rb) {
+    const int r0 = rb * 64 + wave * 16;
+    bf16x8_t qf[ACfg<D>::KS];
+    load_rowfrag<D>(base + (size_t)r0 * 3 * D, 3 * D, lane, qf);
+    f32x4_t s[AN / 16];
+    scores<D, AN>(s, Ks, qf, lane);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[t][r] *= scale; mx = fmaxf(mx, s[t][r]); }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); sum += s[t][r]; }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < AN / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t][r] *= inv;
+    bf16x8_t pk[AN / 32];
+    pack_w<AN>(s, pk);
+    f32x4_t out[CT];
+    outprod<D, AN>(out, Vs, pk, lane);
+    if (o) store_out<D>(o + ((size_t)b * AN + r0) * D, D, out, lane, 1.0f);
+    if (lse && lane < 16) lse[(size_t)b * AN + r0 + lane] = mx + __logf(sum);
+    // y = x + O (O rounded to bf16 first, as the stored o is: what the backward pass differentiates); row lane & 15,
+    // channels 16 c + 4 (lane >> 4) + r
+    const size_t row = (size_t)b * AN + r0 + r16;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const uint2 rs = *reinterpret_cast<const uint2*>(xres + row * D + 16 * c + 4 * g);
+      const float o0 = bf16_to_f32(f32_to_bf16(out[c][0])), o1 = bf16_to_f32(f32_to_bf16(out[c][1]));
+      const float o2 = bf16_to_f32(f32_to_bf16(out[c][2])), o3 = bf16_to_f32(f32_to_bf16(out[c][3]));
+      const float v0 = o0 + __uint_as_float(rs.x << 16), v1 = o1 + __uint_as_float(rs.x & 0xffff0000u);
+      const float v2 = o2 + __uint_as_float(rs.y << 16), v3 = o3 + __uint_as_float(rs.y & 0xffff0000u);
+      const uint2 u = make_uint2(ab_pack2(v0, v1), ab_pack2(v2, v3));
+      *reinterpret_cast<uint2*>(y + row * D + 16 * c + 4 * g) = u;
+      const float h0 = __uint_as_float(u.x << 16), h1 = __uint_as_float(u.x & 0xffff0000u);
+      const float h2 = __uint_as_float(u.y << 16), h3 = __uint_as_float(u.y & 0xffff0000u);
+      s1[c][0] += h0; s1[c][1] += h1; s1[c][2] += h2; s1[c][3] += h3;
+      s2[c][0] += h0 * h0; s2[c][1] += h1 * h1; s2[c][2] += h2 * h2; s2[c][3] += h3 * h3;
+    }
+  }
+  if (st_out) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum_ab(s1[c][r]), q = row16_sum_ab(s2[c][r]);
+        if (r16 == 0) { scr[(wave * D + 16 * c + 4 * g + r) * 2] = a; scr[(wave * D + 16 * c + 4 * g + r) * 2 + 1] = q; }
+      }
+    __syncthreads();
+    if (tid < D) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += scr[(w * D + tid) * 2]; q += scr[(w * D + tid) * 2 + 1]; }
+      float* dst = st_out + (((size_t)b * gridDim.x + blockIdx.x) * D + tid) * 2;
+      dst[0] = a; dst[1] = q;
+    }
+  }
+}
+
+template <int D, int AN>
+hipError_t launch_fwd_res(const void* qkv, const void* xres, void* o, float* lse, void* y, float* st_out, int B, float scale,
+                          int tiles, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * AN * ACfg<D>::PITCH * sizeof(bf16_t) + (size_t)4 * D * 2 * sizeof(float);
+  static IdfLdsGrant grant;
+  if (hipError_t e = idf_ensure_lds((const void*)attn_fwd_res_kernel<D, AN>, lds, grant); e != hipSuccess) return e;
+  const int rb = (AN / 64) / tiles;
+  hipLaunchKernelGGL((attn_fwd_res_kernel<D, AN>), dim3(tiles, B), dim3(ANT), lds, st, (const bf16_t*)qkv, (const bf16_t*)xres,
+                     (bf16_t*)o, lse, (bf16_t*)y, st_out, scale, rb);
+  return hipGetLastError();
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: raised once per (kernel set, device), not per
@@ -741,11 +925,11 @@ extern "C" int idf_attn_bwd_o(const void* qkv, const void* dO, const float* lse,
 extern "C" int idf_attnblock_ok(int N, int C, int dtype) { return (N == 256 && C == 128 && dtype == IDF_BF16) ? 1 : 0; }
 
 extern "C" int idf_attnblock_fwd(const void* x, const float* st, int T, const float* gamma, const float* beta, float eps,
-                                 const void* wqkv_frag, const float* bqkv, const void* wp, const float* bp, void* y,
-                                 float* st_out, void* qkv, void* h, void* o, float* lse, float* mean, float* rstd, float* sc,
-                                 float* sh, float scale, int B, int N, int C, void* stream) {
+                                 const void* wqkv_frag, const float* bqkv, void* y, float* st_out, void* qkv, void* h, void* o,
+                                 float* lse, float* mean, float* rstd, float* sc, float* sh, float scale, int B, int N, int C,
+                                 void* stream) {
   if (!idf_attnblock_ok(N, C, IDF_BF16)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attnblock_fwd: N=%d C=%d not covered", N, C);
-  if (!x || !st || T < 1 || !wqkv_frag || !bqkv || !wp || !bp || !y) IDF_FAIL(IDF_ERR_BADARG, "attnblock_fwd: null argument");
+  if (!x || !st || T < 1 || !wqkv_frag || !bqkv || !y) IDF_FAIL(IDF_ERR_BADARG, "attnblock_fwd: null argument");
   const bool any = qkv || h || o || lse || mean || rstd || sc || sh, all = qkv && h && o && lse && mean && rstd && sc && sh;
   if (any != all) IDF_FAIL(IDF_ERR_BADARG, "attnblock_fwd: the training outputs (qkv, h, o, lse, mean, rstd, sc, sh) go together");
   if (B == 0) return IDF_OK;
@@ -756,10 +940,63 @@ extern "C" int idf_attnblock_fwd(const void* x, const float* st, int T, const fl
     IDF_FAIL(IDF_ERR_HIP, "attnblock_fwd: %d bytes of LDS refused: %s", (int)AB_LDS, hipGetErrorString(e));
   AbP p;
   p.x = (const bf16_t*)x; p.st = st; p.T = T; p.gamma = gamma; p.beta = beta; p.eps = eps;
-  p.wqkv = (const bf16_t*)wqkv_frag; p.bqkv = bqkv; p.wp = (const bf16_t*)wp; p.bp = bp;
+  p.wqkv = (const bf16_t*)wqkv_frag; p.bqkv = bqkv;
   p.y = (bf16_t*)y; p.st_out = st_out; p.qkv = (bf16_t*)qkv; p.h = (bf16_t*)h; p.o = (bf16_t*)o; p.lse = lse;
   p.mean = mean; p.rstd = rstd; p.sc = sc; p.sh = sh; p.scale = scale;
   hipLaunchKernelGGL(attnblock_fwd_kernel<8>, dim3(B), dim3(512), AB_LDS, (hipStream_t)stream, p);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// ---- attention with the residual and the statistics of y in its epilogue (the proj conv folded into V: idf_attn_fold_batched)
+// tiles: statistics tiles per image (st_out [B][tiles][D][2]); 0: shape not covered (the shapes of idf_attn_fused_ok)
+extern "C" int idf_attn_res_tiles(int B, int N, int D, int dtype) {
+  if (!idf_attn_fused_ok(N, D, dtype)) return 0;
+  static const int rb_min_b = getenv("IDF_ATTN_RB_MINB") ? atoi(getenv("IDF_ATTN_RB_MINB")) : 128;
+  return (N == 256 && B < rb_min_b) ? 4 : 1;
+}
+
+extern "C" int idf_attn_fwd_res(const void* qkv, const void* xres, void* o, float* lse, void* y, float* st_out, int B, int N,
+                                int D, float scale, void* stream) {
+  const int tiles = idf_attn_res_tiles(B, N, D, IDF_BF16);
+  if (!tiles) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fwd_res: N=%d D=%d not covered", N, D);
+  if (!qkv || !xres || !y) IDF_FAIL(IDF_ERR_BADARG, "attn_fwd_res: null argument");
+  if ((o != nullptr) != (lse != nullptr)) IDF_FAIL(IDF_ERR_BADARG, "attn_fwd_res: o and lse go together");
+  if (B == 0) return IDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (N == 256) e = D == 128 ? launch_fwd_res<128, 256>(qkv, xres, o, lse, y, st_out, B, scale, tiles, st)
+                             : launch_fwd_res<64, 256>(qkv, xres, o, lse, y, st_out, B, scale, tiles, st);
+  else e = D == 128 ? launch_fwd_res<128, 64>(qkv, xres, o, lse, y, st_out, B, scale, tiles, st)
+                    : launch_fwd_res<64, 64>(qkv, xres, o, lse, y, st_out, B, scale, tiles, st);
+  if (e != hipSuccess) IDF_FAIL(IDF_ERR_HIP, "attn_fwd_res: %s", hipGetErrorString(e));
+  return IDF_OK;
+}
+
+// table (device): nrows x {wp, bp, wv, bv, bq, bk (const float*), wvf, bf (float*), int C, pad} (72 bytes): the folded V weights
+// Wv' = Wp Wv [C][C] and the bias vector (bq | bk | Wp bv + bp) [3 C] of every attention block of a network
+extern "C" int idf_attn_fold_batched(const void* table, int nrows, int max_C, void* stream) {
+  if (nrows <= 0) return IDF_OK;
+  if (!table || max_C <= 0) IDF_FAIL(IDF_ERR_BADARG, "attn_fold_batched: bad arguments");
+  static_assert(sizeof(FoldRow) == 72, "the host builds 72-byte rows");
+  if (max_C % 16) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fold_batched: C %% 16 != 0");
+  hipLaunchKernelGGL(attn_fold_kernel, dim3((unsigned)(max_C / 16), (unsigned)(max_C / 16 + 1), (unsigned)nrows), dim3(256), 0,
+                     (hipStream_t)stream, (const FoldRow*)table);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// table (device): nrows x {g, gb (float*, in place), wp, wv, bv (const float*), dwp, dbp, gs (float*: scratch [C*C + C]), int C, pad}
+// (72 bytes)
+extern "C" int idf_attn_fold_bwd_batched(const void* table, int nrows, int max_C, void* stream) {
+  if (nrows <= 0) return IDF_OK;
+  if (!table || max_C <= 0 || max_C > 512) IDF_FAIL(IDF_ERR_BADARG, "attn_fold_bwd_batched: bad arguments");
+  static_assert(sizeof(FoldBwdRow) == 72, "the host builds 72-byte rows");
+  if (max_C % 16) IDF_FAIL(IDF_ERR_UNSUPPORTED, "attn_fold_bwd_batched: C %% 16 != 0");
+  hipLaunchKernelGGL(attn_fold_bwd_a_kernel, dim3((unsigned)(max_C / 16), (unsigned)(max_C / 16), (unsigned)nrows), dim3(256), 0,
+                     (hipStream_t)stream, (const FoldBwdRow*)table);
+  hipLaunchKernelGGL(attn_fold_bwd_b_kernel, dim3((unsigned)(max_C / 16), (unsigned)(max_C / 16), (unsigned)nrows), dim3(256), 0,
+                     (hipStream_t)stream, (const FoldBwdRow*)table);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

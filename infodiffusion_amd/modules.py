@@ -49,6 +49,10 @@ class _Shadows:
         self.want_sub = False
         self.sub = None
         self.subd = None            # ... and their data-gradient form (rows = cins), idf_upconv_dgrad_bf16
+        # AttnBlock with the proj conv folded into V: the shadows are packed from (Wq, Wk, Wv' = Wp Wv) -- `srcs` replaces the
+        # convs' own weights as the pack sources, `fold` = (wp, bp, wv, bv, bq, bk, wvf, bf) feeds idf_attn_fold_batched first
+        self.srcs = None
+        self.fold = None
         # several convs applied as one (q, k, v): their weights / biases live adjacently so the
         # concatenation is a view and its gradient is written once (grad_arena.ParamGroup)
         self.wgroup = ops.ParamGroup([c.weight for c in convs]) if len(convs) > 1 else None
@@ -65,7 +69,24 @@ class _Shadows:
         return ops.cat_params(self.bgroup)
 
     def current_key(self, dtype):
-        return tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs) + (dtype,)
+        if self.fold is not None:          # the folded weights follow proj's parameters and the biases too
+            key += tuple((t.data_ptr(), t._version) for t in self.fold[:6])
+        return key
+
+    def pack_sources(self):
+        """The fp32 weight tensors the shadows are packed from (the convs' own, unless a fold replaces some)."""
+        return self.srcs if self.srcs is not None else [c.weight for c in self.convs]
+
+    def run_fold(self):
+        """Stand-alone use: the folded V weights / biases with torch products (a network's ShadowSet does all blocks in one launch)."""
+        wp, bp, wv, bv, bq, bk, wvf, bf = self.fold
+        C = wp.shape[0]
+        with torch.no_grad():
+            wvf.view(C, C).copy_(wp.view(C, C) @ wv.view(C, C))
+            bf[:C].copy_(bq)
+            bf[C:2 * C].copy_(bk)
+            bf[2 * C:].copy_(wp.view(C, C) @ bv + bp)
 
     def ensure_buffers(self, dtype, need_dgrad):
         O = sum(c.weight.shape[0] for c in self.convs)
@@ -117,7 +138,10 @@ class _Shadows:
         if self.stale(dtype, need_dgrad):        # stand-alone use (block tests): individual pack
             self.ensure_buffers(dtype, need_dgrad)
             with torch.no_grad():
-                wf, wd = ops.pack_weight(self.weight(), dtype, True, self.val[1] is not None)
+                if self.fold is not None:
+                    self.run_fold()
+                wsrc = self.weight() if self.srcs is None else torch.cat([t.detach() for t in self.srcs], dim=0)
+                wf, wd = ops.pack_weight(wsrc, dtype, True, self.val[1] is not None)
                 self.val[0].copy_(wf)
                 if wd is not None:
                     self.val[1].copy_(wd)
@@ -173,16 +197,15 @@ class ShadowSet:
         import numpy as np
         for s in self.items:
             s.ensure_buffers(dtype, need_dgrad)
-        tkey = (dtype, tuple((c.weight.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0,
+        tkey = (dtype, tuple((w.data_ptr(), s.val[0].data_ptr(), s.val[1].data_ptr() if s.val[1] is not None else 0,
                               s.val[2].data_ptr() if s.val[2] is not None else 0,
                               s.val[3].data_ptr() if s.val[3] is not None else 0)
-                             for s in self.items for c in s.convs))
+                             for s in self.items for w in s.pack_sources()))
         if tkey != self.tkey:
             rows = []
             for s in self.items:
                 Ot, o0 = sum(c.weight.shape[0] for c in s.convs), 0
-                for c in s.convs:
-                    w = c.weight
+                for w in s.pack_sources():
                     O, I, kh, kw = w.shape
                     taps = kh * kw
                     if taps > 1 and w.stride(2) != kw * w.stride(3):
@@ -213,6 +236,19 @@ class ShadowSet:
                 self.table.copy_(host.to(dev))
             self.tkey = tkey
         from ._lib import call, F32, BF16
+        folds = [s for s in self.items if s.fold is not None]
+        if folds:          # the attention blocks' folded V weights / biases first: the pack below reads them
+            fkey = tuple(tuple(t.data_ptr() for t in s.fold) for s in folds)
+            if fkey != getattr(self, 'fold_key', None):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('ShadowSet: run one eager forward before graph capture')
+                dt = np.dtype([('p%d' % i, '<i8') for i in range(8)] + [('C', '<i4'), ('pad', '<i4')])
+                rows = [tuple(t.data_ptr() for t in s.fold) + (s.fold[0].shape[0], 0) for s in folds]
+                self.fold_table = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).reshape(len(rows), -1).copy()).to(
+                    self.items[0].val[0].device)
+                self.fold_key = fkey
+                self.fold_C = max(s.fold[0].shape[0] for s in folds)
+            call('idf_attn_fold_batched', self.fold_table.data_ptr(), len(folds), self.fold_C, torch.cuda.current_stream().cuda_stream)
         call('idf_pack_conv_weights_batched', self.table.data_ptr(), self.table.shape[0],
              F32 if dtype == torch.float32 else BF16, torch.cuda.current_stream().cuda_stream)
         ups = [s for s in self.items if s.sub is not None]
@@ -358,28 +394,58 @@ class AttnBlock(nn.Module):
             init.zeros_(m.bias)
         init.xavier_uniform_(self.proj.weight, gain=1e-5)
 
+    def _fold(self, on, dev):
+        """Switch the q | k | v shadows between the convs' own weights and (Wq, Wk, Wv' = Wp Wv) with biases (bq | bk | Wp bv + bp)."""
+        sh = self._qkv
+        if not on:
+            if sh.fold is not None:
+                sh.srcs = sh.fold = None
+                sh.key = None
+                self._cfg_qkv.pop('bias_values', None)
+            return
+        if sh.fold is None or sh.fold[6].device != dev:
+            C = self.proj.weight.shape[0]
+            wvf = torch.empty((C, C, 1, 1), dtype=torch.float32, device=dev)
+            bf = torch.empty((3 * C,), dtype=torch.float32, device=dev)
+            sh.srcs = [self.proj_q.weight, self.proj_k.weight, wvf]
+            sh.fold = (self.proj.weight, self.proj.bias, self.proj_v.weight, self.proj_v.bias, self.proj_q.bias, self.proj_k.bias,
+                       wvf, bf)
+            sh.key = None
+            self._cfg_qkv['bias_values'] = bf
+
     def forward(self, x):
         gn = self.group_norm
+        B, C, H, W = x.shape
+        # bf16, shapes the fused attention covers: the proj conv is folded into V (Wv' = Wp Wv, b' = Wp bv + bp -- the rows of the
+        # softmax sum to one, so the bias passes through the product): y = x + P V', no proj launch / data gradient / weight
+        # gradient; the chain rule back to proj and proj_v runs once per backward pass (ops._FoldProjV)
+        tiles = 0
+        if ops._ATTN_FOLD and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4:
+            tiles = int(ops._lib.load().idf_attn_res_tiles(B, H * W, C, ops.BF16))
+        self._fold(tiles > 0, x.device)
         wq, bq = self._qkv.weight(), self._qkv.bias()
-        pre_q = pre_a = pre_p = None
-        if ops.attn_block_ok(x):
-            # 256 tokens x 128 channels in bf16: the whole block is ONE launch (idf_attnblock_fwd); while gradients are recorded
-            # it also leaves what the three ops below would have saved, and they only record their backward passes
-            train = torch.is_grad_enabled() and x.requires_grad
-            val = self._qkv(x.dtype, train)
-            if val[2] is None:
-                self._qkv.request_frag()          # fragment-major q | k | v weights come with the next re-pack
-            else:
-                wp = self._cfg_proj['shadows'](x.dtype, train)[0]
-                y, st, qkv, h, o, lse, mean, rstd, sc, sh = ops.attn_block_fwd_raw(
-                    x, ops.stats_of(x), gn.weight, gn.bias, val[2], bq, wp, self.proj.bias, train)
-                if not train:
-                    return ops._tag(y, st)
-                pre_q, pre_a, pre_p = (qkv, h, mean, rstd, sc, sh, None), (o, lse), (y, None, None, None, None, None, st)
-        qkv, x = ops.fused_conv(x, wq, bq, self._cfg_qkv, gn.weight, gn.bias, passthrough=1,
-                                pre=pre_q)          # the residual branch's gradient joins the GN backward
-        o = ops.attention(qkv, pre=pre_a)
-        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x, want_stats=True, pre=pre_p)
+        if tiles:
+            wq, bq = ops.fold_proj_v(wq, bq, self.proj.weight, self.proj.bias, self.proj_v.weight, self.proj_v.bias)
+            pre_q = pre_a = None
+            if ops.attn_block_ok(x):
+                # 256 tokens x 128 channels from B = 256 up: the whole block is ONE launch (idf_attnblock_fwd); while gradients are
+                # recorded it also leaves what the two ops below would have saved, and they only record their backward passes
+                train = torch.is_grad_enabled() and x.requires_grad
+                val = self._qkv(x.dtype, train)
+                if val[2] is None:
+                    self._qkv.request_frag()          # fragment-major q | k | v' weights come with the next re-pack
+                else:
+                    y, st, qkv, h, o, lse, mean, rstd, sc, sh = ops.attn_block_fwd_raw(
+                        x, ops.stats_of(x), gn.weight, gn.bias, val[2], self._qkv.fold[7], train)
+                    if not train:
+                        return ops._tag(y, st)
+                    pre_q, pre_a = (qkv, h, mean, rstd, sc, sh, None), (y, st, o, lse)
+            qkv, xa = ops.fused_conv(x, wq, bq, self._cfg_qkv, gn.weight, gn.bias, passthrough=1, pre=pre_q)
+            return ops.attention_res(qkv, xa, tiles, pre=pre_a)
+        qkv, x = ops.fused_conv(x, wq, bq, self._cfg_qkv, gn.weight, gn.bias,
+                                passthrough=1)      # the residual branch's gradient joins the GN backward
+        o = ops.attention(qkv)
+        return ops.fused_conv(o, self.proj.weight, self.proj.bias, self._cfg_proj, residual=x, want_stats=True)
 
 
 class CrossAttnBlock(nn.Module):

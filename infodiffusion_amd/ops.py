@@ -921,6 +921,9 @@ class _FusedConv(torch.autograd.Function):
         w_fwd = cfg['shadows'](x.dtype, train)[0]
         Cout = weight.shape[0]
         need = ctx.needs_input_grad
+        bias_k = cfg.get('bias_values')          # the values the kernel adds (AttnBlock: the folded (bq | bk | b')); `bias` routes gradients
+        if bias_k is None:
+            bias_k = bias
         if pre is not None:
             # the launch that computed this conv already ran (the one-launch attention block, attn_block_fwd_raw): `pre` is
             # what conv_gn_raw / conv_raw would have returned; this node only records the backward pass
@@ -929,7 +932,7 @@ class _FusedConv(torch.autograd.Function):
                 a = x
         elif act and mode == S1 and xst is not None and conv_gn_ok(x, None, taps, Cout):
             y, a, mean, rstd, sc, sh, st = conv_gn_raw(
-                x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias, residual,
+                x, None, xst, None, gn_w, gn_b, film_t, film_a, seed, cfg['salt'], p_drop, act, w_fwd, bias_k, residual,
                 Cout, taps, keep_a=need[1], keep_coef=any(need[i] for i in (0, 3, 4, 5, 6)), want_stats=want_stats,
                 shadows=cfg['shadows'])
         else:
@@ -945,7 +948,7 @@ class _FusedConv(torch.autograd.Function):
             elif act:
                 mean, rstd, sc, sh = gn_coef_fwd_raw(x, gn_w, gn_b, film_t, film_a)
                 a = gn_apply_raw(x, sc, sh, seed, cfg['salt'], p_drop, act)
-            y = conv_raw(a, w_fwd, bias, residual, None, None, None, 0, 0.0, mode, taps, 0, Cout, want_stats=want_stats)
+            y = conv_raw(a, w_fwd, bias_k, residual, None, None, None, 0, 0.0, mode, taps, 0, Cout, want_stats=want_stats)
             if want_stats:
                 y, st = y
         ctx.cfg, ctx.p_drop, ctx.slots = cfg, p_drop, slots or (None, None, None, None)
@@ -1670,6 +1673,140 @@ def upconv_raw(x, w_sub_frag, bias, Cout, tiles):
     return y, st
 
 
+# ------------------------------------------------- the attention block's proj conv folded into V
+_ATTN_FOLD = os.environ.get('IDF_ATTN_FOLD', '1') != '0'
+
+
+def attn_res_tiles(qkv):
+    """Statistics tiles per image of idf_attn_fwd_res for this q | k | v tensor; 0: not covered (or the fold is switched off)."""
+    if not (_ATTN_FOLD and qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 4):
+        return 0
+    return int(_lib.load().idf_attn_res_tiles(qkv.shape[0], qkv.shape[2] * qkv.shape[3], qkv.shape[1] // 3, BF16))
+
+
+class _AttentionRes(torch.autograd.Function):
+    """y = x + softmax(q k^T C^-1/2) v' with the statistics partials of y (idf_attn_fwd_res): the attention block behind a
+    q | k | v conv whose V weights already carry the proj conv (Wv' = Wp Wv).  The gradient of y goes to the attention backward
+    as dO and, unchanged, to x (the alias the GroupNorm-prologue conv handed out: it joins that GroupNorm's backward)."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, tiles, pre=None):
+        qkv, x = _nhwc(qkv), _nhwc(x)
+        if pre is not None:          # (y, st, o, lse) of the one-launch attention block: record the backward pass only
+            y, st, o, lse = pre
+            ctx.save_for_backward(qkv, lse, o)
+            ctx.mark_non_differentiable(st)
+            return y, st
+        B, C, H, W = x.shape
+        dev = x.device
+        train = torch.is_grad_enabled() or qkv.requires_grad
+        y = empty_nhwc(B, C, H, W, x.dtype, dev)
+        st = torch.empty((B, tiles, C, 2), dtype=torch.float32, device=dev)
+        o = empty_nhwc(B, C, H, W, x.dtype, dev) if train else None
+        lse = torch.empty((B, H * W), dtype=torch.float32, device=dev) if train else None
+        call('idf_attn_fwd_res', _p(qkv), _p(x), _p(o), _p(lse), _p(y), _p(st), B, H * W, C, float(int(C) ** (-0.5)), _st())
+        if train:
+            ctx.save_for_backward(qkv, lse, o)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, dy, _dst):
+        qkv, lse, o = ctx.saved_tensors
+        B, C3, H, W = qkv.shape
+        C, N = C3 // 3, H * W
+        dy = _nhwc(dy.to(qkv.dtype))
+        dqkv = torch.empty_like(qkv, memory_format=CL)
+        call('idf_attn_bwd_o', _p(qkv), _p(dy), _p(lse), _p(o), _p(dqkv), B, N, C, float(int(C) ** (-0.5)), _dt(qkv), _st())
+        return dqkv, dy, None, None
+
+
+def attention_res(qkv, x, tiles, pre=None):
+    y, st = _AttentionRes.apply(qkv, x, tiles, pre)
+    return _tag(y, st)
+
+
+_FOLD_BWD_ROWS = []       # fix-ups of the backward pass in flight: (g, gb, wp, wv, bv, dwp, dbp, C) device addresses
+_FOLD_BWD_TABLES = {}     # tuple of rows -> device table (addresses are fixed: gradient arena, parameters)
+
+
+def _fold_bwd_run():
+    """End of the backward pass (queued behind WgradBatch.flush): the gradients of the folded weights, which the q | k | v weight
+    gradient left in proj_v's arena slots, become the gradients of proj and proj_v -- one launch for all blocks of the pass."""
+    rows = tuple(_FOLD_BWD_ROWS)
+    del _FOLD_BWD_ROWS[:]
+    if not rows:
+        return
+    tab = _FOLD_BWD_TABLES.get(rows)
+    if tab is None:
+        import numpy as np
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('attention fold: run one eager training step before graph capture')
+        dt = np.dtype([('g', '<i8'), ('gb', '<i8'), ('wp', '<i8'), ('wv', '<i8'), ('bv', '<i8'), ('dwp', '<i8'), ('dbp', '<i8'),
+                       ('gs', '<i8'), ('C', '<i4'), ('pad', '<i4')])
+        scratch = torch.empty((sum(r[7] * r[7] + r[7] for r in rows),), dtype=torch.float32, device='cuda')
+        offs, off = [], 0
+        for r in rows:
+            offs.append(scratch.data_ptr() + 4 * off)
+            off += r[7] * r[7] + r[7]
+        host = np.array([r[:7] + (o, r[7], 0) for r, o in zip(rows, offs)], dtype=dt)
+        tab = (torch.from_numpy(host.view(np.uint8).reshape(len(rows), -1).copy()).cuda(), scratch)
+        _FOLD_BWD_TABLES[rows] = tab
+    call('idf_attn_fold_bwd_batched', tab[0].data_ptr(), len(rows), max(r[7] for r in rows), _st())
+
+
+class _FoldProjV(torch.autograd.Function):
+    """Marks the q | k | v weight / bias concatenations as carrying the proj conv in their V third (the VALUES the kernels read
+    are the folded buffers the block keeps; these tensors only route gradients).  Backward: the q | k | v weight gradient
+    arrives for (Wq, Wk, Wv' = Wp Wv) and (bq, bk, b' = Wp bv + bp); the chain rule to proj and proj_v is one batched launch at
+    the end of the backward pass when the gradients live in the arena (deferred weight gradients), else torch products."""
+
+    @staticmethod
+    def forward(ctx, wcat, bcat, wp, bp, wv, bv):
+        ctx.save_for_backward(wp, wv, bv)
+        ctx.slots = (slot_of(wp), slot_of(bp))
+        return wcat.view_as(wcat), bcat.view_as(bcat)
+
+    @staticmethod
+    def backward(ctx, dw, db):
+        wp, wv, bv = ctx.saved_tensors
+        C = wp.shape[0]
+        sw, sb = ctx.slots
+        arena = sw.arena if sw is not None else None
+        if (arena is not None and sb is not None and dw is not None and db is not None and arena.holds(dw) and arena.holds(db)
+                and sw.available() and sb.available() and dw.is_contiguous() and db.is_contiguous()):
+            gw, gbp = sw.take(), sb.take()
+            g, gb = dw[2 * C:], db[2 * C:]
+            _FOLD_BWD_ROWS.append((g.data_ptr(), gb.data_ptr(), wp.data_ptr(), wv.data_ptr(), bv.data_ptr(), gw.data_ptr(),
+                                   gbp.data_ptr(), C))
+            if len(_FOLD_BWD_ROWS) == 1:
+                torch.autograd.Variable._execution_engine.queue_callback(_fold_bwd_run)
+            return dw, db, gw, gbp, None, None
+        # gradients that are ordinary tensors (no arena, or the weight gradient ran eagerly): the same chain rule in torch
+        WgradBatch.flush()
+        G, gb = dw[2 * C:].reshape(C, C).float(), db[2 * C:].float()
+        wp2, wv2 = wp.reshape(C, C).float(), wv.reshape(C, C).float()
+        dwp = (G @ wv2.t() + torch.outer(gb, bv.float())).view_as(wp)
+        dwv = (wp2.t() @ G).view(dw[2 * C:].shape)
+        dbv = wp2.t() @ gb
+        dw2 = torch.cat([dw[:2 * C], dwv.to(dw.dtype)], dim=0)
+        db2 = torch.cat([db[:2 * C], dbv.to(db.dtype)], dim=0)
+        return dw2, db2, dwp, gb.clone(), None, None
+
+
+def fold_proj_v(wcat, bcat, wp, bp, wv, bv):
+    """(wcat, bcat) with the gradient routing of the folded V third (see _FoldProjV); a no-op without gradients."""
+    if not (torch.is_grad_enabled() and wcat.requires_grad):
+        return wcat, bcat
+    grp_w, grp_b = getattr(wcat, '_idf_cat_group', None), getattr(bcat, '_idf_cat_group', None)
+    w2, b2 = _FoldProjV.apply(wcat, bcat, wp, bp, wv, bv)
+    if grp_w is not None:
+        w2._idf_cat_group = grp_w
+    if grp_b is not None:
+        b2._idf_cat_group = grp_b
+    return w2, b2
+
+
 # ------------------------------------------------- the attention block in one launch
 _ATTN_BLOCK = os.environ.get('IDF_ATTN_BLOCK', '1') != '0'
 # One 4-wave workgroup per image: a win only once the batch alone fills the chip (DDIM-100 at B = 256: 306 -> 310.5 img/s).  At
@@ -1681,13 +1818,13 @@ _ATTN_BLOCK_MINB = int(os.environ.get('IDF_ATTN_BLOCK_MINB', '256'))
 def attn_block_ok(x, policy=True):
     """The one-launch attention block (idf_attnblock_fwd) covers this input: bf16, 256 tokens, 128 channels -- and, with
     `policy`, the batch is one the launch pays at."""
-    return bool(_ATTN_BLOCK and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+    return bool(_ATTN_BLOCK and _ATTN_FOLD and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
                 and (not policy or x.shape[0] >= _ATTN_BLOCK_MINB)
                 and _lib.load().idf_attnblock_ok(x.shape[2] * x.shape[3], x.shape[1], BF16))
 
 
-def attn_block_fwd_raw(x, xst, gn_w, gn_b, wqkv_frag, bqkv, wp_fwd, bp, train):
-    """y = x + proj(attention(q | k | v)), q | k | v = conv1x1(GroupNorm(x)) in one launch
+def attn_block_fwd_raw(x, xst, gn_w, gn_b, wqkv_frag, bqkv, train):
+    """y = x + attention(q | k | v'), q | k | v' = conv1x1(GroupNorm(x)) (the proj conv folded into V) in one launch
     -> (y, st_y, qkv, h, o, lse, mean, rstd, sc, sh); everything after st_y is None unless `train` (what the backward reads)."""
     x = _nhwc(x)
     B, C, H, W = x.shape
@@ -1701,9 +1838,8 @@ def attn_block_fwd_raw(x, xst, gn_w, gn_b, wqkv_frag, bqkv, wp_fwd, bp, train):
         lse = torch.empty((B, H * W), dtype=torch.float32, device=dev)
         mean, rstd = (torch.empty((B, 32), dtype=torch.float32, device=dev) for _ in range(2))
         sc, sh = (torch.empty((B, C), dtype=torch.float32, device=dev) for _ in range(2))
-    call('idf_attnblock_fwd', _p(x), _p(xst), xst.shape[1], _p(gn_w), _p(gn_b), GN_EPS, _p(wqkv_frag), _p(bqkv), _p(wp_fwd),
-         _p(bp), _p(y), _p(st), _p(qkv), _p(h), _p(o), _p(lse), _p(mean), _p(rstd), _p(sc), _p(sh), float(int(C) ** (-0.5)),
-         B, H * W, C, _st())
+    call('idf_attnblock_fwd', _p(x), _p(xst), xst.shape[1], _p(gn_w), _p(gn_b), GN_EPS, _p(wqkv_frag), _p(bqkv), _p(y), _p(st),
+         _p(qkv), _p(h), _p(o), _p(lse), _p(mean), _p(rstd), _p(sc), _p(sh), float(int(C) ** (-0.5)), B, H * W, C, _st())
     return y, st, qkv, h, o, lse, mean, rstd, sc, sh
 
 

@@ -844,15 +844,20 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
         assert float((ob.float() - b0.grad).abs().max()) <= 1e-4 * float(b0.grad.abs().max()), (B, Cin, H, W, Cout, taps, mode)
 
 
+@pytest.mark.parametrize('path,H,B,arena', [('block', 16, 3, True), ('fold', 16, 3, True), ('fold', 8, 5, True), ('fold', 16, 130, True),
+                                            ('fold', 16, 3, False)])
 @pytest.mark.parametrize('train', [False, True])
-def test_attention_block_one_launch(train, monkeypatch):
-    """The whole AttnBlock (modules.py:145-164) at 16x16 x 128 channels as ONE launch (idf_attnblock_fwd: GroupNorm fold from the
-    producer's partials, q | k | v from fragment-major weights, softmax(q k^T) v, proj + residual, statistics of y):
-    (a) against fp32 PyTorch of the same block on the same bf16-valued input and parameters (2e-2 of the output's range:
-        the bf16 intermediates q, k, v, P, O, as the per-op path), the statistics partials against the output's own sums;
-    (b) against the per-op path of the same module: output within a few bf16 ulps, and -- training -- the SAME backward pass
-        (the three autograd nodes only record): input gradient and every parameter gradient within the per-op path's own
-        run-to-run band."""
+def test_attention_block_with_proj_folded_into_v(path, H, B, arena, train, monkeypatch):
+    """The AttnBlock (modules.py:145-164) at 128 channels with the proj conv folded into V (Wv' = Wp Wv, b' = Wp bv + bp; the
+    rows of the softmax sum to one): y = x + P V' --
+    'fold':  the GroupNorm-prologue q | k | v' conv, then attention with the residual and the statistics of y in its epilogue
+             (idf_attn_fwd_res; 16x16 with four workgroups per image or -- B >= 128 -- one, and the 8x8 middle block): two launches;
+    'block': the whole block as ONE launch at 16x16 (idf_attnblock_fwd);
+    (a) against fp32 PyTorch of the reference's block (q, k, v, softmax, bmm, proj, + x) on the same bf16-valued input and
+        parameters (2e-2 of the output's range, as the unfolded per-op path), the statistics partials against the output's sums;
+    (b) against the unfolded per-op path of the same module; and -- training -- input gradient and EVERY parameter gradient,
+        proj's and proj_v's through the chain rule of the fold (idf_attn_fold_bwd_batched in the gradient arena; torch products
+        without one), against fp32 PyTorch autograd (4e-2, the bound of the kernel tests) and the unfolded path."""
     import torch.nn.functional as F
     from infodiffusion_amd import modules
     from infodiffusion_amd.optim import FusedClipAdamW
@@ -864,10 +869,10 @@ def test_attention_block_one_launch(train, monkeypatch):
             if prm.dim() == 1:
                 prm.add_(0.2 * rnd(hash(name) % 1000, *prm.shape).to(DEV))
     blk.train(train)
-    opt = FusedClipAdamW(blk.parameters(), lr=0.0, weight_decay=0.0)
-    B = 3
-    x0 = (0.2 + rnd(1, B, 128, 16, 16)).to(DEV).bfloat16().contiguous(memory_format=CL)
-    dyw = rnd(2, B, 128, 16, 16).to(DEV)
+    opt = FusedClipAdamW(blk.parameters(), lr=0.0, weight_decay=0.0) if arena else None
+    N = H * H
+    x0 = (0.2 + rnd(1, B, 128, H, H)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dyw = rnd(2, B, 128, H, H).to(DEV)
     names = []
     orig_call = ops.call
 
@@ -875,13 +880,17 @@ def test_attention_block_one_launch(train, monkeypatch):
         names.append(name)
         return orig_call(name, *a)
     monkeypatch.setattr(ops, 'call', counted)
+    monkeypatch.setattr(ops, '_ATTN_BLOCK_MINB', 1)          # coverage, not the policy (B >= 256)
 
-    def run(fused):
-        monkeypatch.setattr(ops, '_ATTN_BLOCK', fused)
-        monkeypatch.setattr(ops, '_ATTN_BLOCK_MINB', 1)          # coverage, not the policy (B >= 256)
+    def run(which):
+        monkeypatch.setattr(ops, '_ATTN_FOLD', which != 'ops')
+        monkeypatch.setattr(ops, '_ATTN_BLOCK', which == 'block')
         del names[:]
         x = x0.clone().requires_grad_(train)
-        opt.zero_grad()
+        if opt is not None:
+            opt.zero_grad()
+        else:
+            blk.zero_grad()
         with torch.set_grad_enabled(train):
             y = blk(x)
         fwd = list(names)
@@ -894,37 +903,48 @@ def test_attention_block_one_launch(train, monkeypatch):
             g.update({k: prm.grad.detach().float().clone() for k, prm in blk.named_parameters() if prm.grad is not None})
         return y.detach().float().clone(), st, g, fwd
 
-    y_ref, st_ref, g_ref, fwd_ref = run(False)
-    assert 'idf_attnblock_fwd' not in fwd_ref and 'idf_attn_fwd' in fwd_ref
-    run(True)                                         # asks for the fragment-major q | k | v weights (next re-pack)
-    y, st, g, fwd = run(True)
-    assert fwd.count('idf_attnblock_fwd') == 1 and 'idf_attn_fwd' not in fwd and not any(n.startswith('idf_conv') for n in fwd), fwd
-    # (a) fp32 PyTorch
-    with torch.no_grad():
-        xf = x0.float()
-        hn = F.group_norm(xf, 32, blk.group_norm.weight, blk.group_norm.bias, eps=1e-5)
-        q, k, v = (F.conv2d(hn, m.weight, m.bias) for m in (blk.proj_q, blk.proj_k, blk.proj_v))
-        q, k, v = (t.permute(0, 2, 3, 1).reshape(B, 256, 128) for t in (q, k, v))
-        w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * 128 ** -0.5, dim=-1)
-        hh = torch.bmm(w, v).view(B, 16, 16, 128).permute(0, 3, 1, 2)
-        want = xf + F.conv2d(hh, blk.proj.weight, blk.proj.bias)
+    y_ref, st_ref, g_ref, fwd_ref = run('ops')
+    assert 'idf_attnblock_fwd' not in fwd_ref and 'idf_attn_fwd_res' not in fwd_ref and 'idf_attn_fwd' in fwd_ref
+    run(path)                                         # ('block': asks for the fragment-major q | k | v' weights -- next re-pack)
+    y, st, g, fwd = run(path)
+    if path == 'block':
+        assert fwd.count('idf_attnblock_fwd') == 1 and not any(n.startswith('idf_attn_fwd') or n.startswith('idf_conv') for n in fwd), fwd
+    else:
+        assert fwd.count('idf_attn_fwd_res') == 1 and 'idf_attn_fwd' not in fwd and sum(n.startswith('idf_conv') for n in fwd) == 1, fwd
+    # (a) fp32 PyTorch of the reference's block -- on the CPU: PyTorch-ROCm's own GroupNorm backward returns wrong dgamma / dbeta
+    # from B * 32 groups > 4096 on (B = 129: 0.76 / 0.62 off its CPU result, dx exact; this image's torch 2.10.0+rocm7.0)
+    prm = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.named_parameters()}
+    xr = x0.float().cpu().clone().requires_grad_(True)
+    hn = F.group_norm(xr, 32, prm['group_norm.weight'], prm['group_norm.bias'], eps=1e-5)
+    q, k, v = (F.conv2d(hn, prm[n + '.weight'], prm[n + '.bias']) for n in ('proj_q', 'proj_k', 'proj_v'))
+    q, k, v = (t.permute(0, 2, 3, 1).reshape(B, N, 128) for t in (q, k, v))
+    w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * 128 ** -0.5, dim=-1)
+    hh = torch.bmm(w, v).view(B, H, H, 128).permute(0, 3, 1, 2)
+    want = xr + F.conv2d(hh, prm['proj.weight'], prm['proj.bias'])
+    if train:
+        (want * dyw.bfloat16().float().cpu()).sum().backward()
+    want = want.detach().to(DEV)
     assert rel(y, want) < 2e-2, rel(y, want)
     assert rel(y_ref, want) < 2e-2
-    assert st is not None and st.shape == (B, 1, 128, 2)
-    yb = y.permute(0, 2, 3, 1).reshape(B, 256, 128)
-    assert rel(st[:, 0, :, 0], yb.sum(1)) < 1e-5 and rel(st[:, 0, :, 1], (yb * yb).sum(1)) < 1e-5
-    # (b) the per-op path
+    assert st is not None and st.shape[0] == B and st.shape[2:] == (128, 2)
+    T = st.shape[1]
+    assert T == (1 if (path == 'block' or H == 8 or B >= 128) else 4)
+    yb = y.permute(0, 2, 3, 1).reshape(B, T, N // T, 128)
+    assert rel(st[..., 0], yb.sum(2)) < 1e-5 and rel(st[..., 1], (yb * yb).sum(2)) < 1e-5
+    # (b) the unfolded per-op path; gradients
     assert rel(y, y_ref) < 1e-2, rel(y, y_ref)
     if train:
-        assert set(g) == set(g_ref)
+        assert set(g) == set(g_ref) == set(list(prm) + ['x'])
+        top = float(prm['proj_v.bias'].grad.abs().max())
         for kname in g_ref:
             if kname == 'proj_k.bias':
-                # mathematically zero (a bias on k shifts every score of a row alike: softmax does not see it) -- what both
-                # paths hold is rounding noise, compared against the scale of a live gradient instead of against each other
-                top = float(g_ref['proj_v.bias'].abs().max())
+                # mathematically zero (a bias on k shifts every score of a row alike: softmax does not see it) -- rounding noise on
+                # every path, held against the scale of a live gradient
                 assert float(g[kname].abs().max()) < 0.1 * top and float(g_ref[kname].abs().max()) < 0.1 * top
                 continue
-            assert rel(g[kname], g_ref[kname]) < 3e-2, (kname, rel(g[kname], g_ref[kname]))
+            ref32 = (xr.grad if kname == 'x' else prm[kname].grad).to(DEV)
+            assert rel(g[kname], ref32) < 4e-2, (kname, rel(g[kname], ref32))
+            assert rel(g[kname], g_ref[kname]) < 4e-2, (kname, rel(g[kname], g_ref[kname]))
 
 
 @pytest.mark.parametrize('B,C,Co,Hl', [(3, 128, 128, 8), (2, 128, 128, 16), (2, 128, 128, 32), (2, 256, 256, 16), (5, 64, 192, 8)])

@@ -432,6 +432,12 @@ class InfoDiff(nn.Module):
             x_tilde = x
         use_q = self.kld_weight != 0     # models.py:714-721
         if a is None:
+            # both networks run this call: ONE re-pack of every weight shadow (encoder + backbone: three launches instead of the
+            # six of two per-network re-packs; each network's own _prep then finds nothing stale)
+            if getattr(self, '_shadow_all', None) is None:
+                self._shadow_all = ShadowSet(self)
+            if x.is_cuda:
+                self._shadow_all.refresh(self.backbone.ctx.act_dtype, torch.is_grad_enabled())
             a, a_q, mu, log_var = self.encoder(x, want_q=use_q)
         else:
             a_q = a

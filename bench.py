@@ -325,6 +325,10 @@ class LaunchRecorder:
         if name == 'idf_attn_fwd':
             B, N, C = a[3:6]
             return 'attn', [(0, B * N * 3 * C * 2), (1, B * N * C * 2)], 4.0 * B * N * N * C
+        if name == 'idf_attn_fwd_res':           # attention with the residual and the statistics in its epilogue (proj folded into V)
+            B, N, C = a[6:9]
+            bufs = [(0, B * N * 3 * C * 2), (1, B * N * C * 2), (4, B * N * C * 2)] + ([(2, B * N * C * 2)] if a[2] else [])
+            return 'attn', bufs, 4.0 * B * N * N * C
         return None
 
     @staticmethod
@@ -637,9 +641,9 @@ def main():
         if 'attn' in fam:
             n, ms, fl, by = fam['attn']
             ach = fl / (ms * 1e-3) / 1e12
-            out['roofline_attn'] = {'kernel': 'attn_fwd_kernel (N = 256 tokens at 16x16, N = 64 at the 8x8 middle block; d = 128: QK^T, softmax, PV in one launch)',
+            out['roofline_attn'] = {'kernel': 'attn_fwd_res_kernel (N = 256 tokens at 16x16, N = 64 at the 8x8 middle block; d = 128: QK^T, softmax, PV, + x, statistics of y in one launch; the proj conv is folded into V)',
                                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic_file(['attn_fwd_kernel']),
+                                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic_file(['attn_fwd_res_kernel', 'attn_fwd_kernel']),
                                     'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                     'note': '4 N^2 d FLOP per image; launch-bound at B = 32 (32 x 4 workgroups)'}
     if world > 1:

@@ -299,6 +299,10 @@ int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int
  * (idf_wgrad_kr3_ok); the host keeps those that do not in a class of their own: mode | IDF_WGRAD_ROWSPLIT in both
  * calls selects the row-split kernel for that class. */
 #define IDF_WGRAD_ROWSPLIT 16
+/* mode 2 (UpSample) | IDF_WGRAD_UPSUB in both calls: the class in its sub-pixel form (16 tap products per low-resolution pixel
+ * instead of 36: taps that read the same low-resolution pixel share one product, modules.py:78-93) where idf_wgrad_upsub_ok. */
+#define IDF_WGRAD_UPSUB 32
+int idf_wgrad_upsub_ok(int H, int W);
 int idf_wgrad_kr3_ok(int H, int W);
 int idf_wgrad_desc_bytes(void);
 int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy, float* dW,

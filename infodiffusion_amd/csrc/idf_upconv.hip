@@ -9,7 +9,7 @@
 // LDS and ran all nine taps over it (conv3x3_halo_bf16 MODE 2) spent 572 us per DDIM evaluation at B = 256 on three such layers.
 // The sums are formed in fp32 from the master weights and rounded to bf16 once (the host packs them fragment-major: 1 KB per
 // wave instruction, straight into registers; upconv_pack_kernel re-packs them with the other weight shadows).  Forward and data
-// gradient (upconv_dgrad_bf16_kernel below); the weight gradient stays the UP2 class of the batched weight-gradient kernel.
+// gradient (upconv_dgrad_bf16_kernel below); the weight gradient in the same form is idf_wgrad.hip's wgrad_block_upsub.
 //
 // One 512-thread workgroup = 256 output pixels (R rows x W columns of one image) x 64 couts.  Wave w owns parity w & 3 and the
 // cout half w >> 2: 64 pixels of its parity x 32 couts, 4 x 2 accumulator tiles; per 32-channel chunk 4 taps x 8 MFMAs.  The

@@ -35,7 +35,8 @@ struct WgP {
   int tiles_per_blk;
   int c_tiles, n_tiles;
   int Cw, Nw;         // dW is [Nw][taps][Cw] (Cw <= Cin, Nw <= Cout): channels the operands were zero-padded by get no gradient
-  int wshift;         // log2(W) (W is a power of two)
+  int wshift;         // log2(W) (W is a power of two); sub-pixel UP2 form: log2(W / 2)
+  int upsub;          // MODE 2 in the sub-pixel form (wgrad_block_upsub): R = LOW-resolution rows per tile
   unsigned wh_magic;  // (pix * wh_magic) >> 16 == pix / WH over the staged tile's pixels (checked on the host)
 };
 
@@ -281,6 +282,177 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   }
 }
 
+// ---- UpSample's weight gradient (MODE 2) in the sub-pixel form: 16 tap products per low-resolution pixel instead of 36.
+// With oy = 2 Y + py, ox = 2 X + px the up-sampled input under tap (ky, kx) of output pixel (oy, ox) is the low-resolution pixel
+// (Y + ty + py - 1, X + tx + px - 1) with ty = 0 for ky in S(py, 0), 1 for ky in S(py, 1) (S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1},
+// S(1,1) = {2}; the same along x): taps that share (ty, tx) multiply dy with the SAME pixel, so
+//   G[py][px][ty][tx] = sum_{Y,X} dy[2Y+py][2X+px] (x) x[Y+ty+py-1][X+tx+px-1]     and     dW[ky][kx] = sum of the G whose sets hold (ky, kx).
+// A block owns (cin tile, cout tile, py): both column parities, 8 accumulator sets (2 px x 2 ty x 2 tx); per staged tile -- RL
+// low-resolution rows of x with a one-pixel halo, the two dy parity planes of those rows -- every 32-pixel k-step runs 32 MFMAs.
+// The epilogue adds the column-combined tiles (kx = 0: G[0][.][0] + G[1][.][0]; 1: G[0][.][1] + G[1][.][0]; 2: G[0][.][1] + G[1][.][1]) to
+// every kernel row of S(py, ty) with fp32 atomics.
+__device__ __forceinline__ void wgrad_block_upsub(const WgP& p, int bx, const int by) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = 256;
+  const int Wl = p.W >> 1, Hl = p.H >> 1, RL = p.R, WHl = Wl + 2, W2 = p.W;
+  const int npix_h = (RL + 2) * WHl, KT = RL * Wl;
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Ds = Xs + npix_h * PITCH;                 // [2 px][KT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int py = bx & 1;
+  bx >>= 1;
+  const int c0 = (bx % p.c_tiles) * 64, n0 = (bx / p.c_tiles) * 64;
+  const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+  const int tiles_per_img = Hl / RL;
+  const int t_beg = by * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
+
+  f32x4_t acc[2][2][2][2][2];                       // [px][ty][tx][i][j]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][t][u][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int v8 = tid & 7;
+  float dbs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
+  const bool do_db = p.db != nullptr && c0 == 0;
+  const bool cvalid = (c0 + v8 * 8) < p.Cin, nvalid = (n0 + v8 * 8) < p.Cout;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  constexpr int XV = 7, DV = 8;
+  uint4 xreg[XV], dreg[DV];
+  auto load_tile = [&](int t) {
+    const int b = t / tiles_per_img, Y0 = (t - b * tiles_per_img) * RL;
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int idx = tid + k * NT;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (idx < npix_h * 8) {
+        const int pix = idx >> 3;
+        const int hy = (int)(((unsigned)pix * p.wh_magic) >> 16), hx = pix - hy * WHl;
+        const int iy = Y0 + hy - 1, ix = hx - 1;
+        if (cvalid && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
+          val = gload16(p.a + ((size_t)(b * Hl + iy) * Wl + ix) * p.Cin + c0 + v8 * 8);
+      }
+      xreg[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      const int idx = tid + k * NT;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (idx < 2 * KT * 8 && nvalid) {
+        const int pe = idx >> 3, px = pe >= KT ? 1 : 0, pl = pe - px * KT;
+        const int Yl = pl >> p.wshift, Xl = pl & (Wl - 1);
+        val = gload16(p.dy + ((size_t)(b * p.H + 2 * (Y0 + Yl) + py) * W2 + 2 * Xl + px) * p.Cout + n0 + v8 * 8);
+      }
+      dreg[k] = val;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < npix_h * 8) *reinterpret_cast<uint4*>(Xs + (idx >> 3) * PITCH + v8 * 8) = xreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < 2 * KT * 8) {
+        *reinterpret_cast<uint4*>(Ds + (idx >> 3) * PITCH + v8 * 8) = dreg[k];
+        if (do_db) {
+          const uint32_t w4[4] = {dreg[k].x, dreg[k].y, dreg[k].z, dreg[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dbs[2 * e] += __uint_as_float(w4[e] << 16);
+            dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  };
+  if (t_beg < t_end) load_tile(t_beg);
+  for (int t = t_beg; t < t_end; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);
+    for (int ks = 0; ks < KT; ks += 32) {
+      const int pixA = ks + 4 * g + q, pixB = pixA + 16;
+      const int yA = pixA >> p.wshift, xA = pixA & (Wl - 1), yB = pixB >> p.wshift, xB = pixB & (Wl - 1);
+      // x fragments at halo rows y + ty + py, columns x + cx for cx in {0, 1, 2} (cx = tx + px)
+      bf16x8_t cf[2][3][2];
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const bf16_t* x0 = Xs + ((yA + ty + py) * WHl + xA) * PITCH + wc0 + 4 * pp;
+        const bf16_t* x1 = Xs + ((yB + ty + py) * WHl + xB) * PITCH + wc0 + 4 * pp;
+#pragma unroll
+        for (int cx = 0; cx < 3; ++cx)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) cf[ty][cx][j] = mkfrag(tr_read(x0 + cx * PITCH + j * 16), tr_read(x1 + cx * PITCH + j * 16));
+      }
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        bf16x8_t nf[2];
+        const bf16_t* d0 = Ds + (px * KT + pixA) * PITCH + wn0 + 4 * pp;
+        const bf16_t* d1 = Ds + (px * KT + pixB) * PITCH + wn0 + 4 * pp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d1 + i * 16));
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[px][ty][tx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf[ty][tx + px][j], acc[px][ty][tx][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: combine the column parities, add to every kernel row of S(py, ty)
+#pragma unroll
+  for (int ty = 0; ty < 2; ++ty) {
+    const int ky0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2);
+    const int nky = (py == 0) == (ty == 1) ? 2 : 1;        // S(0,1) = {1,2}, S(1,0) = {0,1}: two rows; S(0,0), S(1,1): one
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = c0 + wc0 + j * 16 + (lane & 15);
+          if (c >= p.Cw) continue;
+          f32x4_t v;
+          if (kx == 0) v = acc[0][ty][0][i][j] + acc[1][ty][0][i][j];
+          else if (kx == 1) v = acc[0][ty][1][i][j] + acc[1][ty][0][i][j];
+          else v = acc[0][ty][1][i][j] + acc[1][ty][1][i][j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
+            if (n < p.Nw) {
+              for (int kk = 0; kk < nky; ++kk) gatomic_add(p.dW + ((size_t)n * 9 + (ky0 + kk) * 3 + kx) * p.Cw + c, v[r]);
+            }
+          }
+        }
+  }
+  if (do_db) {
+    float* red = reinterpret_cast<float*>(smem);   // [NT / 8][64]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Nw) {
+      float sacc = 0.f;
+      for (int k = 0; k < NT / 8; ++k) sacc += red[k * 64 + tid];
+      gatomic_add(p.db + n0 + tid, sacc);
+    }
+  }
+}
+
 template <int KW, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16(const WgP p) {
   wgrad_block<KW, MODE>(p, blockIdx.x, blockIdx.y);
@@ -330,6 +502,27 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16_batched(const WgDes
   }
 }
 
+// the sub-pixel form of the UpSample class (wgrad_block_upsub: 8 accumulator sets, ~250 registers -- its own kernel, so the other
+// classes keep their three-blocks-per-CU budgets)
+__global__ __launch_bounds__(256) void conv_wgrad_up_sub_batched(const WgDesc* __restrict__ tab, int n, int total) {
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    if (bid != (int)blockIdx.x) __syncthreads();
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (tab[mid].blk0 <= bid) lo = mid; else hi = mid;
+    }
+    const WgDesc* d = tab + lo;
+    const WgP p = d->p;
+    const int local = bid - d->blk0, gx = d->gx;
+    if (d->xcd) {
+      const int x = local & 7, j = local >> 3;
+      const int by = x + 8 * (j / gx);
+      if (by < d->gy) wgrad_block_upsub(p, j % gx, by);
+    } else if (local < gx * d->gy) wgrad_block_upsub(p, local % gx, local / gx);
+  }
+}
+
 // the shared-tile form of the stride-1 3x3 class (768 threads, one block per CU)
 __global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDesc* __restrict__ tab, int n, int total) {
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
@@ -344,11 +537,18 @@ const int g_kr3 = getenv("IDF_WGRAD_KR3") ? atoi(getenv("IDF_WGRAD_KR3")) : 1;
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
             int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
-            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0, bool kr3 = false) {
+            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0, bool kr3 = false, bool want_upsub = false) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
              Cout, taps, mode);
+  // MODE 2 in the sub-pixel form (wgrad_block_upsub) where the low-resolution map tiles: W / 2 in {8, 16, 32}
+  const int Wl_ = W / 2, Hl_ = H / 2;
+  int RLs = Wl_ > 0 ? 128 / Wl_ : 0;
+  if (RLs > Hl_) RLs = Hl_;
+  const bool upsub = want_upsub && mode == 2 && taps == 9 && Wl_ >= 8 && Wl_ <= 32 && RLs >= 1 && (Hl_ % RLs) == 0 && ((RLs * Wl_) % 32) == 0 &&
+                     (RLs + 2) * (Wl_ + 2) * 8 <= 7 * 256;
+  if (want_upsub && !upsub) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: H%d W%d not covered by the sub-pixel form", H, W);
   int R = (mode == 1 ? 64 : 128) / W;
   if (R > H) R = H;
   if (R < 1 || (H % R) || ((R * W) % 32) || R * ((mode == 1 ? 2 : 1) * W + 2) > 160 || R * W > 128)
@@ -359,16 +559,17 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.a2 = (const bf16_t*)a2; p.C1 = a2 ? C1 : Cin;
   if (Cin_w < 0 || Cin_w > Cin || Cout_w < 0 || Cout_w > Cout)
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16: gradient extents %d x %d exceed the operands' %d x %d", Cout_w, Cin_w, Cout, Cin);
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = upsub ? RLs : R;
+  p.upsub = upsub ? 1 : 0;
   p.Cw = Cin_w > 0 ? Cin_w : Cin; p.Nw = Cout_w > 0 ? Cout_w : Cout;
   p.Hs = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
   p.Ws = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
-  p.tiles = B * (H / R);
+  p.tiles = upsub ? B * (Hl_ / RLs) : B * (H / R);
   {
     int ws = 0;
-    while ((1 << ws) < W) ++ws;
+    while ((1 << ws) < (upsub ? Wl_ : W)) ++ws;
     p.wshift = ws;
-    const int WHh = (mode == 1 ? 2 : 1) * W + 2 * (taps == 9 ? 1 : 0), np = (R + (kr3 ? 2 : 0)) * WHh;
+    const int WHh = upsub ? Wl_ + 2 : (mode == 1 ? 2 : 1) * W + 2 * (taps == 9 ? 1 : 0), np = upsub ? (RLs + 2) * WHh : (R + (kr3 ? 2 : 0)) * WHh;
     unsigned m = 65536u / (unsigned)WHh + 1u;
     for (int i = 0; i < np; ++i)
       if ((((unsigned)i * m) >> 16) != (unsigned)(i / WHh)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: tile of %d pixels not addressable", np);
@@ -377,7 +578,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   p.c_tiles = idf_cdiv(Cin, 64);
   p.n_tiles = idf_cdiv(Cout, 64);
   const int kh = taps == 9 ? 3 : 1;
-  gx = p.c_tiles * p.n_tiles * (kr3 ? 1 : kh);
+  gx = p.c_tiles * p.n_tiles * (upsub ? 2 : (kr3 ? 1 : kh));
   if (target_blocks <= 0) {
     // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
     // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
@@ -403,6 +604,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   gy = idf_cdiv(p.tiles, p.tiles_per_blk);
   const int sx = mode == 1 ? 2 : 1;
   lds = ((size_t)(R + (kr3 ? 2 : 0)) * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB * (kr3 ? 2 : 1);     // kr3: two LDS tiles
+  if (upsub) lds = ((size_t)(RLs + 2) * (Wl_ + 2) + (size_t)2 * RLs * Wl_) * PITCHB;
   const size_t red = (size_t)(kr3 ? 96 : 32) * 64 * sizeof(float);
   if (lds < red) lds = red;
   return IDF_OK;
@@ -422,6 +624,17 @@ bool kr3_fits(int H, int W) {
 
 // 1 when the batched stride-1 3x3 weight gradient of an H x W map runs in the shared-tile form (kr3); the host keeps problems
 // that do not fit in a class of their own (mode | IDF_WGRAD_ROWSPLIT in idf_wgrad_desc_fill / idf_conv_wgrad_bf16_batched)
+// 1 when the UpSample weight gradient of an H x W output map runs in the sub-pixel form (mode | IDF_WGRAD_UPSUB in
+// idf_wgrad_desc_fill / idf_conv_wgrad_bf16_batched): W / 2 in {8, 16, 32}, whole 128-pixel (64 at 8x8) low-resolution tiles
+extern "C" int idf_wgrad_upsub_ok(int H, int W) {
+  static const int on = getenv("IDF_WGRAD_UPSUB") ? atoi(getenv("IDF_WGRAD_UPSUB")) : 1;
+  if (!on || H <= 0 || W < 16 || (W & (W - 1)) || ((H | W) & 1)) return 0;
+  const int Wl = W / 2, Hl = H / 2;
+  int RL = 128 / Wl;
+  if (RL > Hl) RL = Hl;
+  return (Wl >= 8 && Wl <= 32 && RL >= 1 && (Hl % RL) == 0 && ((RL * Wl) % 32) == 0 && (RL + 2) * (Wl + 2) * 8 <= 7 * 256) ? 1 : 0;
+}
+
 extern "C" int idf_wgrad_kr3_ok(int H, int W) { return (g_kr3 && H > 0 && W >= 4 && !(W & (W - 1)) && kr3_fits(H, W)) ? 1 : 0; }
 
 // taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
@@ -479,12 +692,13 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 128;
   static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
   const bool rowsplit = (mode & 16) != 0;         // IDF_WGRAD_ROWSPLIT: the caller keeps this problem out of the shared-tile class
+  const bool upsub = (mode & 32) != 0;            // IDF_WGRAD_UPSUB: the UpSample class in its sub-pixel form
   mode &= 15;
   const bool kr3 = g_kr3 && taps == 9 && mode == 0 && !rowsplit;
   if (kr3 && !kr3_fits(H, W))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_desc_fill: H%d W%d does not fit the shared-tile form (class it with IDF_WGRAD_ROWSPLIT)", H, W);
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
-                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : tpb), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3);
+                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : tpb), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;
@@ -499,7 +713,7 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
 extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
                                                   int mode, int max_blocks, void* stream) {
   if (n <= 0 || total_blocks <= 0) return IDF_OK;
-  const bool rowsplit = (mode & 16) != 0;
+  const bool rowsplit = (mode & 16) != 0, upsub = (mode & 32) != 0;
   mode &= 15;
   if (!dev_table || (taps != 9 && taps != 1) || mode < 0 || mode > 2 || (mode && taps != 9))
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16_batched: bad arguments (taps %d mode %d)", taps, mode);
@@ -523,6 +737,12 @@ extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, 
   }
   else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   else if (mode == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 1>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  else if (upsub) {
+    static IdfLdsGrant grant;
+    if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_up_sub_batched, (size_t)lds_bytes, grant); e != hipSuccess)
+      IDF_FAIL(IDF_ERR_HIP, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_wgrad_up_sub_batched, g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  }
   else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   IDF_CHECK_LAUNCH();
   return IDF_OK;

@@ -675,6 +675,11 @@ def _slot_views(w_slot, b_slot, want_bias, shape):
 
 
 @functools.lru_cache(maxsize=None)
+def _upsub_ok(H, W):
+    return bool(_lib.load().idf_wgrad_upsub_ok(H, W))
+
+
+@functools.lru_cache(maxsize=None)
 def _kr3_ok(H, W):
     return bool(_lib.load().idf_wgrad_kr3_ok(H, W))
 
@@ -770,6 +775,8 @@ class WgradBatch:
             mode = it[10]
             if it[9] == 9 and mode == S1 and not _kr3_ok(it[5], it[6]):
                 mode |= 16          # IDF_WGRAD_ROWSPLIT: a map the shared-tile kernel does not take (W = 128) is a class of its own
+            if it[9] == 9 and mode == UP2 and _upsub_ok(it[5], it[6]):
+                mode |= 32          # IDF_WGRAD_UPSUB: the UpSample class in its sub-pixel form
             groups.setdefault((it[9], mode), []).append(it)
         nb = lib.idf_wgrad_desc_bytes()
         capturing = torch.cuda.is_current_stream_capturing()

@@ -685,6 +685,7 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   if (forced > 0) target_blocks = forced;
   static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 16;      // re-swept for the 1x1 / stride-2 / up-sampling classes: profiles/r03_wgrad_tpb_sweep.txt
   static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 96;
+  static const int tpb_up = getenv("IDF_WGRAD_TPB_UP") ? atoi(getenv("IDF_WGRAD_TPB_UP")) : 16;   // sub-pixel UpSample class: tiles are 128 LOW-resolution pixels
   // pixel tiles per block of the shared-tile 3x3 class: 128 (round 4; 64 before) halves the pixel splits of the 64x64 / 32x32 problems
   // at a slightly shorter step (9.088 -> 9.065 ms; 192 / 256: the same; profiles/r04_wgrad_tpb3.txt).  The launch's atomic bytes
   // barely move (291 -> 281 MB by the WRITE_SIZE counter): they are the 16x16 / 8x8 problems' (590 KB - 1.2 MB of dW each, split by
@@ -698,7 +699,7 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   if (kr3 && !kr3_fits(H, W))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_desc_fill: H%d W%d does not fit the shared-tile form (class it with IDF_WGRAD_ROWSPLIT)", H, W);
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
-                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : tpb), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
+                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : (upsub ? tpb_up : tpb)), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;

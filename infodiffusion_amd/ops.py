@@ -1699,6 +1699,7 @@ class _AttentionRes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, x, tiles, pre=None):
         qkv, x = _nhwc(qkv), _nhwc(x)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the statistics output
         if pre is not None:          # (y, st, o, lse) of the one-launch attention block: record the backward pass only
             y, st, o, lse = pre
             ctx.save_for_backward(qkv, lse, o)
@@ -1719,6 +1720,8 @@ class _AttentionRes(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dst):
+        if dy is None:
+            return None, None, None, None
         qkv, lse, o = ctx.saved_tensors
         B, C3, H, W = qkv.shape
         C, N = C3 // 3, H * W
@@ -2162,6 +2165,7 @@ class _Objective(torch.autograd.Function):
         m = lat.shape[0]
         res = torch.empty((4,), dtype=torch.float32, device=out.device)
         ws = torch.empty((2048 + 2 * n + m,), dtype=torch.float32, device=out.device)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the (not differentiable) terms
         call('idf_objective_fwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(prior), _p(lat), n, m, D, w, _p(res), _p(ws),
              out.numel(), _dt(out), _st())
         ctx.k = (c0, c1, inv_T, w)
@@ -2172,6 +2176,8 @@ class _Objective(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _):
+        if g is None:
+            return (None,) * 9
         out, eps, x, prior, lat = ctx.saved_tensors
         c0, c1, inv_T, w = ctx.k
         g = _f32c(g).reshape(1)

@@ -1682,6 +1682,9 @@ def upconv_raw(x, w_sub_frag, bias, Cout, tiles):
 
 # ------------------------------------------------- the attention block's proj conv folded into V
 _ATTN_FOLD = os.environ.get('IDF_ATTN_FOLD', '1') != '0'
+# 1 = autograd hands the attention / objective nodes zero-filled gradients for their statistics / terms outputs (13 fill launches
+# per step; the A/B switch of profiles/r04_conv_wr.txt)
+_MATERIALIZE = os.environ.get('IDF_MATERIALIZE_GRADS', '0') == '1'
 
 
 def attn_res_tiles(qkv):
@@ -1699,7 +1702,7 @@ class _AttentionRes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, x, tiles, pre=None):
         qkv, x = _nhwc(qkv), _nhwc(x)
-        ctx.set_materialize_grads(False)      # no zero-filled gradient for the statistics output
+        ctx.set_materialize_grads(_MATERIALIZE)      # no zero-filled gradient for the statistics output
         if pre is not None:          # (y, st, o, lse) of the one-launch attention block: record the backward pass only
             y, st, o, lse = pre
             ctx.save_for_backward(qkv, lse, o)
@@ -2165,7 +2168,7 @@ class _Objective(torch.autograd.Function):
         m = lat.shape[0]
         res = torch.empty((4,), dtype=torch.float32, device=out.device)
         ws = torch.empty((2048 + 2 * n + m,), dtype=torch.float32, device=out.device)
-        ctx.set_materialize_grads(False)      # no zero-filled gradient for the (not differentiable) terms
+        ctx.set_materialize_grads(_MATERIALIZE)      # no zero-filled gradient for the (not differentiable) terms
         call('idf_objective_fwd', _p(out), _p(eps), _p(x), c0, c1, inv_T, _p(prior), _p(lat), n, m, D, w, _p(res), _p(ws),
              out.numel(), _dt(out), _st())
         ctx.k = (c0, c1, inv_T, w)

@@ -709,14 +709,21 @@ class WgradBatch:
     _side = None
     _inflight = []     # operands of side-stream flushes, kept alive until the join
     _cb_queued = False
+    _task = -1         # autograd graph task that queued the flush
 
     @classmethod
     def add(cls, item):
+        task = torch._C._current_graph_task_id()
+        if cls._cb_queued and task != cls._task:
+            # the pass (autograd graph task) that queued the flush never ended -- the engine skips its final callbacks when a
+            # node raises: its items belong to no launch, and this pass queues a flush of its own
+            cls._drop()
         cls.pending.append(item)
         if not cls._cb_queued:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
                 cls._cb_queued = True
+                cls._task = task
             except RuntimeError:          # not inside a backward pass: nothing to defer to
                 cls.flush()
                 return
@@ -725,15 +732,21 @@ class WgradBatch:
     def reset(cls):
         """Forget everything queued by a backward pass that did not end (the autograd engine skips its final callbacks
         when a node raises, so `flush` never ran): stale (a, dy, slot address) items must not be launched by a later
-        step, and `_cb_queued` must not keep later passes from queueing their own end-of-backward flush.  Safe to call
-        whenever no backward pass is running (trainer: before every forward, and after a failed capture)."""
+        step, and `_cb_queued` must not keep later passes from queueing their own end-of-backward flush (`add` also notices a
+        new graph task by itself).  Safe to call whenever no backward pass is running (trainer: before every forward, and
+        after a failed capture)."""
+        cls._drop()
+        _LAZY_PENDING.clear()
+        del _FOLD_BWD_ROWS[:]
+
+    @classmethod
+    def _drop(cls):
         cls.pending = []
         cls._cb_queued = False
         if cls._inflight:
             if cls._side is not None and cls._inflight[0][0].is_cuda and not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream().wait_stream(cls._side)     # their operands may be freed now
             cls._inflight = []
-        _LAZY_PENDING.clear()
 
     @classmethod
     def side_stream(cls):
@@ -1741,6 +1754,7 @@ def attention_res(qkv, x, tiles, pre=None):
 
 _FOLD_BWD_ROWS = []       # fix-ups of the backward pass in flight: (g, gb, wp, wv, bv, dwp, dbp, C) device addresses
 _FOLD_BWD_TABLES = {}     # tuple of rows -> device table (addresses are fixed: gradient arena, parameters)
+_FOLD_BWD_TASK = [-1]     # autograd graph task the rows belong to
 
 
 def _fold_bwd_run():
@@ -1790,10 +1804,15 @@ class _FoldProjV(torch.autograd.Function):
                 and sw.available() and sb.available() and dw.is_contiguous() and db.is_contiguous()):
             gw, gbp = sw.take(), sb.take()
             g, gb = dw[2 * C:], db[2 * C:]
+            # rows of a backward pass that did not end (the engine skips the final callbacks when a node raises) belong to no
+            # launch: the first fix-up of every pass (graph task) starts the list and queues that pass's callback
+            task = torch._C._current_graph_task_id()
+            if task != _FOLD_BWD_TASK[0] or not _FOLD_BWD_ROWS:
+                del _FOLD_BWD_ROWS[:]
+                _FOLD_BWD_TASK[0] = task
+                torch.autograd.Variable._execution_engine.queue_callback(_fold_bwd_run)
             _FOLD_BWD_ROWS.append((g.data_ptr(), gb.data_ptr(), wp.data_ptr(), wv.data_ptr(), bv.data_ptr(), gw.data_ptr(),
                                    gbp.data_ptr(), C))
-            if len(_FOLD_BWD_ROWS) == 1:
-                torch.autograd.Variable._execution_engine.queue_callback(_fold_bwd_run)
             return dw, db, gw, gbp, None, None
         # gradients that are ordinary tensors (no arena, or the weight gradient ran eagerly): the same chain rule in torch
         WgradBatch.flush()

@@ -1754,7 +1754,7 @@ def attention_res(qkv, x, tiles, pre=None):
 
 _FOLD_BWD_ROWS = []       # fix-ups of the backward pass in flight: (g, gb, wp, wv, bv, dwp, dbp, C) device addresses
 _FOLD_BWD_TABLES = {}     # tuple of rows -> device table (addresses are fixed: gradient arena, parameters)
-_FOLD_BWD_TASK = [-1]     # autograd graph task the rows belong to
+_FOLD_BWD_TASK = [-1, None]     # autograd graph task the rows belong to, their device
 
 
 def _fold_bwd_run():
@@ -1771,13 +1771,13 @@ def _fold_bwd_run():
             raise RuntimeError('attention fold: run one eager training step before graph capture')
         dt = np.dtype([('g', '<i8'), ('gb', '<i8'), ('wp', '<i8'), ('wv', '<i8'), ('bv', '<i8'), ('dwp', '<i8'), ('dbp', '<i8'),
                        ('gs', '<i8'), ('C', '<i4'), ('pad', '<i4')])
-        scratch = torch.empty((sum(r[7] * r[7] + r[7] for r in rows),), dtype=torch.float32, device='cuda')
+        scratch = torch.empty((sum(r[7] * r[7] + r[7] for r in rows),), dtype=torch.float32, device=_FOLD_BWD_TASK[1])
         offs, off = [], 0
         for r in rows:
             offs.append(scratch.data_ptr() + 4 * off)
             off += r[7] * r[7] + r[7]
         host = np.array([r[:7] + (o, r[7], 0) for r, o in zip(rows, offs)], dtype=dt)
-        tab = (torch.from_numpy(host.view(np.uint8).reshape(len(rows), -1).copy()).cuda(), scratch)
+        tab = (torch.from_numpy(host.view(np.uint8).reshape(len(rows), -1).copy()).to(scratch.device), scratch)
         _FOLD_BWD_TABLES[rows] = tab
     call('idf_attn_fold_bwd_batched', tab[0].data_ptr(), len(rows), max(r[7] for r in rows), _st())
 
@@ -1809,7 +1809,7 @@ class _FoldProjV(torch.autograd.Function):
             task = torch._C._current_graph_task_id()
             if task != _FOLD_BWD_TASK[0] or not _FOLD_BWD_ROWS:
                 del _FOLD_BWD_ROWS[:]
-                _FOLD_BWD_TASK[0] = task
+                _FOLD_BWD_TASK[0], _FOLD_BWD_TASK[1] = task, wp.device
                 torch.autograd.Variable._execution_engine.queue_callback(_fold_bwd_run)
             _FOLD_BWD_ROWS.append((g.data_ptr(), gb.data_ptr(), wp.data_ptr(), wv.data_ptr(), bv.data_ptr(), gw.data_ptr(),
                                    gbp.data_ptr(), C))

@@ -1753,9 +1753,8 @@ void launch(C3P& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.main_blocks + p.aux_blocks), dim3(NWM * 128), lds, st, p);
 }
 
-template <int TM, int NWM, int KS>
+template <int TM, int NWM, int KS, int BN = 64>
 void launch_gnb(C3P& p, hipStream_t st) {
-  constexpr int BN = 64;
   size_t lds = ((size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2)) + KS * KS * BN) * 64;
   size_t olds = (size_t)NWM * TM * 16 * (BN + 4) * sizeof(float);      // epilogue tile
   if (olds > lds) lds = olds;
@@ -2118,10 +2117,19 @@ extern "C" int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void*
   p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
   p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
   hipStream_t st = (hipStream_t)stream;
+  // whole-image tiles of 64 couts are B * Cout / 64 workgroups -- 64 or 128 of them at the benchmark's batch on 256 CUs: 32-cout
+  // tiles (complete GroupNorm groups still: 32 % (Cout / 32) == 0) double the grid while it stays under one workgroup per CU
+  // (IDF_GNB_BN32=0: off; profiles/r04_conv_wr.txt)
+  static const int bn32 = getenv("IDF_GNB_BN32") ? atoi(getenv("IDF_GNB_BN32")) : 1;
+  const int cpg = Cout >> 5;
+  const bool half = bn32 && BM == 256 && (long)B * (Cout / 64) < 256 && cpg >= 1 && cpg <= 32 && 32 % cpg == 0;
+  if (half) p.n_tiles = Cout / 32;
   if (taps == 9) {
-    if (BM == 256) launch_gnb<4, 4, 3>(p, st); else if (BM == 128) launch_gnb<4, 2, 3>(p, st); else launch_gnb<2, 2, 3>(p, st);
+    if (half) launch_gnb<4, 4, 3, 32>(p, st);
+    else if (BM == 256) launch_gnb<4, 4, 3>(p, st); else if (BM == 128) launch_gnb<4, 2, 3>(p, st); else launch_gnb<2, 2, 3>(p, st);
   } else {
-    if (BM == 256) launch_gnb<4, 4, 1>(p, st); else if (BM == 128) launch_gnb<4, 2, 1>(p, st); else launch_gnb<2, 2, 1>(p, st);
+    if (half) launch_gnb<4, 4, 1, 32>(p, st);
+    else if (BM == 256) launch_gnb<4, 4, 1>(p, st); else if (BM == 128) launch_gnb<4, 2, 1>(p, st); else launch_gnb<2, 2, 1>(p, st);
   }
   IDF_CHECK_LAUNCH();
   return IDF_OK;

@@ -62,7 +62,8 @@ def make_args(a):
 # 4.7-5.8 / 0.31 (profiles/r04_cpu_baseline_threads.txt, tools/cpu_threads_sweep.sh); 64 threads 8.7-10, 128 threads 18-25
 # (profiles/r03_cpu_baseline_threads.txt).  16 is the fastest measured: the default.  IDF_CPU_THREADS overrides for a sweep
 CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '16'))
-CPU_BATCH = 32        # the benchmarked batch, 1 warm-up + 3 timed steps; then 3 backbone evaluations
+CPU_BATCH = 32        # the benchmarked batch, CPU_WARMUP warm-ups + 3 timed steps; then 3 backbone evaluations
+CPU_WARMUP = 3        # the series is still falling at step 4 with one warm-up (round-4 verdict)
 
 
 def cpu_baseline_worker(a_dim, out_path):
@@ -88,7 +89,7 @@ def cpu_baseline_worker(a_dim, out_path):
     g = torch.Generator(device='cpu')
     g.manual_seed(64)
     B = CPU_BATCH
-    for it in range(4):
+    for it in range(CPU_WARMUP + 3):
         x = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
         t0 = time.time()
         idx = torch.randint(0, 1000, (B,))
@@ -140,13 +141,17 @@ def cpu_baseline(margs, budget_s=240):
     if not train:
         return {'value': None, 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
                 'sample': 'CPU oracle did not finish one B=%d step within %d s' % (CPU_BATCH, budget_s)}
-    timed = train[1:] if len(train) > 1 else train
+    # the first steps are still warming (allocator, thread pools: 6.5, 4.6, 3.8, 3.0 s in profiles/r04_cpu_baseline_threads.txt):
+    # CPU_WARMUP of them are dropped, the mean of the rest is the baseline
+    timed = train[CPU_WARMUP:] if len(train) > CPU_WARMUP else train[-1:]
     t = sum(timed) / len(timed)
     res = {'value': round(CPU_BATCH / t, 3), 'unit': 'images/s', 'cores': CPU_THREADS, 'kind': 'port',
            'sample': 'CPU oracle (fp32 NCHW stock-ATen restatement of the reference), CelebA 64x64 train step '
                      '(fwd+bwd+clip+AdamW, dropout on) at B=%d on %d threads (host has %d cores; ATen convs do not scale '
-                     'past a few dozen threads: profiles/r04_cpu_baseline_threads.txt): %d timed step(s) after 1 warm-up, '
-                     '%.2f s/step' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0, len(timed), t)}
+                     'past a few dozen threads: profiles/r04_cpu_baseline_threads.txt): %d timed step(s) after %d warm-ups, '
+                     '%.2f s/step (every step: %s s)' % (CPU_BATCH, CPU_THREADS, os.cpu_count() or 0, len(timed),
+                                                         min(CPU_WARMUP, len(train) - len(timed)), t,
+                                                         ' '.join('%.2f' % v for v in train))}
     if len(evals) > 1:
         te = sum(evals[1:]) / len(evals[1:])
         res['sampling'] = {'value': round(CPU_BATCH / (100 * te), 4), 'unit': 'images/s',
@@ -649,6 +654,7 @@ def main():
     if world > 1:
         dist.barrier()
 
+    sampler_capture_failed = False
     if not a.no_sampling:
         # second headline metric (BASELINE configs[2]): DDIM-100 sampling, B = 256 per GPU.  The image batch is
         # sharded over the ranks with NO data-path collective; the barrier / MAX below only bracket the timing.
@@ -661,21 +667,35 @@ def main():
         smodel = InfoDiff(sargs, dev, (3, 64, 64)).eval()
         proc = DiffusionProcess(sargs, smodel, dev, (3, 64, 64))
         proc.sampling(8)
+        small_stats = dict(proc.graph_stats)
+        # the reference's eval flows sample batch after batch (run.py:255-259, 284-287): the step graph of a batch shape is captured by
+        # the first batch and replayed by the following ones -- the timed batch is such a following one
+        proc.sampling(a.sampling_batch)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        before = dict(proc.graph_stats)
         t0 = time.time()
         proc.sampling(a.sampling_batch)
         torch.cuda.synchronize()
         ds = time.time() - t0
+        big_stats = {k: proc.graph_stats[k] - before[k] for k in before}
         if world > 1:
             tmax = torch.tensor([ds], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             ds = float(tmax)
         out['sampling'] = {'metric': 'DDIM-100 sampling images/sec (B=%d per GPU, 100 network evaluations, batch '
-                                     'sharded over the GPUs, no collective)' % a.sampling_batch,
+                                     'sharded over the GPUs, no collective; steady state of batch-after-batch sampling: the '
+                                     'step graph was captured by the preceding, untimed batch of the same shape)' % a.sampling_batch,
                            'value': round(a.sampling_batch * world / ds, 2), 'unit': 'images/s', 'n_gpus': world,
-                           'seconds': round(ds, 3)}
+                           'seconds': round(ds, 3),
+                           # inner steps replayed from a captured step (98 of the 100: first and last run eagerly)?
+                           'graphed': big_stats['replays'] > 0 and proc.graph_stats['fallback'] == 0,
+                           'graph_stats': {'warmup_b8': small_stats, 'timed_batch': big_stats}}
+        if proc.graph_stats['fallback']:
+            # a capture the sampler expected to work fell back to eager stepping: a product defect, not a number to report
+            print('bench: the sampler\'s step capture FAILED (%r)' % (proc.graph_stats,), file=sys.stderr)
+            sampler_capture_failed = True
         del proc, smodel
         torch.cuda.empty_cache()
 
@@ -704,6 +724,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if sampler_capture_failed:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

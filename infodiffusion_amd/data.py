@@ -43,9 +43,9 @@ class _Batches:
         mode = getattr(args, 'mode', 'train')
         self.shuffle = args.dataset in ('cifar10', 'dsprites', 'chairs') or (
             args.dataset == 'celeba' and mode in ('attr_classification', 'eval_fid', 'reconstruction'))
-        # RandomHorizontalFlip is part of the CelebA / FFHQ transform in every mode (data.py:165-166 `do_augment` defaults
-        # to True and no caller clears it; :237)
-        self.augment = args.dataset in ('celeba', 'ffhq')
+        # RandomHorizontalFlip is part of the fmnist (data.py:138), CelebA (:165-166: `do_augment` defaults to True and no caller
+        # clears it), cifar10 (:191), chairs (:224) and FFHQ (:237) transforms in every mode; mnist and dsprites have none
+        self.augment = args.dataset in ('celeba', 'ffhq', 'fmnist', 'cifar10', 'chairs')
 
     def __len__(self):
         return self.n
@@ -84,16 +84,19 @@ class _Batches:
                 lo = (i * self.world + self.rank) * self.bs
                 rows = self.array[lo:lo + self.bs] if perm is None else self.array[np.sort(perm[lo:lo + self.bs])]
                 a = torch.from_numpy(np.ascontiguousarray(rows))
+                flip = (torch.rand(self.bs, generator=g) < 0.5) if self.augment else None      # one draw per image, every path
                 if a.dtype == torch.uint8 and torch.device(self.device).type == 'cuda':
                     # bytes cross PCIe; ToTensor / RandomHorizontalFlip / Normalize run on the GPU (idf_prep_u8)
                     from . import ops
-                    flip = (torch.rand(self.bs, generator=g) < 0.5).to(torch.uint8) if self.augment else None
+                    flip = flip.to(torch.uint8) if flip is not None else None
                     x = ops.prep_u8(a.pin_memory().to(self.device, non_blocking=True), flip)
                     yield (x, torch.zeros(self.bs, dtype=torch.long))
                     continue
                 if a.dtype == torch.uint8:
                     a = a.permute(0, 3, 1, 2).float() / 255.0
                 x = (a.float() - 0.5) / 0.5
+                if flip is not None:             # float arrays / CPU batches: the same transform, NCHW (flip = reverse the columns)
+                    x = torch.where(flip[:, None, None, None], x.flip(3), x)
             yield (x, torch.zeros(self.bs, dtype=torch.long))
 
 

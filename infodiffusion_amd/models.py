@@ -128,7 +128,11 @@ class _UNetSkeleton(nn.Module):
                 h = block_call(layer, (h, skips.pop()))      # the block reads the pair in place (no torch.cat)
         assert len(skips) == 0
         gn, conv = self.tail[0], self.tail[-1]
-        return ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias, x_single_use=True)
+        y = ops.fused_conv(h, conv.weight, conv.bias, self._cfg_tail, gn.weight, gn.bias, x_single_use=True)
+        # blocks that met their kernels for the first time asked for other weight layouts (fragment-major shadows, the attention
+        # fold): pack them now, so that the NEXT pass -- possibly a captured one -- runs the steady-state kernels on settled tables
+        self._shadow_set.settle(self.ctx.act_dtype, torch.is_grad_enabled())
+        return y
 
 
 _WGRAD_POINT_MAXW = int(os.environ.get('IDF_WGRAD_POINT_MAXW', '16'))
@@ -360,11 +364,22 @@ class InfoDiff(nn.Module):
         self._dp_sync = sync if (sync is not None and sync.attach(self.backbone)) else None
         self.cut_latent = self._dp_sync is not None and self.kld_weight == 0
         self._latent_cut = None
+        self._cut_armed = False
         return self.cut_latent
 
+    def arm_latent_cut(self):
+        """The cut is PER CALL: only the forward pass that follows this request detaches the latent (and its caller must
+        `pop_latent_cut()` and continue the backward pass into the encoder: trainer.GraphedTrainStep).  Every other caller --
+        a plain `loss_fn(...).backward()`, a validation pass with gradients, the tools -- gets the single-backward graph."""
+        if getattr(self, '_latent_cut', None) is not None:
+            raise RuntimeError('InfoDiff: the previous latent cut was never popped (its encoder backward pass did not run)')
+        self._cut_armed = bool(getattr(self, 'cut_latent', False))
+        return self._cut_armed
+
     def pop_latent_cut(self):
-        """(latent as the encoder produced it, the leaf that replaced it downstream) of the last forward pass, or None."""
+        """(latent as the encoder produced it, the leaf that replaced it downstream) of the last armed forward pass, or None."""
         cut, self._latent_cut = getattr(self, '_latent_cut', None), None
+        self._cut_armed = False
         return cut
 
     def _draw_idx(self, n):
@@ -442,7 +457,8 @@ class InfoDiff(nn.Module):
         else:
             a_q = a
         lat = a_q if use_q else a
-        if getattr(self, 'cut_latent', False) and torch.is_grad_enabled() and lat.requires_grad:
+        if getattr(self, '_cut_armed', False) and torch.is_grad_enabled() and lat.requires_grad:
+            self._cut_armed = False
             # data parallel (kld_weight == 0, so lat is a): the latent enters the backbone AND the loss (the MMD term
             # reads the returned `a`) as a leaf; whoever runs the backward pass (trainer.GraphedTrainStep) continues
             # from `leaf.grad` into the encoder once the backbone's share of the gradient exchange is on the wire
@@ -452,6 +468,8 @@ class InfoDiff(nn.Module):
         elif torch.is_grad_enabled() and lat.requires_grad:
             lat = ops.wgrad_point(lat)       # the backbone's backward is through: its weight gradients run beside the encoder's
         output = self.backbone(x_tilde, idx, lat)
+        if getattr(self, '_shadow_all', None) is not None:
+            self._shadow_all.settle(self.backbone.ctx.act_dtype, torch.is_grad_enabled())
         return (output, epsilon, a, mu, log_var) if get_target else output
 
 

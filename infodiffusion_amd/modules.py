@@ -41,6 +41,7 @@ class _Shadows:
     def __init__(self, *convs):
         self.convs = convs
         self.key = None
+        self.owners = []            # the ShadowSets that re-pack this shadow: told when its layout state changes mid-forward
         self.val = [None, None, None, None]      # forward, data-gradient, [fragment-major forward / data-gradient: want_frag]
         # the image-resident ResBlock kernel (ops.resblock_small) reads its weights fragment-major; a conv it has met once
         # gets that third shadow from the next re-pack on
@@ -88,6 +89,13 @@ class _Shadows:
             bf[C:2 * C].copy_(bk)
             bf[2 * C:].copy_(wp.view(C, C) @ bv + bp)
 
+    @staticmethod
+    def _new(shape, dtype, dev):
+        if torch.cuda.is_current_stream_capturing():
+            # a buffer allocated now would live in the capture's private pool and die with the graph
+            raise RuntimeError('ShadowSet: run one eager forward before graph capture')
+        return torch.empty(shape, dtype=dtype, device=dev)
+
     def ensure_buffers(self, dtype, need_dgrad):
         O = sum(c.weight.shape[0] for c in self.convs)
         _, I, kh, kw = self.convs[0].weight.shape
@@ -97,17 +105,17 @@ class _Shadows:
                 continue
             v = self.val[j]
             if v is None or v.dtype != dtype or v.device != dev:
-                self.val[j] = torch.empty(shape, dtype=dtype, device=dev)
+                self.val[j] = self._new(shape, dtype, dev)
                 self.key = None
         if self.want_sub and dtype == torch.bfloat16 and O % 16 == 0 and I % 64 == 0 and (kh, kw) == (3, 3) and (
                 self.sub is None or self.sub.device != dev):
-            self.sub = torch.empty((O * 16 * I,), dtype=dtype, device=dev)
-            self.subd = torch.empty((O * 16 * I,), dtype=dtype, device=dev) if (O % 64 == 0 and I % 16 == 0) else None
+            self.sub = self._new((O * 16 * I,), dtype, dev)
+            self.subd = self._new((O * 16 * I,), dtype, dev) if (O % 64 == 0 and I % 16 == 0) else None
             self.key = None
         if self.want_frag:
             for j, fits, on in ((2, O % 16 == 0 and I % 64 == 0, True), (3, I % 16 == 0 and O % 64 == 0, need_dgrad)):
                 if fits and on and (self.val[j] is None or self.val[j].dtype != dtype or self.val[j].device != dev):
-                    self.val[j] = torch.empty((O * kh * kw * I,), dtype=dtype, device=dev)
+                    self.val[j] = self._new((O * kh * kw * I,), dtype, dev)
                     self.key = None
 
     def request_frag(self):
@@ -120,6 +128,13 @@ class _Shadows:
         if not self.want_frag and (plain or qkv) and O % 16 == 0 and w.shape[1] % 16 == 0:
             self.want_frag = True
             self.key = None
+            self.touch()
+
+    def touch(self):
+        """The set of shadows / pack sources changed while a forward pass was running: the owning networks re-pack at the END of
+        that pass (`ShadowSet.settle`), so the next pass -- the one a sampler or trainer may capture -- finds nothing stale."""
+        for o in self.owners:
+            o.dirty = True
 
     def stale(self, dtype, need_dgrad):
         if self.want_sub and self.sub is None and dtype == torch.bfloat16:
@@ -185,14 +200,23 @@ class ShadowSet:
                 if isinstance(sh, _Shadows) and id(sh) not in seen:
                     seen.add(id(sh))
                     self.items.append(sh)
+                    sh.owners.append(self)
+        self.dirty = False          # a shadow changed its layout state during a forward pass (see _Shadows.touch)
         self.tkey = None
         self.table = None
         self.pinned = None
         self.up_key = None          # the UpSample convs' summed sub-pixel weights: their own table, one more launch
         self.up_table = None
 
-    def refresh(self, dtype, need_dgrad):
-        if not any(s.stale(dtype, need_dgrad) for s in self.items):
+    def settle(self, dtype, need_dgrad):
+        """End of a forward pass: if a block switched a shadow's layout state during the pass (fragment-major request, the
+        attention fold), re-pack NOW -- tables and buffers are (re)built outside any capture, and the next pass starts clean."""
+        if self.dirty and not torch.cuda.is_current_stream_capturing():
+            self.dirty = False
+            self.refresh(dtype, need_dgrad, force=True)       # the table too, even if another set has re-packed the shadows
+
+    def refresh(self, dtype, need_dgrad, force=False):
+        if not force and not any(s.stale(dtype, need_dgrad) for s in self.items):
             return
         import numpy as np
         for s in self.items:
@@ -401,9 +425,12 @@ class AttnBlock(nn.Module):
             if sh.fold is not None:
                 sh.srcs = sh.fold = None
                 sh.key = None
+                sh.touch()
                 self._cfg_qkv.pop('bias_values', None)
             return
         if sh.fold is None or sh.fold[6].device != dev:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('AttnBlock: run one eager forward before graph capture')
             C = self.proj.weight.shape[0]
             wvf = torch.empty((C, C, 1, 1), dtype=torch.float32, device=dev)
             bf = torch.empty((3 * C,), dtype=torch.float32, device=dev)
@@ -411,6 +438,7 @@ class AttnBlock(nn.Module):
             sh.fold = (self.proj.weight, self.proj.bias, self.proj_v.weight, self.proj_v.bias, self.proj_q.bias, self.proj_k.bias,
                        wvf, bf)
             sh.key = None
+            sh.touch()
             self._cfg_qkv['bias_values'] = bf
 
     def forward(self, x):

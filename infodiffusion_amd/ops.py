@@ -1513,6 +1513,8 @@ class _ResBlockSmall(torch.autograd.Function):
             dx, dgw, dgb, _, _ = conv_dgrad_gn_raw(g, w_dgrad, x, gw, gb, None, None, mean, rstd, sc, sh, None,
                                                    cfgs[0]['salt'], 0.0, 2, 9, (gws, gbs), dres, dskip, shadows=cfgs[0]['shadows'])
         else:
+            # a skip pair never hands out a passthrough alias (models._UNetSkeleton._run): a gradient arriving on one would be lost
+            assert dskip is None, 'resblock_small: a two-source block entry cannot carry a passthrough alias'
             sw, sb = tensors[4 * n], tensors[4 * n + 1]
             sws, sbs = slots[4 * n], slots[4 * n + 1]
             dx, dx2, dgw, dgb, dsW, dsb = _entry_cat_bwd(x, x2, g, ds, gw, gb, mean, rstd, sc, sh, cfgs[0], meta['cfg_sc'],
@@ -1558,12 +1560,14 @@ def _entry_cat_bwd(x1, x2, dh, ds, gn_w, gn_b, mean, rstd, sc, sh, cfg, cfg_sc, 
 
 def resblock_small(x, x2, stages, shortcut, film_t, film_a, film_stage, seed, p_drop, drop, want_alias):
     """stages = [(conv, gn, cfg)] (2 or 3), shortcut = (conv, cfg) or None.  -> y (statistics attached) [, alias of x]."""
-    train = torch.is_grad_enabled() and (x.requires_grad or (x2 is not None and x2.requires_grad))
     tensors, slots = [], []
     for conv, gn, _ in stages:
         tensors += [conv.weight, conv.bias, gn.weight, gn.bias]
     if shortcut is not None:
         tensors += [shortcut[0].weight, shortcut[0].bias]
+    # anything that will ask this node for a gradient -- the block input OR only its weights (frozen prefix, fine-tuning the
+    # deepest blocks) OR the conditioning -- needs the forward launch to keep a / mean / rstd / sc / sh
+    train = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, x2, film_t, film_a, *tensors))
     if torch.is_grad_enabled():
         slots = [slot_of(t) for t in tensors]
     else:

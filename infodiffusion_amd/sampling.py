@@ -21,8 +21,10 @@ from . import ops
 _DDPM, _DDIM, _REV = 0, 1, 2
 ETA = 0.01     # sampling.py:45
 GRAPH = os.environ.get('IDF_SAMPLER_GRAPH', '1') != '0'
+STRICT_GRAPH = os.environ.get('IDF_SAMPLER_GRAPH_STRICT', '0') != '0'     # a failed capture raises instead of stepping eagerly
 GRAPH_MIN_STEPS = 8
-GRAPH_MAX_PIXELS = int(os.environ.get('IDF_SAMPLER_GRAPH_MAXPIX', 64 * 64 * 64))   # batch x H x W up to which a step is launch-bound (64 CelebA images)
+GRAPH_MAX_PIXELS = int(os.environ.get('IDF_SAMPLER_GRAPH_MAXPIX', 256 * 64 * 64))   # batch x H x W up to which a step is replayed (256 CelebA images:
+                                                                                     # 5.5 % of an eagerly issued B = 256 step is host gap)
 
 
 def _tables(args, device):
@@ -43,6 +45,9 @@ class _ProcessBase:
         self.model = args.model
         self.device = device
         self._steps = torch.arange(len(self.alpha_bars), dtype=torch.long, device=device)
+        # what the loops did with their inner steps: captures that worked, captures that fell back to eager stepping, replays
+        self.graph_stats = {'captured': 0, 'fallback': 0, 'replays': 0}
+        self._graphs = {}
         self._coef = ops.sampler_coef_table(self.betas, self.alphas, self.alpha_bars, self.alpha_prev_bars, ETA)
 
     # hooks (tests override to inject the reference's noise draws)
@@ -83,14 +88,33 @@ class _ProcessBase:
         return steps >= GRAPH_MIN_STEPS and x.shape[0] * per <= GRAPH_MAX_PIXELS \
             and not torch.cuda.is_current_stream_capturing()
 
-    def _graphed(self, x, eps_fn, mode, first, delta, count):
+    def _graphed(self, x, eps_fn, mode, first, delta, count, eps_of=None, a=None):
         """Generator over `count` steps idx = first, first+delta, ...: the step is captured once and replayed.
-        x must come from an eagerly executed step (weight shadows / allocator already warm)."""
+        x must come from an eagerly executed step (weight shadows / allocator already warm).
+        eps_of(a) -> eps_fn: given, the captured step reads the latent from a buffer of its own and the graph is kept for the
+        next call with the same shapes (the reference's eval flows sample batch after batch: run.py:255-259, 284-287)."""
+        key = (mode, first, delta, count, tuple(x.shape), None if a is None else tuple(a.shape))
+        ent = self._graphs.get(key) if eps_of is not None else None
+        if ent is not None:
+            xs, idx_t, a_s, g = ent
+            xs.copy_(x)
+            idx_t.fill_(first)
+            if a_s is not None:
+                a_s.copy_(a)
+            for _ in range(count):
+                g.replay()
+                self.graph_stats['replays'] += 1
+                yield xs.clone()
+            return
         xs = x.float().clone()
         if xs.dim() == 4:
             xs = xs.contiguous(memory_format=torch.channels_last)
         idx_t = torch.full((1,), first, dtype=torch.long, device=xs.device)
         n = xs.shape[0]
+        a_s = None
+        if eps_of is not None:
+            a_s = a.clone() if a is not None else None
+            eps_fn = eps_of(a_s)
 
         def body():
             t = idx_t.expand(n).contiguous()
@@ -113,20 +137,29 @@ class _ProcessBase:
             torch.cuda.synchronize()
             g = None
             idx_t.fill_(first)
+            self.graph_stats['fallback'] += 1
+            if STRICT_GRAPH:
+                raise
+        else:
+            self.graph_stats['captured'] += 1
+            if eps_of is not None:
+                self._graphs.clear()            # one resident graph (its private pool holds a network evaluation's activations)
+                self._graphs[key] = (xs, idx_t, a_s, g)
         for _ in range(count):
             if g is not None:
                 g.replay()
+                self.graph_stats['replays'] += 1
             else:
                 body()
             yield xs.clone()
 
-    def _loop(self, x, eps_fn, deterministic):
+    def _loop(self, x, eps_fn, deterministic, eps_of=None, a=None):
         T = len(self.alpha_bars)
         mode = _DDIM if deterministic else _DDPM
         graphed = self._graph_ok(x, T - 2)
         for idx in reversed(range(T)):
             if graphed and idx == T - 2:
-                for x in self._graphed(x, eps_fn, mode, idx, -1, T - 2):      # steps T-2 ... 1
+                for x in self._graphed(x, eps_fn, mode, idx, -1, T - 2, eps_of, a):      # steps T-2 ... 1
                     yield x
             if graphed and 0 < idx < T - 1:
                 continue
@@ -177,7 +210,7 @@ class DiffusionProcess(_ProcessBase):
         return self._reverse_loop(x, self._eps(a))
 
     def _one_diffusion_step(self, sample, a=None, deterministic=False):
-        return self._loop(sample, self._eps(a), bool(deterministic))
+        return self._loop(sample, self._eps(a), bool(deterministic), self._eps, a)
 
     @torch.no_grad()
     def reverse_sampling(self, x0, a=None):

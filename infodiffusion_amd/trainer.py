@@ -57,6 +57,8 @@ class GraphedTrainStep:
         ops.WgradBatch.reset()          # nothing of an earlier, aborted backward pass may leak into this one
         if self.sync is not None:
             self.sync.begin_step()
+        if self.split:
+            self.model.arm_latent_cut()         # this call only: nobody else's forward pass is cut at the latent
         loss = self.model.loss_fn(args=self.args, x=x, curr_epoch=epoch)
         cut = self.model.pop_latent_cut() if self.split else None
         self.opt.zero_grad()

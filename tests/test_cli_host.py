@@ -54,6 +54,27 @@ def test_synthetic_batches_are_normalised_and_sharded():
     assert not torch.equal(b0[0], b1[0])
 
 
+def test_flip_augmentation_follows_the_reference_transforms(tmp_path):
+    """RandomHorizontalFlip is in the reference's fmnist / celeba / cifar10 / chairs / ffhq transforms (data.py:138, 166, 191,
+    224, 237) and absent from mnist / dsprites (:125, :203-207); float arrays and CPU batches are flipped like uint8 ones."""
+    import numpy as np
+    from infodiffusion_amd.data import get_dataset
+    n = 64
+    ramp = np.tile(np.linspace(0.0, 1.0, 8, dtype=np.float32), (n, 1, 8, 1))        # every row of every image rises left -> right
+    for ds, flips in (('fmnist', True), ('cifar10', True), ('chairs', True), ('celeba', True), ('ffhq', True),
+                      ('mnist', False), ('dsprites', False)):
+        ch = 3 if ds in ('cifar10', 'chairs', 'celeba', 'ffhq') else 1
+        np.save(tmp_path / ('%s.npy' % ds), np.repeat(ramp, ch, axis=1))
+        a = types.SimpleNamespace(dataset=ds, batch_size=n, steps_per_epoch=1, data_dir=str(tmp_path), r_seed=3, mode='train')
+        (x, _), = list(get_dataset(a, (ch, 8, 8), 'cpu'))
+        rising = (x[:, 0, 0, -1] > x[:, 0, 0, 0])
+        assert x.shape == (n, ch, 8, 8) and float(x.min()) == -1.0 and float(x.max()) == 1.0
+        if flips:
+            assert 8 < int(rising.sum()) < n - 8, (ds, int(rising.sum()))          # about half the images are mirrored
+        else:
+            assert bool(rising.all()), ds
+
+
 def test_save_original_img_mode_runs_without_a_gpu(tmp_path):
     """--mode save_original_img (reference run.py:540-549): dataset images in [0, 1], no model involved."""
     import glob
@@ -79,6 +100,7 @@ def test_save_original_img_mode_runs_without_a_gpu(tmp_path):
     # each saved image is one of the source images, every source image is saved exactly once
     allimgs = np.concatenate([np.load(f) for f in files])
     src = raw.transpose(0, 3, 1, 2) / 255.0
-    match = [int(np.argmin([np.abs(im - s_).max() for s_ in src])) for im in allimgs]
+    # ... possibly mirrored: the reference's fmnist transform carries RandomHorizontalFlip (data.py:138) in every mode
+    match = [int(np.argmin([min(np.abs(im - s_).max(), np.abs(im[..., ::-1] - s_).max()) for s_ in src])) for im in allimgs]
     assert sorted(match) == list(range(8))
-    assert all(np.allclose(im, src[j], atol=1e-6) for im, j in zip(allimgs, match))
+    assert all(np.allclose(im, src[j], atol=1e-6) or np.allclose(im[..., ::-1], src[j], atol=1e-6) for im, j in zip(allimgs, match))

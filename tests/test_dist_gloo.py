@@ -133,19 +133,27 @@ def _trainer_worker(rank, world, port, q):
             self.encoder = torch.nn.Linear(4, 4)
             self.cut_latent = False
             self._latent_cut = None
+            self._cut_armed = False
             self.calls = []
 
         def attach_grad_sync(self, sync):
             self.cut_latent = bool(sync.attach(self.backbone))
             return self.cut_latent
 
+        def arm_latent_cut(self):           # the product's protocol (models.InfoDiff): the cut is per call
+            assert self._latent_cut is None
+            self._cut_armed = self.cut_latent
+            return self._cut_armed
+
         def pop_latent_cut(self):
             cut, self._latent_cut = self._latent_cut, None
+            self._cut_armed = False
             return cut
 
         def loss_fn(self, args, x, curr_epoch=0):
             lat = self.encoder(x)
-            if self.cut_latent:
+            if self._cut_armed:
+                self._cut_armed = False
                 leaf = lat.detach().requires_grad_(True)
                 self._latent_cut = (lat, leaf)
                 lat = leaf

@@ -1013,6 +1013,17 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
         got, st = run(True)
         # three graphs, the middle one being the encoder's backward pass behind the latent cut
         assert st.split and isinstance(st.graph, tuple) and len(st.graph) == 3 and st.graph[1] is not None
+        # the cut is per call (trainer arms it): any OTHER caller of the attached model -- a plain loss_fn().backward(), a
+        # validation pass with gradients, the tools -- still gets ONE backward pass that reaches the encoder
+        m = st.model
+        assert m.cut_latent and m._latent_cut is None
+        for p_ in m.parameters():
+            p_.grad = None
+        with _ReplayedDraws(g):
+            m.loss_fn(args_of(cfg), x).backward()
+        assert m._latent_cut is None
+        enc = [p_.grad for n_, p_ in m.named_parameters() if n_.startswith('encoder.head.') or n_.startswith('encoder.fc_a.')]
+        assert enc and all(gr is not None and float(gr.abs().max()) > 0 for gr in enc)
         tols = [(1e-3, 1e-2)] * 5 if dtype == 'fp32' else [(1e-3, 1e-2), (1e-3, 3e-2)]
         for k, (tl, tn) in enumerate(tols):
             (l0, n0), (l1, n1) = ref[k], got[k]
@@ -1176,6 +1187,53 @@ def test_graphed_sampler_steps_match_eager_steps():
     finally:
         S._ProcessBase._graphed = orig
         S.GRAPH = True
+
+
+def test_graphed_sampler_captures_in_bf16_on_celeba():
+    """The small-batch sampler of the reference's eval / interpolate / disentangle flows (run.py:255-259, 16 images;
+    sampling.py:89-101) in the BENCHMARKED dtype: the inner steps must really be replayed from a captured step -- asserted
+    on the process's own counters, not on the trajectory (a silent eager fallback produces the same trajectory) -- for
+    DDIM, DDPM and the inversion, and the trajectories must equal the eager ones."""
+    import time
+    from infodiffusion_amd import sampling as S
+    from infodiffusion_amd.sampling import DiffusionProcess
+    T, B = 24, 16
+    cfg = O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1, diffusion_steps=T, deterministic=True)
+    model, args, sd = make_infodiff(cfg, DEV, 'bf16')
+    model.eval()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(5)
+    x0 = (torch.rand(B, *cfg.shape, generator=g) * 2 - 1).to(DEV)
+    xT = torch.randn(B, *cfg.shape, generator=g).to(DEV)
+    a = torch.randn(B, 32, generator=g).to(DEV)
+    out, secs = {}, {}
+    try:
+        for graph in (True, False):          # graphed FIRST: the capture must work on a model that has never run
+            S.GRAPH = graph
+            for det in (True, False):
+                args.deterministic = det
+                proc = DiffusionProcess(args, model, DEV, cfg.shape)
+                torch.manual_seed(11)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                out[graph, det] = proc.sampling(xT=xT, a=a)
+                torch.cuda.synchronize()
+                secs[graph, det] = time.time() - t0
+                if graph:
+                    assert proc.graph_stats == {'captured': 1, 'fallback': 0, 'replays': T - 2}, (det, proc.graph_stats)
+                else:
+                    assert proc.graph_stats == {'captured': 0, 'fallback': 0, 'replays': 0}
+            proc = DiffusionProcess(args, model, DEV, cfg.shape)
+            out[graph, 'rev'] = proc.reverse_sampling(x0)
+            if graph:
+                assert proc.graph_stats == {'captured': 1, 'fallback': 0, 'replays': T - 3}, proc.graph_stats
+    finally:
+        S.GRAPH = True
+    for key in ((True, True), (True, False), (True, 'rev')):
+        ref = out[(False,) + key[1:]]
+        assert torch.isfinite(out[key]).all()
+        assert rel(out[key], ref) < 1e-5, (key, rel(out[key], ref))
+    print('DDIM-%d B=%d bf16: graphed %.1f steps/s, eager %.1f steps/s' % (T, B, T / secs[True, True], T / secs[False, True]))
 
 
 def test_kl_capacity_branch_vs_reference():

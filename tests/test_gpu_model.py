@@ -1199,8 +1199,6 @@ def test_graphed_sampler_captures_in_bf16_on_celeba():
     from infodiffusion_amd.sampling import DiffusionProcess
     T, B = 24, 16
     cfg = O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1, diffusion_steps=T, deterministic=True)
-    model, args, sd = make_infodiff(cfg, DEV, 'bf16')
-    model.eval()
     g = torch.Generator(device='cpu')
     g.manual_seed(5)
     x0 = (torch.rand(B, *cfg.shape, generator=g) * 2 - 1).to(DEV)
@@ -1208,7 +1206,12 @@ def test_graphed_sampler_captures_in_bf16_on_celeba():
     a = torch.randn(B, 32, generator=g).to(DEV)
     out, secs = {}, {}
     try:
-        for graph in (True, False):          # graphed FIRST: the capture must work on a model that has never run
+        for graph in (True, False):
+            # a model that has never run, for either arm: the capture must work right behind the first eager step, and both arms
+            # then run the same kernels step for step (a network's first pass uses the layouts it starts with, the later ones the
+            # fragment-major shadows it asked for during the first)
+            model, args, sd = make_infodiff(cfg, DEV, 'bf16')
+            model.eval()
             S.GRAPH = graph
             for det in (True, False):
                 args.deterministic = det

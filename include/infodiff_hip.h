@@ -202,6 +202,26 @@ int idf_conv_wr_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x,
                               uint32_t salt, float p_drop, int B, int H, int W, int Cin, int Cout, void* stream);
 int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
 
+/* ---- the ResBlock 3x3 convs of the 64x64 / 32x32 maps in the "register weights, row reuse" form (round 5, idf_conv_rs.hip):
+ * a 512-thread workgroup per CU walks consecutive 256-pixel x 64-cout tiles; wave = 16 couts, ALL its weights of a 64-channel
+ * pair in registers (fragment-major shadow, never through LDS), the halo image of every channel chunk resident in LDS, each
+ * input row's three shifted fragments used for the three output rows they feed, the next tile's rows in flight during this
+ * tile's MFMAs and epilogue.  Replaces the halo / direct-to-LDS kernels for modules.py:264-268, 283-288, 312-320 (forward) and
+ * their data gradients where idf_conv_rs_tiles() != 0: H = W = 64 with 64 input channels, H = W = 32 with 64 or 128,
+ * Cout % 64 == 0, >= 128 work items.  Same tiles and partial layouts as idf_conv_tiles / idf_conv_dgrad_chain_tiles give.
+ * idf_conv_rs_gn_bf16:           idf_conv_gn_bf16's contract (taps 9, one source, T1 <= 16), w_frag fragment-major forward weights.
+ * idf_conv_rs_dgrad_chain_bf16:  idf_conv_dgrad_chain_bf16's contract with the du epilogue and no dy prologue (taps 9): dy
+ *                                [B,H,W,Cin], w_frag = fragment-major data-gradient weights, x | x2 = the GroupNorm input
+ *                                [B,H,W,Cout] (C1 % 64 == 0), out = du, part_out [B][T][Cout][2]. */
+int idf_conv_rs_tiles(int B, int H, int W, int Cin, int Cout);
+int idf_conv_rs_gn_bf16(const void* x, const float* st1, int T1, const float* gamma, const float* beta, const float* film_t,
+                        const float* film_a, int ld_t, int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt,
+                        float p_drop, const void* w_frag, const float* bias, const void* res, void* y, void* a_out, float* mean,
+                        float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin, int Cout, void* stream);
+int idf_conv_rs_dgrad_chain_bf16(const void* dy, const void* w_frag, const void* x, const void* x2, int C1, const float* sc,
+                                 const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, void* out,
+                                 float* part_out, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* The backward of the same blocks: the data-gradient convs of stages nstage-1 .. first with the GroupNorm / FiLM / SiLU / dropout
  * backward behind each (what idf_conv_wr_dgrad_gn_bf16 computes per stage) in ONE launch, one workgroup per image; every stage
  * has 128 channels.  Stage i: x = its GroupNorm input (h_{i-1}; the block input for stage 0), w_frag = the data-gradient weights

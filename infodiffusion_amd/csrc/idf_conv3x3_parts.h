@@ -69,6 +69,10 @@ struct C3P {
   unsigned ps_magic_img;        // (pix * magic) >> 16 == pix / ps_npi over the tile's halo pixels
   int ps_nptiles, ps_work;      // pixel tiles, work items (= pixel tiles x cout tiles)
   int ps_hbytes;                // bytes of one halo ring slot (whole 1-KB groups)
+  // ---- weights-in-registers row-reuse form (idf_conv_rs.hip): w = the fragment-major shadow; a workgroup walks rs_per consecutive
+  // (cout tile, pixel tile) items of the rs_total; LDS: chunk images | fp32 epilogue tile at rs_os_off | statistics scratch at
+  // aux_off | coefficients at rs_cof_off
+  int rs_per, rs_total, rs_os_off, rs_cof_off;
 #ifdef IDF_PS_DBG
   int ps_dbg;                   // timing-only ablation build (tools/build_variant.sh ... -DIDF_PS_DBG; env IDF_CONV_PS_DBG;
                                 // results are wrong when set): 1 no halo loads after a block's first stage, 2 no MFMAs,

@@ -1,0 +1,446 @@
+// 3x3 stride-1 convolution of the 64x64 / 32x32 maps (bf16 NHWC, gfx950), "register weights, row reuse" form.
+//
+// The ResBlock convs of the big maps -- the GroupNorm-prologue forward conv (modules.py:264-268, 283-288, 312-320) and the
+// data-gradient conv with the `du` epilogue of its backward -- were a chain of phases per 256-pixel tile in the halo kernels
+// (idf_conv3x3.hip): stage 32 channels of the halo tile AND a 36-KB weight slab, barrier, 72 MFMAs per wave, barrier, next
+// chunk ..., epilogue; one block per CU, the block's life 14 us for 2 us of matrix work.  This form removes the per-chunk
+// structure altogether:
+//
+//  * WEIGHTS NEVER TOUCH LDS.  Wave w owns couts 16 (w & 3) .. + 15 of the 64-cout tile and keeps ALL its A fragments of a
+//    64-channel pair -- 9 taps x 2 chunks x 16 B per lane = 72 VGPRs -- in registers, loaded once per workgroup from the
+//    fragment-major shadow (1 KB of consecutive bytes per wave instruction, idf_pack_conv_weights_batched) and kept across the
+//    tiles the workgroup walks.  No weight slab staging, no barrier inside the K loop.
+//  * THE WHOLE K RANGE OF THE TILE IS RESIDENT: the halo image of every 32-channel chunk lies in LDS at once (64-byte pixel rows,
+//    16-byte slots XOR-swizzled by the pixel's column as in idf_conv3x3.hip, so ds_read_b128 of 16 consecutive pixels is
+//    conflict-free and every row / chunk displacement is an instruction immediate).
+//  * ROW REUSE.  A wave's pixels are a 16-pixel-wide column block over all R rows of the tile.  For an input row it reads the
+//    three horizontally shifted B fragments once and uses them for the (up to) three output rows they feed (ky = 0, 1, 2):
+//    (R + 2) * 3 LDS reads per R * 9 MFMAs = 0.5 per MFMA at R = 4, 0.42 at R = 8, with one operand per MFMA in registers.
+//  * PERSISTENT over consecutive tiles of the same cout tile: the next tile's rows are in flight (registers) during this tile's
+//    MFMAs and epilogue and are written into the image right behind the last fragment read; the GroupNorm fold runs once per
+//    image and workgroup with its partial sums fetched AHEAD of the row loads (vmcnt is in order: a fold behind the rows waits
+//    for every row).
+//  * Workgroup barriers order LDS only (`s_waitcnt lgkmcnt(0); s_barrier`): __syncthreads() would drain the prefetch.
+//
+// Epilogues are the halo kernels' (idf_conv3x3_parts.h): the fp32 tile through LDS, full-line stores, statistics partials of
+// the bf16-rounded outputs (forward) or du + (sum du, sum du x) partials (backward chain).  Same tiles (256 pixels = R rows x
+// W), same partial layout [B][H / R][Cout][2], same arithmetic per element: results differ from the halo kernels' only by the
+// summation order inside the MFMA accumulators.
+#include "idf_conv3x3_parts.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int W>
+struct RsGeo {
+  static constexpr int R = 256 / W, WH = W + 2, HR = R + 2, NPH = HR * WH;
+  static constexpr int CHB = NPH * 64 + 64;     // bytes of one 32-channel chunk image; == 64 (mod 128): the two chunks a ds_write_b128
+                                                // lane group covers fall into different halves of the 32 store banks
+  static constexpr int NCB = W / 32;            // 16-pixel column blocks per wave (two pixel halves x NCB x 16 = W)
+  static constexpr int WS = W == 64 ? 6 : 5;
+  static_assert(W == 64 || W == 32, "64x64 / 32x32 maps");
+  static_assert((NPH * 64) % 128 == 0, "chunk image pitch");
+};
+
+// (mean, rstd) of a group from (sum, sum of squares): idf_resblock.hip's group_stats (mu / var in double, 1 / sqrt as v_rsq_f32 +
+// one Newton step in double -- the double-precision divide and square root sequences cost ~1 us in front of the first MFMA)
+__device__ __forceinline__ void rs_group_stats(double a, double d, double inv_n, float eps, float* mean, float* rstd) {
+  const double mu = a * inv_n;
+  double var = d * inv_n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double vd = var + (double)eps;
+  const double r0 = (double)__builtin_amdgcn_rsqf((float)vd);
+  *rstd = (float)(r0 * (1.5 - 0.5 * vd * r0 * r0));
+  *mean = (float)mu;
+}
+
+// EPI: 0 plain (bias, residual, statistics partials of y), 2 the backward chain's du epilogue (idf_conv_dgrad_chain_bf16's)
+template <int W, int CIN, bool PRO, int EPI>
+__global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
+  using G = RsGeo<W>;
+  constexpr int R = G::R, WH = G::WH, HR = G::HR, CHB = G::CHB, NCB = G::NCB, WS = G::WS;
+  constexpr int NT = 512, BM = 256, BN = 64, KP = CIN / 64, NCH = CIN / 32;
+  constexpr int PIECES = CIN / 8, PXK = NT / PIECES, HV = HR * W * PIECES / NT;     // 16-byte vectors per pixel / pixels per round / rounds
+  constexpr bool DUE = EPI == 2;
+  static_assert(CIN == 64 || CIN == 128, "one or two 64-channel pairs");
+  static_assert((HR * W * PIECES) % NT == 0, "whole rounds");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cg = wave & 3, ph = wave >> 2;            // cout group of 16, pixel half
+  const int wgid = xcd_tile_id(blockIdx.x, gridDim.x);
+  int item = wgid * p.rs_per;
+  const int item_end = min(item + p.rs_per, p.rs_total);
+  if (item >= item_end) return;
+  const int npt = p.B * p.tiles_per_img;
+
+  unsigned char* const Os = smem + p.rs_os_off;
+  float* const cof = reinterpret_cast<float*>(smem + p.rs_cof_off);     // PRO: (sc, sh) [CIN][2] | channel sums [CIN][2]
+  float* const chs = cof + 2 * CIN;
+  C3P pe = p;                                          // the epilogue tails address their scratch relative to the fp32 tile
+  pe.aux_off = p.aux_off - p.rs_os_off;
+
+  // ---- this thread's slot in the row staging: vector v = tid + NT * k  ->  pixel (tid / PIECES) + k * PXK of the halo rows'
+  // interior, 8-channel piece tid % PIECES (the same piece in every round: its coefficients stay in registers)
+  const int piece = tid & (PIECES - 1), pbase = tid / PIECES;
+  const int pch = piece >> 2, pq = piece & 3;
+  // ---- this lane's fragment addresses: column blocks x0 = 16 * (NCB * ph + jj), taps kx = 0..2
+  int lp[NCB][3];
+#pragma unroll
+  for (int jj = 0; jj < NCB; ++jj)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int hx = (NCB * ph + jj) * 16 + fr + kx;
+      lp[jj][kx] = hx * 64 + ((fq ^ (((hx >> 2) & 1) << 1)) << 4);
+    }
+
+  int nt = item / npt, pt = item - nt * npt;
+  int b = pt / p.tiles_per_img, oy0 = (pt - b * p.tiles_per_img) * R, n0 = nt * BN;
+
+  // ---- weights: this wave's 16 couts, one 64-channel pair = 18 fragments
+  bf16x8_t Wf[2][9];
+  auto wsrc = [&](int kp, int n16, int c, int tap) __attribute__((always_inline)) -> const bf16x8_t* {
+    return reinterpret_cast<const bf16x8_t*>(p.w + ((size_t)((kp * (p.Cout >> 4) + n16) * 18 + tap * 2 + c) * 64 + lane) * 8);
+  };
+
+  // ---- GroupNorm fold.  Phase 1 (first image of the workgroup): the T1 <= 16 partial sums and this channel's parameters on
+  // their way, every load issued before anything waits (clamped addresses + a 0 / 1 factor: no branch, no per-load wait)
+  struct FoldRegs { float2 fpart[PRO ? 16 : 1]; float fpar[6]; };
+  auto fold_params = [&](int bb, float (&fpar)[6]) __attribute__((always_inline)) {
+    fpar[0] = 1.f; fpar[1] = fpar[2] = fpar[3] = fpar[4] = fpar[5] = 0.f;
+    if (p.gamma) fpar[0] = p.gamma[tid];
+    if (p.beta) fpar[1] = p.beta[tid];
+    if (p.film_t) { fpar[2] = p.film_t[(size_t)bb * p.ld_t + tid]; fpar[3] = p.film_t[(size_t)bb * p.ld_t + CIN + tid]; }
+    if (p.film_a) { fpar[4] = p.film_a[(size_t)bb * p.ld_a + tid]; fpar[5] = p.film_a[(size_t)bb * p.ld_a + CIN + tid]; }
+  };
+  auto fold_issue = [&](int bb, FoldRegs& fr_) __attribute__((always_inline)) {
+    if constexpr (PRO) {
+      if (tid < CIN) {
+        const float2* src = reinterpret_cast<const float2*>(p.st1) + (size_t)bb * p.T1 * CIN + tid;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) fr_.fpart[j] = src[(size_t)min(j, p.T1 - 1) * CIN];
+        fold_params(bb, fr_.fpar);
+      }
+    }
+  };
+  // phase 2: (sc, sh) per channel into LDS (idf_conv3x3_parts.h's pro_coefficients; the sums in idf_sum_partials' order).
+  // fast: the sums come from phase 1's registers; else (the workgroup crosses into another image: rare) a plain loop
+  auto fold_finish = [&](int bb, bool writer, bool fast, FoldRegs& fr_) __attribute__((always_inline)) {
+    if constexpr (PRO) {
+      float (&fpar)[6] = fr_.fpar;
+      float2 (&fpart)[PRO ? 16 : 1] = fr_.fpart;
+      if (tid < CIN) {
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        if (fast) {
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            const float m0 = j < p.T1 ? 1.f : 0.f, m1 = j + 1 < p.T1 ? 1.f : 0.f;
+            s0 += m0 * fpart[j].x; q0 += m0 * fpart[j].y; s1 += m1 * fpart[j + 1].x; q1 += m1 * fpart[j + 1].y;
+          }
+        } else {
+          const float2* src = reinterpret_cast<const float2*>(p.st1) + (size_t)bb * p.T1 * CIN + tid;
+#pragma unroll 1
+          for (int j = 0; j < p.T1; j += 2) {
+            const float2 v0 = src[(size_t)j * CIN], v1 = j + 1 < p.T1 ? src[(size_t)(j + 1) * CIN] : make_float2(0.f, 0.f);
+            s0 += v0.x; q0 += v0.y; s1 += v1.x; q1 += v1.y;
+          }
+          fold_params(bb, fpar);
+        }
+        chs[2 * tid] = s0 + s1; chs[2 * tid + 1] = q0 + q1;
+      }
+      lds_barrier();
+      if (tid < CIN) {
+        constexpr int cpg = CIN >> 5;
+        const int c = tid, g = c / cpg;
+        double a = 0.0, d = 0.0;
+#pragma unroll
+        for (int k = 0; k < cpg; ++k) { a += chs[2 * (g * cpg + k)]; d += chs[2 * (g * cpg + k) + 1]; }
+        float mf, r;
+        rs_group_stats(a, d, 1.0 / ((double)p.H * W * cpg), p.eps, &mf, &r);
+        float sc = r * fpar[0], sh = fpar[1] - mf * sc;
+        if (p.film_t) { const float f = 1.f + fpar[2]; sc *= f; sh = sh * f + fpar[3]; }
+        if (p.film_a) { const float f = 1.f + fpar[4]; sc *= f; sh = sh * f + fpar[5]; }
+        cof[2 * c] = sc; cof[2 * c + 1] = sh;
+        if (writer && p.sc_out) {
+          p.sc_out[(size_t)bb * CIN + c] = sc; p.sh_out[(size_t)bb * CIN + c] = sh;
+          if (c == g * cpg) { p.mean_out[bb * 32 + g] = mf; p.rstd_out[bb * 32 + g] = r; }
+        }
+      }
+      lds_barrier();
+    }
+  };
+
+  // ---- rows of a tile: global -> registers (in flight), registers -> (transform) -> LDS image
+  u32x4_t rows[HV];
+  auto issue_rows = [&](int bb, int oy) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      const int pv = pbase + k * PXK, ly = pv >> WS, px = pv & (W - 1), iy = oy + ly - 1;
+      rows[k] = u32x4_t{0, 0, 0, 0};
+      if ((unsigned)iy < (unsigned)p.H)
+        rows[k] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + px) * CIN + piece * 8));
+    }
+  };
+  uint64_t seedv = 0;
+  bool drop = false;
+  if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
+  auto write_rows = [&](int bb, int oy, bool keep_a) __attribute__((always_inline)) {
+    float scv[8], shv[8];
+    if constexpr (PRO) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * (piece * 8) + 4 * q4);
+        scv[2 * q4] = t4.x; shv[2 * q4] = t4.y; scv[2 * q4 + 1] = t4.z; shv[2 * q4 + 1] = t4.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      const int pv = pbase + k * PXK, ly = pv >> WS, px = pv & (W - 1), iy = oy + ly - 1, hx = px + 1;
+      u32x4_t v = rows[k];
+      if constexpr (PRO) {
+        if ((unsigned)iy < (unsigned)p.H) {            // rows outside the image stay zero (the reference pads the ACTIVATED tensor)
+          const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + px) * CIN + piece * 8);
+          const uint4 a4 = pro_vec<8>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+          v = u32x4_t{a4.x, a4.y, a4.z, a4.w};
+          if (keep_a && ly >= 1 && ly <= R) *reinterpret_cast<u32x4_t*>(p.a_out + e0) = v;
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(smem + pch * CHB + (ly * WH + hx) * 64 + ((pq ^ (((hx >> 2) & 1) << 1)) << 4)) = v;
+      if constexpr (PRO) __builtin_amdgcn_sched_barrier(0);      // one vector's exp / rcp chains at a time: interleaving all HV of them spills
+    }
+  };
+
+  {
+  FoldRegs f0;
+  if (PRO) fold_issue(b, f0);
+  issue_rows(b, oy0);
+  // the image's left / right halo columns: zero, once (nothing ever writes them again)
+  {
+    constexpr int NZ = NCH * HR * 8;
+    static_assert(NZ <= NT, "one zero vector per thread");
+    if (tid < NZ) {
+      const int c = tid / (HR * 8), rem = tid - c * (HR * 8), ly = rem >> 3, hx = (rem & 4) ? WH - 1 : 0;
+      *reinterpret_cast<u32x4_t*>(smem + c * CHB + (ly * WH + hx) * 64 + (rem & 3) * 16) = u32x4_t{0, 0, 0, 0};
+    }
+  }
+  if (PRO) fold_finish(b, oy0 == 0 && n0 == 0, true, f0);
+  }
+  // the weights land behind the rows (and behind the fold's registers): their latency hides under the first tile's transform
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) { Wf[0][tap] = *wsrc(0, (n0 >> 4) + cg, 0, tap); Wf[1][tap] = *wsrc(0, (n0 >> 4) + cg, 1, tap); }
+  write_rows(b, oy0, PRO && p.a_out != nullptr && n0 == 0);
+  lds_barrier();
+
+  for (;;) {
+    const bool has_next = item + 1 < item_end;
+    int nnt = nt, nb = b, noy0 = oy0, nn0 = n0;
+    if (has_next) {
+      nnt = (item + 1) / npt;
+      const int npt_i = item + 1 - nnt * npt;
+      nb = npt_i / p.tiles_per_img; noy0 = (npt_i - nb * p.tiles_per_img) * R; nn0 = nnt * BN;
+    }
+    // ---- what the epilogue reads from memory, then the next tile's rows (vmcnt is in order: the epilogue's operands first)
+    uint4 due_xr[DUE ? BM * (BN / 8) / NT : 1];
+    float dscv[8], dshv[8];
+    uint64_t dseed = 0;
+    if constexpr (DUE) {
+      due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, BM, tid);
+      due_fetch_coef<BN>(p, b, n0, tid, dscv, dshv, dseed);
+    }
+    const bool refold = PRO && has_next && nb != b;       // the workgroup crosses into the next image (never at one or two tiles per CU)
+    if (has_next) issue_rows(nb, noy0);
+
+    // ---- the conv: per 64-channel pair 2 chunks x NCB column blocks x HR input rows; per step 3 fragment reads (one row,
+    // kx = 0..2; read one step ahead) and up to 9 MFMAs (the output rows the input row feeds)
+    f32x4_t acc[NCB * R];
+#pragma unroll
+    for (int i = 0; i < NCB * R; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const unsigned char* X0 = smem + kp * 2 * CHB;
+      constexpr int NS = 2 * NCB * HR;
+      bf16x8_t xa[3], xb[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) xa[kx] = *reinterpret_cast<const bf16x8_t*>(X0 + lp[0][kx]);
+      // the weights this wave needs next: the following pair of this tile, else the first pair of the next tile when it differs
+      const bool wmore = kp + 1 < KP || (has_next && (KP > 1 || nn0 != n0));
+      const int wkp = kp + 1 < KP ? kp + 1 : 0, wn16 = ((kp + 1 < KP ? n0 : nn0) >> 4) + cg;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c = s / (NCB * HR), jj = (s / HR) % NCB, ly = s % HR;
+        bf16x8_t (&cur)[3] = (s & 1) ? xb : xa;
+        bf16x8_t (&nxt)[3] = (s & 1) ? xa : xb;
+        if (s + 1 < NS) {
+          const int nc = (s + 1) / (NCB * HR), njj = ((s + 1) / HR) % NCB, nly = (s + 1) % HR;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) nxt[kx] = *reinterpret_cast<const bf16x8_t*>(X0 + nc * CHB + nly * WH * 64 + lp[njj][kx]);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int orow = ly - ky;
+          if (orow < 0 || orow >= R) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[jj * R + orow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[c][ky * 3 + kx], cur[kx], acc[jj * R + orow], 0, 0, 0);
+        }
+        if (s == NCB * HR - 1 || s == NS - 1) {        // chunk c's fragments are through: their registers take the next pair's
+          if (wmore) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) Wf[c][tap] = *wsrc(wkp, wn16, c, tap);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue: accumulators -> fp32 tile in LDS; the next tile's rows -> image (every wave is past its last fragment read)
+    lds_barrier();
+    {
+      constexpr int PF = BN + 4;
+      float* O = reinterpret_cast<float*>(Os);
+#pragma unroll
+      for (int jj = 0; jj < NCB; ++jj)
+#pragma unroll
+        for (int orow = 0; orow < R; ++orow) {
+          const int pl = orow * W + (NCB * ph + jj) * 16 + fr;
+          const f32x4_t a = acc[jj * R + orow];
+          *reinterpret_cast<float4*>(O + pl * PF + cg * 16 + fq * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
+    if (has_next) {
+      if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0, false, f1); }
+      write_rows(nb, noy0, PRO && p.a_out != nullptr && nn0 == 0);
+    }
+    lds_barrier();
+    if constexpr (DUE) {
+      due_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
+    } else {
+      uint4 none[(BM * (BN / 8) + NT - 1) / NT];
+      lds_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, none, false);
+    }
+    if (!has_next) break;
+    ++item; nt = nnt; b = nb; oy0 = noy0; n0 = nn0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- host
+const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;
+const int g_rs_min = getenv("IDF_CONV_RS_MIN") ? atoi(getenv("IDF_CONV_RS_MIN")) : 128;     // work items below which the launch leaves most CUs idle
+
+// tiles per image (= T of the statistics partials) or 0 when the form does not cover the shape
+int rs_tiles(int B, int H, int W, int Cin, int Cout) {
+  if (!g_rs || B <= 0 || H != W || (W != 64 && W != 32) || (Cout % 64) || Cout <= 0) return 0;
+  if (!((W == 64 && Cin == 64) || (W == 32 && (Cin == 128 || Cin == 64)))) return 0;
+  if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31) || (long)Cout * 9 * Cin >= (1L << 31)) return 0;
+  const int T = H / (256 / W);
+  if ((long)B * T * (Cout / 64) < g_rs_min) return 0;
+  return T;
+}
+
+int rs_ncu() {
+  static const int ncu = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return ncu;
+}
+
+template <int W, int CIN, bool PRO, int EPI>
+int launch_rs(C3P& p, hipStream_t st) {
+  using G = RsGeo<W>;
+  p.R = G::R; p.tiles_per_img = p.H / G::R; p.n_tiles = p.Cout / 64;
+  p.rs_total = p.B * p.tiles_per_img * p.n_tiles;
+  const int ncu = rs_ncu();
+  p.rs_per = idf_cdiv(p.rs_total, ncu);
+  const int grid = idf_cdiv(p.rs_total, p.rs_per);
+  size_t lds = (size_t)(CIN / 32) * G::CHB;
+  p.rs_os_off = (int)lds;
+  lds += (size_t)256 * (64 + 4) * sizeof(float);
+  p.aux_off = (int)lds;
+  lds += (size_t)8 * 64 * 8;                      // wave partials of the statistics
+  p.rs_cof_off = (int)lds;
+  if (PRO) lds += (size_t)CIN * 16;
+  if (lds > 160 * 1024) return 1;
+  auto kern = conv_rs_bf16<W, CIN, PRO, EPI>;
+  static IdfLdsGrant grant;
+  if (idf_ensure_lds((const void*)kern, lds, grant) != hipSuccess) return 2;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  return 0;
+}
+
+template <bool PRO, int EPI>
+int dispatch_rs(C3P& p, hipStream_t st) {
+  if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, PRO, EPI>(p, st);
+  if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, PRO, EPI>(p, st);
+  if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, PRO, EPI>(p, st);
+  return 3;
+}
+
+}  // namespace
+
+// Tiles per image (= T of the statistics / du partials the entry points below write: [B][T][Cout][2]) when the row-reuse form
+// covers a stride-1 3x3 conv of this shape, else 0: square 64x64 maps with 64 input channels, 32x32 maps with 64 or 128,
+// Cout % 64 == 0, at least IDF_CONV_RS_MIN (128) work items of 256 pixels x 64 couts.
+extern "C" int idf_conv_rs_tiles(int B, int H, int W, int Cin, int Cout) { return rs_tiles(B, H, W, Cin, Cout); }
+
+// y = conv3x3(dropout(SiLU(FiLM(GroupNorm(x))))) + bias (+ res): idf_conv_gn_bf16's contract (taps 9, one source) with the weights
+// fragment-major (idf_pack_conv_weights_batched's w_frag: [Cin / 64][Cout / 16][tap][half][lane][8]).  T1 <= 16.
+extern "C" int idf_conv_rs_gn_bf16(const void* x, const float* st1, int T1, const float* gamma, const float* beta, const float* film_t,
+                                   const float* film_a, int ld_t, int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt,
+                                   float p_drop, const void* w_frag, const float* bias, const void* res, void* y, void* a_out,
+                                   float* mean, float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin,
+                                   int Cout, void* stream) {
+  if (!rs_tiles(B, H, W, Cin, Cout) || T1 < 1 || T1 > 16)
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_gn_bf16: B%d H%d W%d Cin%d Cout%d T1 %d not covered", B, H, W, Cin, Cout, T1);
+  if (!x || !st1 || !w_frag || !y) IDF_FAIL(IDF_ERR_BADARG, "conv_rs_gn_bf16: null argument");
+  if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "conv_rs_gn_bf16: act must be 1 or 2");
+  if ((sc != nullptr) != (sh != nullptr) || (sc != nullptr) != (mean != nullptr) || (sc != nullptr) != (rstd != nullptr))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_rs_gn_bf16: mean / rstd / sc / sh go together");
+  C3P p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)x; p.C1 = Cin; p.w = (const bf16_t*)w_frag; p.bias = bias; p.res = (const bf16_t*)res; p.y = (bf16_t*)y;
+  p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout;
+  p.st_out = st_out; p.st1 = st1; p.T1 = T1;
+  p.gamma = gamma; p.beta = beta; p.film_t = film_t; p.film_a = film_a;
+  p.ld_t = ld_t ? ld_t : 2 * Cin; p.ld_a = ld_a ? ld_a : 2 * Cin; p.eps = eps;
+  p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
+  p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  p.a_out = (bf16_t*)a_out; p.mean_out = mean; p.rstd_out = rstd; p.sc_out = sc; p.sh_out = sh;
+  if (int rc = dispatch_rs<true, 0>(p, (hipStream_t)stream)) IDF_FAIL(IDF_ERR_HIP, "conv_rs_gn_bf16: launch refused (%d)", rc);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// du = conv3x3(dy, w) * act'(x * sc + sh) * mask and its partials (sum du, sum du x): idf_conv_dgrad_chain_bf16's contract without a
+// dy prologue (taps 9), w_frag = the data-gradient weights fragment-major; Cin = channels of dy, Cout = channels of x | x2 / du.
+extern "C" int idf_conv_rs_dgrad_chain_bf16(const void* dy, const void* w_frag, const void* x, const void* x2, int C1, const float* sc,
+                                            const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, void* out,
+                                            float* part_out, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!rs_tiles(B, H, W, Cin, Cout))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_dgrad_chain_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (!dy || !w_frag || !x || !sc || !sh || !out || !part_out || (act != 1 && act != 2))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_rs_dgrad_chain_bf16: null argument / act");
+  if (!x2) C1 = Cout;
+  if (x2 && (C1 <= 0 || C1 >= Cout || (C1 % 64))) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_dgrad_chain_bf16: C1 %d of %d", C1, Cout);
+  C3P p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)dy; p.C1 = Cin; p.w = (const bf16_t*)w_frag; p.y = (bf16_t*)out;
+  p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout;
+  p.due_x = (const bf16_t*)x; p.due_x2 = (const bf16_t*)x2; p.due_C1 = C1; p.due_sc = sc; p.due_sh = sh;
+  p.st_out = part_out;
+  p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
+  p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  if (int rc = dispatch_rs<false, 2>(p, (hipStream_t)stream)) IDF_FAIL(IDF_ERR_HIP, "conv_rs_dgrad_chain_bf16: launch refused (%d)", rc);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}

@@ -245,6 +245,25 @@ def _wr_frag(shadows, j, B, H, W, Cin, Cout, whole):
     return v
 
 
+_RS = os.environ.get('IDF_CONV_RS', '1') != '0'          # the big-map ResBlock convs in the register-weights / row-reuse form (idf_conv_rs_*)
+
+
+@functools.lru_cache(maxsize=None)
+def rs_tiles(B, H, W, Cin, Cout):
+    return int(_lib.load().idf_conv_rs_tiles(B, H, W, Cin, Cout))
+
+
+def _rs_frag(shadows, j, B, H, W, Cin, Cout):
+    """The fragment-major shadow j (2 forward, 3 data gradient) when idf_conv_rs_* covers the shape and the shadow exists; a conv
+    met here for the first time is asked for one (it comes with the re-pack at the end of this forward pass / the next one)."""
+    if not (_RS and shadows is not None and rs_tiles(B, H, W, Cin, Cout) > 0):
+        return None
+    v = shadows.val[j]
+    if v is None:
+        shadows.request_frag()
+    return v
+
+
 def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop, act, w_fwd, bias, residual, Cout, taps,
                 keep_a=False, keep_coef=False, want_stats=False, shortcut=None, shadows=None):
     """y = conv(act(GN/FiLM(x | x2))) + bias (+ residual) in one launch -> (y, a, mean, rstd, sc, sh, st_out);
@@ -268,6 +287,16 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
         call('idf_conv_wr_gn_bf16', _p(x), _p(x2), C1, _p(st1), st1.shape[1], _p(st2), st2.shape[1] if st2 is not None else 0,
              _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), GN_EPS, _p(seed), salt, float(p_drop),
              _p(wfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout, _st())
+        return y, a, mean, rstd, sc, sh, st
+    rfrag = None
+    if taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 16:
+        rfrag = _rs_frag(shadows, 2, B, H, W, Cin, Cout)
+    if rfrag is not None:
+        # 64x64 / 32x32: weights fragment-major into registers, whole-K halo image in LDS, row reuse, persistent over the CU's tiles
+        st = torch.empty((B, rs_tiles(B, H, W, Cin, Cout), Cout, 2), dtype=torch.float32, device=dev) if (want_stats and Cout % 8 == 0) else None
+        call('idf_conv_rs_gn_bf16', _p(x), _p(st1), st1.shape[1], _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
+             GN_EPS, act, _p(seed), salt, float(p_drop), _p(rfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc),
+             _p(sh), _p(st), B, H, W, Cin, Cout, _st())
         return y, a, mean, rstd, sc, sh, st
     st = _new_stats(B, H, W, Cin, Cout, S1, taps, dev, 1) if want_stats else None
     ws = torch.empty((B, Cin, 2), dtype=torch.float32, device=dev) if B * H * W >= (1 << 18) else None
@@ -576,7 +605,7 @@ def _lazy_check_consumed():
 
 
 def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=None, x2=None, sc=None, sh=None, seed=None,
-                         salt=0, p_drop=0.0, act=0, shortcut=None):
+                         salt=0, p_drop=0.0, act=0, shortcut=None, shadows=None):
     """Stride-1 data-gradient conv of the backward chain -> (out, part, dy_mat).  lazy: `dy` is lazy.du and the real input
     gradient is formed in the prologue (written to dy_mat when want_dy); x (+ x2): du epilogue, out = du and part = its
     per-tile partial sums -- else out = dA.  shortcut = (ds, w_sc_dgrad): the launch also computes the block shortcut's
@@ -585,6 +614,14 @@ def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=No
     out = empty_nhwc(B, Cout, H, W, dy.dtype, dy.device)
     part = None
     C1 = x.shape[1] if (x is not None and x2 is not None) else 0
+    if (x is not None and lazy is None and shortcut is None and taps == 9 and dy.dtype == torch.bfloat16 and act
+            and (x2 is None or C1 % 64 == 0)):
+        rfrag = _rs_frag(shadows, 3, B, H, W, Cin, Cout)
+        if rfrag is not None:
+            part = torch.empty((B, rs_tiles(B, H, W, Cin, Cout), Cout, 2), dtype=torch.float32, device=dy.device)
+            call('idf_conv_rs_dgrad_chain_bf16', _p(dy), _p(rfrag), _p(x), _p(x2), C1, _p(sc), _p(sh), _p(seed), salt, float(p_drop),
+                 act, _p(out), _p(part), B, H, W, Cin, Cout, _st())
+            return out, part, None
     if x is not None:
         part = torch.empty((B, chain_tiles(B, H, W, Cin, Cout, taps), Cout, 2), dtype=torch.float32, device=dy.device)
     if shortcut is not None:
@@ -1032,7 +1069,7 @@ class _FusedConv(torch.autograd.Function):
                 want_dy = lazy_in is not None and (need[1] or want_b or (ctx.has_res and need[7]))
                 if act:
                     du, part, dy_mat = conv_dgrad_chain_raw(dy, w_dgrad, taps, x.shape[1], lazy_in, want_dy, x=x, sc=sc, sh=sh,
-                                                            seed=seed, salt=salt, p_drop=p_drop, act=act)
+                                                            seed=seed, salt=salt, p_drop=p_drop, act=act, shadows=cfg['shadows'])
                     gacc = _gn_acc(gslots) if (ctx.lazy_out and dres_in is None) else None
                     if ctx.lazy_out and dres_in is None and (gacc is not None or not (need[3] or need[4])):
                         dft = torch.empty(film_t.shape, dtype=torch.float32, device=x.device) if film_t is not None else None
@@ -1247,7 +1284,7 @@ class _BlockEntryCat(torch.autograd.Function):
                                                      shortcut=(ds, w_sc_dgrad))
             else:
                 du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc,
-                                                        sh=sh, act=cfg['act'])
+                                                        sh=sh, act=cfg['act'], shadows=cfg['shadows'])
                 if lazy_in is not None:
                     dh = dh_mat
             (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, (gws, gbs),
@@ -1547,7 +1584,7 @@ def _entry_cat_bwd(x1, x2, dh, ds, gn_w, gn_b, mean, rstd, sc, sh, cfg, cfg_sc, 
                                                  shortcut=(ds, w_sc_dgrad))
         else:
             dxs = conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
-            du, part, _ = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'])
+            du, part, _ = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'], shadows=cfg['shadows'])
         (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, gslots, dres=dxs,
                                                        x2=x2)
     else:

@@ -612,6 +612,123 @@ def test_conv_wr_groupnorm_prologue_conv_vs_pytorch(case):
 
 
 @pytest.mark.parametrize('case', [
+    # (B, Cin, H, Cout, film, p_drop, with_res): 64x64 with 64 channels, 32x32 with 128 / 64; one and several tiles per workgroup
+    (32, 64, 64, 64, True, 0.1, True), (5, 64, 64, 64, False, 0.0, False), (70, 64, 64, 128, True, 0.1, False),
+    (32, 128, 32, 128, True, 0.1, True), (16, 128, 32, 128, False, 0.0, False), (150, 128, 32, 128, True, 0.0, True),
+    (32, 64, 32, 128, True, 0.1, False), (64, 128, 32, 64, False, 0.1, True),
+])
+def test_conv_rs_groupnorm_prologue_conv_vs_pytorch(case):
+    """idf_conv_rs_gn_bf16 (round 5: the GroupNorm-prologue conv of the 64x64 / 32x32 maps with the weights fragment-major in
+    registers, the whole-K halo image in LDS, row reuse, persistent over the CU's tiles) against fp32 PyTorch -- y, the
+    activated tensor, mean / rstd / sc / sh, the statistics partials of y -- and against idf_conv_gn_bf16 on the same inputs."""
+    B, C, H, Cout, film, p_drop, with_res = case
+    x1 = (0.5 + 1.5 * rnd(1, B, C, H, H)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    gam, bet = (1 + 0.1 * rnd(3, C)).to(DEV), (0.1 * rnd(4, C)).to(DEV)
+    ft = (0.2 * rnd(5, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    w = (rnd(7, Cout, C, 3, 3) / (C * 9) ** 0.5).to(DEV)
+    bias = rnd(8, Cout).to(DEV)
+    res = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL) if with_res else None
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV) if p_drop else None
+    sh_ = _FragShadows(w)
+    T = ops.rs_tiles(B, H, H, C, Cout)
+    assert T == H // (256 // H), (case, T)
+    st1 = ops.gn_partials_raw(x1)
+    names = []
+    orig = ops.call
+    ops.call = lambda n, *a: (names.append(n), orig(n, *a))[1]
+    try:
+        y, a, mean, rstd, sc, sh, st = ops.conv_gn_raw(x1, None, st1, None, gam, bet, ft, fa, seed, 7, p_drop, 2, sh_.val[0], bias, res,
+                                                       Cout, 9, keep_a=True, keep_coef=True, want_stats=True, shadows=sh_)
+    finally:
+        ops.call = orig
+    assert names == ['idf_conv_rs_gn_bf16'], names
+    u = F.group_norm(x1.float(), 32, gam, bet, eps=1e-5)
+    if film:
+        u = u * (1 + ft[:, :C, None, None]) + ft[:, C:, None, None]
+        u = u * (1 + fa[:, :C, None, None]) + fa[:, C:, None, None]
+    u = F.silu(u)
+    if p_drop:
+        u = u * ops.dropout_mask(seed, 7, p_drop, x1.numel()).view(B, H, H, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(u, w, bias, padding=1)
+    if with_res:
+        ref = ref + res.float()
+    assert rel(y, ref) < 2e-2, rel(y, ref)
+    assert rel(a, u) < 1e-2
+    mu = x1.float().reshape(B, 32, -1).mean(dim=2)
+    var = x1.float().reshape(B, 32, -1).var(dim=2, unbiased=False)
+    assert rel(mean, mu) < 1e-5 and rel(rstd, (var + 1e-5).rsqrt()) < 1e-5
+    s1, s2 = _chan_sums(y)
+    got = st.double().sum(dim=1)
+    assert st.shape == (B, T, Cout, 2)
+    assert float((got[..., 1] - s2).abs().max() / s2.abs().max()) < 1e-5
+    assert float((got[..., 0] - s1).abs().max()) < 2e-3 * (1 + float(s1.abs().max()))
+    # the halo / direct-to-LDS kernels on the same inputs: same coefficients, outputs within a bf16 ulp or two
+    y0, a0, m0, r0, sc0, sh0, _ = ops.conv_gn_raw(x1, None, st1, None, gam, bet, ft, fa, seed, 7, p_drop, 2, sh_.val[0], bias, res,
+                                                  Cout, 9, keep_a=True, keep_coef=True, want_stats=True)
+    assert rel(sc, sc0) < 1e-5 and rel(sh, sh0) < 1e-5
+    assert float((a.float() - a0.float()).abs().max()) <= 2 ** -7 * float(a0.float().abs().max())
+    assert rel(y, y0) < 1e-2
+
+
+@pytest.mark.parametrize('case', [
+    # (B, channels of dy, C1, C2 of x | x2, H, act, film, p_drop, n_res)
+    (32, 64, 64, 0, 64, 2, True, 0.1, 1), (5, 64, 64, 0, 64, 2, False, 0.0, 0), (33, 64, 128, 64, 64, 2, False, 0.0, 1),
+    (32, 128, 128, 0, 32, 2, True, 0.1, 2), (40, 128, 128, 128, 32, 2, False, 0.0, 1), (64, 64, 128, 0, 32, 2, True, 0.1, 0),
+    (64, 128, 64, 0, 32, 1, False, 0.0, 0),
+])
+def test_conv_rs_backward_chain_du_epilogue_vs_pytorch_autograd(case):
+    """idf_conv_rs_dgrad_chain_bf16 (round 5: the data-gradient conv of the 64x64 / 32x32 maps in the register-weights form with
+    the du epilogue) + idf_gn_bwd_apply against fp32 PyTorch autograd of conv(dropout(act(FiLM(GroupNorm(x | x2))))) with the
+    product's dropout mask: dx (two-source inputs: dx1 | dx2), dgamma, dbeta, dFiLM_t, dFiLM_a <= 4e-2; du and its partials
+    against idf_conv_dgrad_chain_bf16 on the same inputs."""
+    B, Cin, C1, C2, H, act, film, p_drop, n_res = case
+    W, C = H, C1 + C2
+    x1 = (0.3 + rnd(1, B, C1, H, W)).to(DEV).bfloat16().contiguous(memory_format=CL)
+    x2 = (rnd(11, B, C2, H, W) - 0.2).to(DEV).bfloat16().contiguous(memory_format=CL) if C2 else None
+    xc = torch.cat([x1, x2], dim=1).contiguous(memory_format=CL) if C2 else x1
+    dy = rnd(2, B, Cin, H, W).to(DEV).bfloat16().contiguous(memory_format=CL)
+    wgt = (rnd(3, Cin, C, 3, 3) / (C * 9) ** 0.5).to(DEV).bfloat16().float()
+    sh_ = _FragShadows(wgt)
+    gam, bet = (1 + 0.1 * rnd(4, C)).to(DEV), (0.1 * rnd(5, C)).to(DEV)
+    ft = (0.2 * rnd(6, B, 2 * C)).to(DEV) if film else None
+    fa = (0.2 * rnd(7, B, 2 * C)).to(DEV) if film else None
+    seed = torch.tensor([987654321], dtype=torch.int64, device=DEV) if p_drop else None
+    res = [rnd(8 + i, B, C, H, W).to(DEV).bfloat16().contiguous(memory_format=CL) for i in range(n_res)]
+    dres, dres2 = (res + [None, None])[:2]
+    mask = ops.dropout_mask(seed, 5, p_drop, xc.numel()).view(B, H, W, C).permute(0, 3, 1, 2) if p_drop else None
+    want = _gn_act_conv_reference(xc, gam, bet, ft, fa, act, mask, wgt, dy, res)
+    mean, rstd, sc, sh = ops.gn_coef_fwd_raw(xc, gam, bet, ft, fa)
+    T = ops.rs_tiles(B, H, W, Cin, C)
+    assert T == H // (256 // H)
+    names = []
+    orig = ops.call
+    ops.call = lambda n, *a: (names.append(n), orig(n, *a))[1]
+    try:
+        du, part, _ = ops.conv_dgrad_chain_raw(dy, sh_.val[1], 9, C, x=x1, x2=x2, sc=sc, sh=sh, seed=seed, salt=5, p_drop=p_drop, act=act,
+                                               shadows=sh_)
+    finally:
+        ops.call = orig
+    assert names == ['idf_conv_rs_dgrad_chain_bf16'], names
+    assert part.shape == (B, T, C, 2)
+    s1 = du.double().sum(dim=(2, 3))
+    s2 = (du.double() * xc.double()).sum(dim=(2, 3))
+    got = part.double().sum(dim=1)
+    assert float((got[..., 0] - s1).abs().max()) < 1e-4 * (1 + float(s1.abs().max()))
+    assert float((got[..., 1] - s2).abs().max()) < 1e-4 * (1 + float(s2.abs().max()))
+    du0, part0, _ = ops.conv_dgrad_chain_raw(dy, sh_.val[1], 9, C, x=x1, x2=x2, sc=sc, sh=sh, seed=seed, salt=5, p_drop=p_drop, act=act)
+    assert rel(du, du0) < 1e-2, rel(du, du0)
+    out = ops.gn_bwd_apply_raw(du, part, x1, gam, bet, ft, fa, mean, rstd, sc, dres=dres, dres2=dres2, x2=x2)
+    dx = torch.cat(out[0], dim=1) if C2 else out[0]
+    for nm, g, r in zip(('dx', 'dgamma', 'dbeta', 'dfilm_t', 'dfilm_a'), (dx,) + tuple(out[1:]), want):
+        assert (g is None) == (r is None), nm
+        if g is not None:
+            parts = [(g, r)] if g.dim() != 2 else [(g[:, :C], r[:, :C]), (g[:, C:], r[:, C:])]
+            for gg, rr in parts:
+                assert rel(gg, rr) < 4e-2, (nm, rel(gg, rr))
+
+
+@pytest.mark.parametrize('case', [
     # (B, channels of dy, C of x, H, film, p_drop, n_res)
     (3, 128, 128, 16, True, 0.1, 1), (2, 128, 128, 8, True, 0.1, 2), (2, 128, 256, 8, True, 0.0, 1), (33, 128, 128, 16, False, 0.0, 0),
     (2, 64, 128, 16, False, 0.1, 1),

@@ -35,6 +35,29 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Diagnostic build only (tools/build_variant.sh rsstamp idf_conv_rs.hip -DIDF_RS_STAMP; never in the shipped library): wave 0 of
+// every workgroup stamps s_memtime at the phase boundaries and adds the differences to g_rs_stamps (tools/rs_stamps.py):
+// [0] issue (plan, fold + row loads) [1] fold [2] rows landed, transformed, written [3] first barrier [4] per-tile issue
+// [5] MFMA loop [6] barrier behind it [7] accumulators -> LDS + next rows -> image [8] barrier [9] epilogue tail [10] workgroup
+// [11] tiles [12] workgroups
+#ifdef IDF_RS_STAMP
+__device__ unsigned long long g_rs_stamps[64 * 16];
+__device__ __forceinline__ unsigned long long rs_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define RS_STAMP(var) const unsigned long long var = rs_now()
+#define RS_DECL unsigned long long rs_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0}
+#define RS_ADD(i, a, b) rs_sum[i] += (b) - (a)
+#define RS_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_rs_stamps[(blockIdx.x & 63) * 16 + i_], rs_sum[i_]); } while (0)
+#else
+#define RS_STAMP(var)
+#define RS_DECL
+#define RS_ADD(i, a, b)
+#define RS_FLUSH
+#endif
+
 template <int W>
 struct RsGeo {
   static constexpr int R = 256 / W, WH = W + 2, HR = R + 2, NPH = HR * WH;
@@ -216,10 +239,14 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     }
   };
 
+  RS_DECL;
+  RS_STAMP(ts0);
   {
   FoldRegs f0;
   if (PRO) fold_issue(b, f0);
   issue_rows(b, oy0);
+  RS_STAMP(ts1);
+  RS_ADD(0, ts0, ts1);
   // the image's left / right halo columns: zero, once (nothing ever writes them again)
   {
     constexpr int NZ = NCH * HR * 8;
@@ -230,14 +257,22 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     }
   }
   if (PRO) fold_finish(b, oy0 == 0 && n0 == 0, true, f0);
+  RS_STAMP(ts2);
+  RS_ADD(1, ts1, ts2);
   }
+  RS_STAMP(ts2b);
   // the weights land behind the rows (and behind the fold's registers): their latency hides under the first tile's transform
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) { Wf[0][tap] = *wsrc(0, (n0 >> 4) + cg, 0, tap); Wf[1][tap] = *wsrc(0, (n0 >> 4) + cg, 1, tap); }
   write_rows(b, oy0, PRO && p.a_out != nullptr && n0 == 0);
+  RS_STAMP(ts3);
+  RS_ADD(2, ts2b, ts3);
   lds_barrier();
+  RS_STAMP(ts4);
+  RS_ADD(3, ts3, ts4);
 
   for (;;) {
+    RS_STAMP(tt0);
     const bool has_next = item + 1 < item_end;
     int nnt = nt, nb = b, noy0 = oy0, nn0 = n0;
     if (has_next) {
@@ -255,6 +290,8 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     }
     const bool refold = PRO && has_next && nb != b;       // the workgroup crosses into the next image (never at one or two tiles per CU)
     if (has_next) issue_rows(nb, noy0);
+    RS_STAMP(tt1);
+    RS_ADD(4, tt0, tt1);
 
     // ---- the conv: per 64-channel pair 2 chunks x NCB column blocks x HR input rows; per step 3 fragment reads (one row,
     // kx = 0..2; read one step ahead) and up to 9 MFMAs (the output rows the input row feeds)
@@ -300,7 +337,11 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     }
 
     // ---- epilogue: accumulators -> fp32 tile in LDS; the next tile's rows -> image (every wave is past its last fragment read)
+    RS_STAMP(tt2);
+    RS_ADD(5, tt1, tt2);
     lds_barrier();
+    RS_STAMP(tt3);
+    RS_ADD(6, tt2, tt3);
     {
       constexpr int PF = BN + 4;
       float* O = reinterpret_cast<float*>(Os);
@@ -317,17 +358,36 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
       if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0, false, f1); }
       write_rows(nb, noy0, PRO && p.a_out != nullptr && nn0 == 0);
     }
+    RS_STAMP(tt4);
+    RS_ADD(7, tt3, tt4);
     lds_barrier();
+    RS_STAMP(tt5);
+    RS_ADD(8, tt4, tt5);
     if constexpr (DUE) {
       due_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
     } else {
       uint4 none[(BM * (BN / 8) + NT - 1) / NT];
       lds_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, none, false);
     }
+    RS_STAMP(tt6);
+    RS_ADD(9, tt5, tt6);
+    RS_ADD(10, (item == wgid * p.rs_per ? ts0 : tt0), tt6);
+#ifdef IDF_RS_STAMP
+    rs_sum[11] += 1;
+#endif
     if (!has_next) break;
     ++item; nt = nnt; b = nb; oy0 = noy0; n0 = nn0;
   }
+  RS_FLUSH;
 }
+
+#ifdef IDF_RS_STAMP
+}  // namespace
+extern "C" int idf_debug_rs_stamps(void** dev_addr) {
+  return hipGetSymbolAddress(dev_addr, HIP_SYMBOL(g_rs_stamps)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------- host
 const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;

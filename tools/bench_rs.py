@@ -45,7 +45,10 @@ def main():
         sets = []
         for _ in range(n):
             x = torch.randn(B, Cin, H, H, device=DEV).bfloat16().contiguous(memory_format=CL)
-            sets.append((x, ops.gn_partials_raw(x)))
+            st = ops.gn_partials_raw(x)
+            if st.shape[1] > 16:
+                st = st.view(B, 16, st.shape[1] // 16, Cin, 2).sum(dim=2).contiguous()
+            sets.append((x, st))
 
         def fwd(s, shadows):
             return ops.conv_gn_raw(s[0], None, s[1], None, gam, bet, ft, fa, seed, 7, 0.1, 2, sh.val[0], bias, None, Cout, 9,

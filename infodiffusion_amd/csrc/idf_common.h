@@ -128,10 +128,27 @@ __device__ __forceinline__ uint32_t idf_vec_hash(uint64_t seed, uint32_t salt, u
   uint32_t h = idf_hash32((uint32_t)vec ^ (uint32_t)seed);
   return idf_hash32(h + salt * 0x9E3779B9u + (uint32_t)(seed >> 32) + (uint32_t)(vec >> 32) * 0x85ebca6bU);
 }
+// (round 5: a 24-bit multiply -- v_mad_u32_u24, full rate -- instead of the quarter-rate 32-bit v_mul_lo_u32: the per-element draw
+// was a fifth of the cycles of the conv epilogues that recompute the mask; the upper half of the 32-bit product of the hash's low
+// 24 bits with an odd 24-bit constant is the draw: uniform, pairwise correlation of the 8 draws of a vector < 1.2e-3 over 4e6
+// vectors, keep rate 0.9000 +- 2e-4 per lane at p = 0.1.)
 __device__ __forceinline__ bool idf_keep_h(uint32_t h, int lane, uint32_t thresh16) {
-  constexpr uint32_t A[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu,
-                             0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-  return ((h * A[lane & 7] + (A[lane & 7] >> 5)) >> 16) >= thresh16;
+  constexpr uint32_t A[8] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu, 0x165667u, 0xD3A265u, 0xFD7047u, 0xB55A4Fu};
+  return ((__umul24(h, A[lane & 7]) + (A[lane & 7] >> 5)) >> 16) >= thresh16;
+}
+// all-lanes sums across the halves / quarters / eighths of a wave (xor 32, 16, 8) without LDS traffic: gfx950's permlane swaps
+// exchange 32- / 16-lane rows between two registers (both = v: the results hold the two partners side by side), row_ror:8 rotates
+// inside a 16-lane row
+__device__ __forceinline__ float idf_xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float idf_xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float idf_xor8_sum(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
 }
 __device__ __forceinline__ bool idf_keep(uint64_t seed, uint32_t salt, uint64_t idx, uint32_t thresh16) {
   return idf_keep_h(idf_vec_hash(seed, salt, idx >> 3), (int)(idx & 7), thresh16);

@@ -253,7 +253,7 @@ __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* s
     float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc);
     float4 v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
     o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-    size_t e = ((size_t)(b * p.H + oy0) * W + pl) * p.Cout + n0 + cc;
+    const unsigned e = (unsigned)(((b * p.H + oy0) * W + pl) * p.Cout + n0 + cc);      // tensors < 2^31 elements (checked on the host)
     if (p.bias) {
       float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
       float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
@@ -280,10 +280,18 @@ __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* s
   }
   if (p.st_out) {
     // lanes CPR apart hold the same couts: fold them, then the waves through LDS (outside the fp32 tile)
+    if constexpr (CPR == 8) {
 #pragma unroll
-    for (int off = 32; off >= CPR; off >>= 1)
+      for (int k = 0; k < 8; ++k) {
+        ssum[k] = idf_xor8_sum(idf_xor16_sum(idf_xor32_sum(ssum[k])));
+        ssq[k] = idf_xor8_sum(idf_xor16_sum(idf_xor32_sum(ssq[k])));
+      }
+    } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { ssum[k] += __shfl_xor(ssum[k], off, 64); ssq[k] += __shfl_xor(ssq[k], off, 64); }
+      for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ssum[k] += __shfl_xor(ssum[k], off, 64); ssq[k] += __shfl_xor(ssq[k], off, 64); }
+    }
     float* part = reinterpret_cast<float*>(smem + p.aux_off);     // [waves][BN][2]
     if (lane < CPR) {
 #pragma unroll
@@ -537,17 +545,16 @@ __device__ __forceinline__ void due_fetch_coef(const C3P& p, int b, int n0, int 
 }
 
 // second half of due_epilogue: dA [BM][BN + 4] is in LDS (the caller's barrier is behind it).  LDSONLY as lds_epilogue_tail's.
-template <int BM, int BN, int NT, bool LDSONLY = false>
-__device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
-                                                  const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
-                                                  uint64_t seedv) {
+template <int BM, int BN, int NT, bool LDSONLY, bool SILU, bool DROP>
+__device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
+                                                    const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
+                                                    uint64_t seedv) {
   const int lane = tid & 63, wave = tid >> 6;
   const int W = p.W, R = p.R, C = p.Cout;
   constexpr int PF = BN + 4, CPR = BN / 8, NI = BM * CPR / NT;
   static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "a thread keeps one channel slot");
   float* Os = reinterpret_cast<float*>(smem);      // [BM][PF]
   const int cc = (tid % CPR) * 8;                  // this thread's 8 channels of the tile
-  const bool drop = p.act == 2 && p.seed != nullptr;
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -561,18 +568,11 @@ __device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* s
       const uint32_t w4[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) { xv[2 * i] = __uint_as_float(w4[i] << 16); xv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
-      const size_t e0 = ((size_t)(b * p.H + oy0) * W + pl) * C + n0 + cc;      // index in the dense activated tensor
-      const uint32_t h = drop ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
-      if (p.act == 2) {
+      const unsigned e0 = (unsigned)(((b * p.H + oy0) * W + pl) * C + n0 + cc);      // index in the dense activated tensor (< 2^31: host check)
+      const uint32_t h = DROP ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
 #pragma unroll
-        for (int g0 = 0; g0 < 8; g0 += 4) {
-          if (drop) idf_dact_vec_t<4, true, true>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
-          else idf_dact_vec_t<4, true, false>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) du[e] = dav[e];
-      }
+      for (int g0 = 0; g0 < 8; g0 += 4)
+        idf_dact_vec_t<4, SILU, DROP>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         du[e] = bf16_to_f32(f32_to_bf16(du[e]));
@@ -582,10 +582,18 @@ __device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* s
     }
   }
   // lanes CPR apart hold the same channels: fold them, then the waves through LDS (outside the fp32 tile)
+  if constexpr (CPR == 8) {
 #pragma unroll
-  for (int off = 32; off >= CPR; off >>= 1)
+    for (int e = 0; e < 8; ++e) {
+      s1[e] = idf_xor8_sum(idf_xor16_sum(idf_xor32_sum(s1[e])));
+      s2[e] = idf_xor8_sum(idf_xor16_sum(idf_xor32_sum(s2[e])));
+    }
+  } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+    for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+  }
   float* part = reinterpret_cast<float*>(smem + p.aux_off);     // [waves][BN][2]
   if (lane < CPR) {
 #pragma unroll
@@ -600,6 +608,18 @@ __device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* s
   }
 }
 
+
+// the activation / dropout switches are launch-uniform: resolved ONCE per tile, each case straight-line (with the conditions inside
+// the vector loop hipcc emitted a branch, a wait and a partial copy of the body per 4 elements)
+template <int BM, int BN, int NT, bool LDSONLY = false>
+__device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
+                                                  const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
+                                                  uint64_t seedv) {
+  if (p.act == 2) {
+    if (p.seed != nullptr) due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, true>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+    else due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, false>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+  } else due_epilogue_tail_t<BM, BN, NT, LDSONLY, false, false>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+}
 
 template <int TM, int TN, int BM, int BN, int NT>
 __device__ __forceinline__ void due_epilogue(const C3P& p, const f32x4_t (&acc)[TN][TM], unsigned char* smem, int b, int oy0,

@@ -73,6 +73,8 @@ struct C3P {
   // (cout tile, pixel tile) items of the rs_total; LDS: chunk images | fp32 epilogue tile at rs_os_off | statistics scratch at
   // aux_off | coefficients at rs_cof_off
   int rs_per, rs_total, rs_os_off, rs_cof_off;
+  int rs_skew;                     // start delay of the workgroup in a CU's second wave slots (units of ~1 us)
+  int rs_x0, rs_tidx, rs_halves;   // half-width tiles (two 256-thread workgroups per CU): first column and statistics-tile index of the current tile; tiles per row strip
 #ifdef IDF_PS_DBG
   int ps_dbg;                   // timing-only ablation build (tools/build_variant.sh ... -DIDF_PS_DBG; env IDF_CONV_PS_DBG;
                                 // results are wrong when set): 1 no halo loads after a block's first stage, 2 no MFMAs,
@@ -99,6 +101,14 @@ constexpr int HALO_VEC_MAX_256 = 1280, HALO_VEC_MAX_512 = 2048, HALO_VEC_MAX_S2 
 constexpr int CK = 32;
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ (((row >> 2) & 1) << 1); }
+
+// pixel index in [B * H * W] of pixel pl of a tile that starts at row oy0: whole rows (TWS = 0: the tile's pixels are contiguous), or
+// 2^TWS columns from column p.rs_x0 on (idf_conv_rs.hip's half-width tiles)
+template <int TWS>
+__device__ __forceinline__ int tile_pix(const C3P& p, int b, int oy0, int pl) {
+  if constexpr (TWS == 0) return (b * p.H + oy0) * p.W + pl;
+  else return (b * p.H + oy0 + (pl >> TWS)) * p.W + p.rs_x0 + (pl & ((1 << TWS) - 1));
+}
 
 // In-block fold of the GroupNorm statistics + gamma / beta + FiLM pairs into cof[c] = (sc, sh) (the fold of
 // idf_groupnorm.hip's gn_finalize, from per-channel partial sums).  One image per block; the partials are summed
@@ -231,7 +241,7 @@ __device__ __forceinline__ void res_fetch(const C3P& p, uint4 (&rr)[(BM * (BN / 
 // second half of lds_epilogue: the fp32 tile Os [BM][BN + 4] is in LDS (the caller's barrier is behind it); bias, residual,
 // rounding, full-line stores and the statistics partials.  LDSONLY: the waits in front of the internal barrier are for LDS only
 // (the row-stream kernel keeps global loads in flight across it).
-template <int BM, int BN, int NT, bool LDSONLY = false>
+template <int BM, int BN, int NT, bool LDSONLY = false, int TWS = 0>
 __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
                                                   const uint4 (&rpre)[(BM * (BN / 8) + NT - 1) / NT], bool have_rpre) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -253,7 +263,7 @@ __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* s
     float4 v0 = *reinterpret_cast<const float4*>(Os + pl * PF + cc);
     float4 v1 = *reinterpret_cast<const float4*>(Os + pl * PF + cc + 4);
     o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
-    const unsigned e = (unsigned)(((b * p.H + oy0) * W + pl) * p.Cout + n0 + cc);      // tensors < 2^31 elements (checked on the host)
+    const unsigned e = (unsigned)(tile_pix<TWS>(p, b, oy0, pl) * p.Cout + n0 + cc);      // tensors < 2^31 elements (checked on the host)
     if (p.bias) {
       float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + cc);
       float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + cc + 4);
@@ -305,7 +315,7 @@ __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* s
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + c) * 2]; q += part[(w * BN + c) * 2 + 1]; }
-      reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (oy0 / R)) * p.Cout + n0 + c] = make_float2(a, q);
+      reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (TWS ? p.rs_tidx : oy0 / R)) * p.Cout + n0 + c] = make_float2(a, q);
     }
   }
 }
@@ -512,7 +522,7 @@ __device__ __forceinline__ void gnb_epilogue(const C3P& p, const f32x4_t (&acc)[
 // through LDS); the sums are of the bf16-rounded du, i.e. of what the consumer of du will read.
 // this thread's vectors of the GroupNorm input x for the du epilogue (x [.., C1] | x2 [.., C - C1], C1 % BN == 0: a cout
 // tile lies in one of them): issued by the caller while its last MFMA phase still runs, consumed by due_epilogue
-template <int BM, int BN, int NT>
+template <int BM, int BN, int NT, int TWS = 0>
 __device__ __forceinline__ void due_fetch_x(const C3P& p, uint4 (&xr)[BM * (BN / 8) / NT], int b, int oy0, int n0, int KT, int tid) {
   constexpr int CPR = BN / 8, NI = BM * CPR / NT;
   const int C = p.Cout, cc = (tid % CPR) * 8;
@@ -526,7 +536,7 @@ __device__ __forceinline__ void due_fetch_x(const C3P& p, uint4 (&xr)[BM * (BN /
   for (int k = 0; k < NI; ++k) {
     const int pl = (tid + k * NT) / CPR;
     xr[k] = make_uint4(0, 0, 0, 0);
-    if (pl < KT) xr[k] = *reinterpret_cast<const uint4*>(xs + ((size_t)(b * p.H + oy0) * p.W + pl) * xpitch + xc);
+    if (pl < KT) xr[k] = *reinterpret_cast<const uint4*>(xs + (size_t)tile_pix<TWS>(p, b, oy0, pl) * xpitch + xc);
   }
 }
 
@@ -545,7 +555,7 @@ __device__ __forceinline__ void due_fetch_coef(const C3P& p, int b, int n0, int 
 }
 
 // second half of due_epilogue: dA [BM][BN + 4] is in LDS (the caller's barrier is behind it).  LDSONLY as lds_epilogue_tail's.
-template <int BM, int BN, int NT, bool LDSONLY, bool SILU, bool DROP>
+template <int BM, int BN, int NT, bool LDSONLY, bool SILU, bool DROP, int TWS = 0>
 __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
                                                     const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
                                                     uint64_t seedv) {
@@ -568,7 +578,7 @@ __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char*
       const uint32_t w4[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) { xv[2 * i] = __uint_as_float(w4[i] << 16); xv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
-      const unsigned e0 = (unsigned)(((b * p.H + oy0) * W + pl) * C + n0 + cc);      // index in the dense activated tensor (< 2^31: host check)
+      const unsigned e0 = (unsigned)(tile_pix<TWS>(p, b, oy0, pl) * C + n0 + cc);      // index in the dense activated tensor (< 2^31: host check)
       const uint32_t h = DROP ? idf_vec_hash(seedv, p.salt, e0 >> 3) : 0u;
 #pragma unroll
       for (int g0 = 0; g0 < 8; g0 += 4)
@@ -604,21 +614,21 @@ __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char*
     float a = 0.f, q = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + c) * 2]; q += part[(w * BN + c) * 2 + 1]; }
-    reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (oy0 / R)) * C + n0 + c] = make_float2(a, q);
+    reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (TWS ? p.rs_tidx : oy0 / R)) * C + n0 + c] = make_float2(a, q);
   }
 }
 
 
 // the activation / dropout switches are launch-uniform: resolved ONCE per tile, each case straight-line (with the conditions inside
 // the vector loop hipcc emitted a branch, a wait and a partial copy of the body per 4 elements)
-template <int BM, int BN, int NT, bool LDSONLY = false>
+template <int BM, int BN, int NT, bool LDSONLY = false, int TWS = 0>
 __device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
                                                   const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
                                                   uint64_t seedv) {
   if (p.act == 2) {
-    if (p.seed != nullptr) due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, true>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
-    else due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, false>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
-  } else due_epilogue_tail_t<BM, BN, NT, LDSONLY, false, false>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+    if (p.seed != nullptr) due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, true, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+    else due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, false, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+  } else due_epilogue_tail_t<BM, BN, NT, LDSONLY, false, false, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
 }
 
 template <int TM, int TN, int BM, int BN, int NT>

@@ -58,15 +58,19 @@ __device__ __forceinline__ unsigned long long rs_now() {
 #define RS_FLUSH
 #endif
 
-template <int W>
+// NPH = pixel halves per workgroup: 2 -> a 512-thread workgroup owns the whole 256-pixel tile (R rows x W columns), one per CU;
+// 1 -> a 256-thread workgroup owns one half-width tile (R rows x W / 2 columns = 128 pixels), TWO independent workgroups per CU:
+// while one sits in its epilogue (vector pipe) the other runs its MFMA loop on the same SIMDs, and a barrier stalls four waves,
+// not eight.
+template <int W, int NPH>
 struct RsGeo {
-  static constexpr int R = 256 / W, WH = W + 2, HR = R + 2, NPH = HR * WH;
-  static constexpr int CHB = NPH * 64 + 64;     // bytes of one 32-channel chunk image; == 64 (mod 128): the two chunks a ds_write_b128
-                                                // lane group covers fall into different halves of the 32 store banks
-  static constexpr int NCB = W / 32;            // 16-pixel column blocks per wave (two pixel halves x NCB x 16 = W)
-  static constexpr int WS = W == 64 ? 6 : 5;
+  static constexpr int R = 256 / W, TW = W * NPH / 2, WH = TW + 2, HR = R + 2, NPH_ = NPH, NPHW = HR * WH;
+  static constexpr int CHB = NPHW * 64 + ((NPHW * 64) % 128 == 0 ? 64 : 0);     // bytes of one 32-channel chunk image; == 64 (mod 128): the
+                                                // two chunks a ds_write_b128 lane group covers fall into different halves of the 32 store banks
+  static constexpr int NCB = W / 32;            // 16-pixel column blocks per wave
+  static constexpr int TWS = TW == 64 ? 6 : (TW == 32 ? 5 : 4);
   static_assert(W == 64 || W == 32, "64x64 / 32x32 maps");
-  static_assert((NPH * 64) % 128 == 0, "chunk image pitch");
+  static_assert(NPH == 1 || NPH == 2, "one or two pixel halves");
 };
 
 // (mean, rstd) of a group from (sum, sum of squares): idf_resblock.hip's group_stats (mu / var in double, 1 / sqrt as v_rsq_f32 +
@@ -82,26 +86,31 @@ __device__ __forceinline__ void rs_group_stats(double a, double d, double inv_n,
 }
 
 // EPI: 0 plain (bias, residual, statistics partials of y), 2 the backward chain's du epilogue (idf_conv_dgrad_chain_bf16's)
-template <int W, int CIN, bool PRO, int EPI>
-__global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
-  using G = RsGeo<W>;
-  constexpr int R = G::R, WH = G::WH, HR = G::HR, CHB = G::CHB, NCB = G::NCB, WS = G::WS;
-  constexpr int NT = 512, BM = 256, BN = 64, KP = CIN / 64, NCH = CIN / 32;
-  constexpr int PIECES = CIN / 8, PXK = NT / PIECES, HV = HR * W * PIECES / NT;     // 16-byte vectors per pixel / pixels per round / rounds
+template <int W, int CIN, bool PRO, int EPI, int NPH>
+__global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
+  using G = RsGeo<W, NPH>;
+  constexpr int R = G::R, TW = G::TW, WH = G::WH, HR = G::HR, CHB = G::CHB, NCB = G::NCB, TWS = G::TWS;
+  constexpr int NT = 256 * NPH, BM = R * TW, BN = 64, KP = CIN / 64, NCH = CIN / 32;
+  constexpr int PIECES = CIN / 8, PXK = NT / PIECES, HV = HR * TW * PIECES / NT;     // 16-byte vectors per pixel / pixels per round / rounds
+  constexpr int RPK = PXK / TW;                                                       // halo rows per round (1, or 2 for 64 channels at 32x32)
+  constexpr int NEV = HR * 2 * PIECES, NE = (NEV + NT - 1) / NT;                      // the two halo columns: vectors, rounds
+  constexpr int TWP = NPH == 2 ? 0 : TWS;                                             // the tails' pixel map: whole rows / half-width tiles
   constexpr bool DUE = EPI == 2;
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel pairs");
-  static_assert((HR * W * PIECES) % NT == 0, "whole rounds");
+  static_assert(PXK == RPK * TW && HV * RPK == HR, "whole halo rows per staging round");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int cg = wave & 3, ph = wave >> 2;            // cout group of 16, pixel half
+  const int cg = wave & 3, ph = wave >> 2;            // cout group of 16, pixel half (NPH = 1: always 0)
   const int wgid = xcd_tile_id(blockIdx.x, gridDim.x);
   int item = wgid * p.rs_per;
   const int item_end = min(item + p.rs_per, p.rs_total);
   if (item >= item_end) return;
-  const int npt = p.B * p.tiles_per_img;
+  const int TR = p.H / R, halves = p.rs_halves;      // row strips per image; tiles per strip (1 or 2)
+  const int npt = p.B * halves * TR;                  // pixel tiles: ((image, half), strip) -- a workgroup's consecutive items are
+                                                      // vertically adjacent tiles of one image half
 
   unsigned char* const Os = smem + p.rs_os_off;
   float* const cof = reinterpret_cast<float*>(smem + p.rs_cof_off);     // PRO: (sc, sh) [CIN][2] | channel sums [CIN][2]
@@ -109,9 +118,24 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
   C3P pe = p;                                          // the epilogue tails address their scratch relative to the fp32 tile
   pe.aux_off = p.aux_off - p.rs_os_off;
 
-  // ---- this thread's slot in the row staging: vector v = tid + NT * k  ->  pixel (tid / PIECES) + k * PXK of the halo rows'
-  // interior, 8-channel piece tid % PIECES (the same piece in every round: its coefficients stay in registers)
-  const int piece = tid & (PIECES - 1), pbase = tid / PIECES;
+#ifndef IDF_RS_SKEW
+#define IDF_RS_SKEW 1
+#endif
+  if constexpr (NPH == 1 && IDF_RS_SKEW) {
+    // two workgroups per CU that start together stay in lockstep -- both in their MFMA loops, both in their epilogues.  The one in
+    // the CU's second wave slots (HW_ID.WAVE_ID odd: the later arrival) starts half a tile period late; from then on one's vector
+    // phases face the other's matrix phases.
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));
+    if (hwid & 1) {
+#pragma unroll 1
+      for (int i = 0; i < p.rs_skew; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
+  // ---- this thread's slot in the row staging: round k = halo row(s) RPK k (+ prl), pixel ppx of the tile's TW columns, 8-channel
+  // piece tid % PIECES (the same piece in every round: its coefficients stay in registers)
+  const int piece = tid & (PIECES - 1), prl = (tid / PIECES) / TW, ppx = (tid / PIECES) % TW;
   const int pch = piece >> 2, pq = piece & 3;
   // ---- this lane's fragment addresses: column blocks x0 = 16 * (NCB * ph + jj), taps kx = 0..2
   int lp[NCB][3];
@@ -123,8 +147,16 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
       lp[jj][kx] = hx * 64 + ((fq ^ (((hx >> 2) & 1) << 1)) << 4);
     }
 
-  int nt = item / npt, pt = item - nt * npt;
-  int b = pt / p.tiles_per_img, oy0 = (pt - b * p.tiles_per_img) * R, n0 = nt * BN;
+  // item -> (cout tile, image, half, strip)
+  int nt, b, half, oy0, n0;
+  auto decode = [&](int it, int& nt_, int& b_, int& half_, int& oy_, int& n0_) __attribute__((always_inline)) {
+    nt_ = it / npt;
+    const int pt = it - nt_ * npt, bh = pt / TR;
+    oy_ = (pt - bh * TR) * R;
+    b_ = halves == 2 ? bh >> 1 : bh; half_ = halves == 2 ? bh & 1 : 0;
+    n0_ = nt_ * BN;
+  };
+  decode(item, nt, b, half, oy0, n0);
 
   // ---- weights: this wave's 16 couts, one 64-channel pair = 18 fragments
   bf16x8_t Wf[2][9];
@@ -132,9 +164,10 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     return reinterpret_cast<const bf16x8_t*>(p.w + ((size_t)((kp * (p.Cout >> 4) + n16) * 18 + tap * 2 + c) * 64 + lane) * 8);
   };
 
-  // ---- GroupNorm fold.  Phase 1 (first image of the workgroup): the T1 <= 16 partial sums and this channel's parameters on
+  // ---- GroupNorm fold.  Phase 1 (first image of the workgroup): the T1 <= 32 partial sums and this channel's parameters on
   // their way, every load issued before anything waits (clamped addresses + a 0 / 1 factor: no branch, no per-load wait)
-  struct FoldRegs { float2 fpart[PRO ? 16 : 1]; float fpar[6]; };
+  constexpr int FT = 32;
+  struct FoldRegs { float2 fpart[PRO ? FT : 1]; float fpar[6]; };
   auto fold_params = [&](int bb, float (&fpar)[6]) __attribute__((always_inline)) {
     fpar[0] = 1.f; fpar[1] = fpar[2] = fpar[3] = fpar[4] = fpar[5] = 0.f;
     if (p.gamma) fpar[0] = p.gamma[tid];
@@ -147,22 +180,23 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
       if (tid < CIN) {
         const float2* src = reinterpret_cast<const float2*>(p.st1) + (size_t)bb * p.T1 * CIN + tid;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) fr_.fpart[j] = src[(size_t)min(j, p.T1 - 1) * CIN];
+        for (int j = 0; j < FT; ++j) fr_.fpart[j] = src[(size_t)min(j, p.T1 - 1) * CIN];
         fold_params(bb, fr_.fpar);
       }
     }
   };
-  // phase 2: (sc, sh) per channel into LDS (idf_conv3x3_parts.h's pro_coefficients; the sums in idf_sum_partials' order).
-  // fast: the sums come from phase 1's registers; else (the workgroup crosses into another image: rare) a plain loop
+  // phase 2: (sc, sh) per channel into LDS (idf_conv3x3_parts.h's pro_coefficients; the sums in idf_sum_partials' order: batches
+  // of 16, two interleaved chains).  fast: the sums come from phase 1's registers; else (the workgroup crosses into another
+  // image: rare) a plain loop
   auto fold_finish = [&](int bb, bool writer, bool fast, FoldRegs& fr_) __attribute__((always_inline)) {
     if constexpr (PRO) {
       float (&fpar)[6] = fr_.fpar;
-      float2 (&fpart)[PRO ? 16 : 1] = fr_.fpart;
+      float2 (&fpart)[PRO ? FT : 1] = fr_.fpart;
       if (tid < CIN) {
         float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
         if (fast) {
 #pragma unroll
-          for (int j = 0; j < 16; j += 2) {
+          for (int j = 0; j < FT; j += 2) {
             const float m0 = j < p.T1 ? 1.f : 0.f, m1 = j + 1 < p.T1 ? 1.f : 0.f;
             s0 += m0 * fpart[j].x; q0 += m0 * fpart[j].y; s1 += m1 * fpart[j + 1].x; q1 += m1 * fpart[j + 1].y;
           }
@@ -199,36 +233,83 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     }
   };
 
-  // ---- rows of a tile: global -> registers (in flight), registers -> (transform) -> LDS image
-  u32x4_t rows[HV];
-  auto issue_rows = [&](int bb, int oy) __attribute__((always_inline)) {
+  // ---- rows of a tile: global -> registers (in flight), registers -> (transform) -> LDS image.  rows[k]: halo row k, the tile's own
+  // TW columns; edge[j]: the two halo columns (image border: zero; half-width tiles: the neighbouring half's first / last column)
+  u32x4_t rows[HV], edge[NE];
+  auto edge_slot = [&](int j, int& ly, int& hx, int& ix, int& epiece, int x0) __attribute__((always_inline)) -> bool {
+    const int ev = tid + NT * j;
+    epiece = ev & (PIECES - 1);
+    const int side = (ev / PIECES) & 1;
+    ly = ev / (2 * PIECES);
+    hx = side ? WH - 1 : 0;
+    ix = x0 + (side ? TW : -1);
+    return ev < NEV;
+  };
+  auto issue_rows = [&](int bb, int oy, int x0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-      const int pv = pbase + k * PXK, ly = pv >> WS, px = pv & (W - 1), iy = oy + ly - 1;
+      const int iy = oy + k * RPK + prl - 1;
       rows[k] = u32x4_t{0, 0, 0, 0};
       if ((unsigned)iy < (unsigned)p.H)
-        rows[k] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + px) * CIN + piece * 8));
+        rows[k] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + x0 + ppx) * CIN + piece * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      int ly, hx, ix, ep;
+      const bool in = edge_slot(j, ly, hx, ix, ep, x0);
+      const int iy = oy + ly - 1;
+      edge[j] = u32x4_t{0, 0, 0, 0};
+      if (in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+        edge[j] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + ix) * CIN + ep * 8));
     }
   };
   uint64_t seedv = 0;
   bool drop = false;
   if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
-  auto write_rows = [&](int bb, int oy, bool keep_a) __attribute__((always_inline)) {
+  auto write_rows = [&](int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
     float scv[8], shv[8];
-    if constexpr (PRO) {
+    auto coefs = [&](int pc) __attribute__((always_inline)) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * (piece * 8) + 4 * q4);
+        const float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * (pc * 8) + 4 * q4);
         scv[2 * q4] = t4.x; shv[2 * q4] = t4.y; scv[2 * q4 + 1] = t4.z; shv[2 * q4 + 1] = t4.w;
+      }
+    };
+    if constexpr (PRO) {
+      // the halo columns first (their piece differs from the thread's row piece)
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        int ly, hx, ix, ep;
+        const bool in = edge_slot(j, ly, hx, ix, ep, x0);
+        const int iy = oy + ly - 1;
+        if (in) {
+          u32x4_t v = edge[j];
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {
+            coefs(ep);
+            const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + ix) * CIN + ep * 8);
+            const uint4 a4 = pro_vec<8>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+            v = u32x4_t{a4.x, a4.y, a4.z, a4.w};
+          }
+          *reinterpret_cast<u32x4_t*>(smem + (ep >> 2) * CHB + (ly * WH + hx) * 64 + (((ep & 3) ^ (((hx >> 2) & 1) << 1)) << 4)) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      coefs(piece);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        int ly, hx, ix, ep;
+        if (edge_slot(j, ly, hx, ix, ep, x0))
+          *reinterpret_cast<u32x4_t*>(smem + (ep >> 2) * CHB + (ly * WH + hx) * 64 + (((ep & 3) ^ (((hx >> 2) & 1) << 1)) << 4)) = edge[j];
       }
     }
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-      const int pv = pbase + k * PXK, ly = pv >> WS, px = pv & (W - 1), iy = oy + ly - 1, hx = px + 1;
+      const int ly = k * RPK + prl, iy = oy + ly - 1, hx = ppx + 1;
       u32x4_t v = rows[k];
       if constexpr (PRO) {
         if ((unsigned)iy < (unsigned)p.H) {            // rows outside the image stay zero (the reference pads the ACTIVATED tensor)
-          const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + px) * CIN + piece * 8);
+          const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + x0 + ppx) * CIN + piece * 8);
           const uint4 a4 = pro_vec<8>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
           v = u32x4_t{a4.x, a4.y, a4.z, a4.w};
           if (keep_a && ly >= 1 && ly <= R) *reinterpret_cast<u32x4_t*>(p.a_out + e0) = v;
@@ -244,19 +325,10 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
   {
   FoldRegs f0;
   if (PRO) fold_issue(b, f0);
-  issue_rows(b, oy0);
+  issue_rows(b, oy0, half * TW);
   RS_STAMP(ts1);
   RS_ADD(0, ts0, ts1);
-  // the image's left / right halo columns: zero, once (nothing ever writes them again)
-  {
-    constexpr int NZ = NCH * HR * 8;
-    static_assert(NZ <= NT, "one zero vector per thread");
-    if (tid < NZ) {
-      const int c = tid / (HR * 8), rem = tid - c * (HR * 8), ly = rem >> 3, hx = (rem & 4) ? WH - 1 : 0;
-      *reinterpret_cast<u32x4_t*>(smem + c * CHB + (ly * WH + hx) * 64 + (rem & 3) * 16) = u32x4_t{0, 0, 0, 0};
-    }
-  }
-  if (PRO) fold_finish(b, oy0 == 0 && n0 == 0, true, f0);
+  if (PRO) fold_finish(b, oy0 == 0 && n0 == 0 && half == 0, true, f0);
   RS_STAMP(ts2);
   RS_ADD(1, ts1, ts2);
   }
@@ -264,7 +336,7 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
   // the weights land behind the rows (and behind the fold's registers): their latency hides under the first tile's transform
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) { Wf[0][tap] = *wsrc(0, (n0 >> 4) + cg, 0, tap); Wf[1][tap] = *wsrc(0, (n0 >> 4) + cg, 1, tap); }
-  write_rows(b, oy0, PRO && p.a_out != nullptr && n0 == 0);
+  write_rows(b, oy0, half * TW, PRO && p.a_out != nullptr && n0 == 0);
   RS_STAMP(ts3);
   RS_ADD(2, ts2b, ts3);
   lds_barrier();
@@ -274,22 +346,19 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
   for (;;) {
     RS_STAMP(tt0);
     const bool has_next = item + 1 < item_end;
-    int nnt = nt, nb = b, noy0 = oy0, nn0 = n0;
-    if (has_next) {
-      nnt = (item + 1) / npt;
-      const int npt_i = item + 1 - nnt * npt;
-      nb = npt_i / p.tiles_per_img; noy0 = (npt_i - nb * p.tiles_per_img) * R; nn0 = nnt * BN;
-    }
+    int nnt = nt, nb = b, nhalf = half, noy0 = oy0, nn0 = n0;
+    if (has_next) decode(item + 1, nnt, nb, nhalf, noy0, nn0);
+    pe.rs_x0 = half * TW; pe.rs_tidx = (oy0 / R) * halves + half;
     // ---- what the epilogue reads from memory, then the next tile's rows (vmcnt is in order: the epilogue's operands first)
     uint4 due_xr[DUE ? BM * (BN / 8) / NT : 1];
     float dscv[8], dshv[8];
     uint64_t dseed = 0;
     if constexpr (DUE) {
-      due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, BM, tid);
+      due_fetch_x<BM, BN, NT, TWP>(pe, due_xr, b, oy0, n0, BM, tid);
       due_fetch_coef<BN>(p, b, n0, tid, dscv, dshv, dseed);
     }
     const bool refold = PRO && has_next && nb != b;       // the workgroup crosses into the next image (never at one or two tiles per CU)
-    if (has_next) issue_rows(nb, noy0);
+    if (has_next) issue_rows(nb, noy0, nhalf * TW);
     RS_STAMP(tt1);
     RS_ADD(4, tt0, tt1);
 
@@ -349,14 +418,14 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
       for (int jj = 0; jj < NCB; ++jj)
 #pragma unroll
         for (int orow = 0; orow < R; ++orow) {
-          const int pl = orow * W + (NCB * ph + jj) * 16 + fr;
+          const int pl = orow * TW + (NCB * ph + jj) * 16 + fr;
           const f32x4_t a = acc[jj * R + orow];
           *reinterpret_cast<float4*>(O + pl * PF + cg * 16 + fq * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
     }
     if (has_next) {
-      if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0, false, f1); }
-      write_rows(nb, noy0, PRO && p.a_out != nullptr && nn0 == 0);
+      if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
+      write_rows(nb, noy0, nhalf * TW, PRO && p.a_out != nullptr && nn0 == 0);
     }
     RS_STAMP(tt4);
     RS_ADD(7, tt3, tt4);
@@ -364,10 +433,10 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     RS_STAMP(tt5);
     RS_ADD(8, tt4, tt5);
     if constexpr (DUE) {
-      due_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
+      due_epilogue_tail<BM, BN, NT, true, TWP>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
     } else {
       uint4 none[(BM * (BN / 8) + NT - 1) / NT];
-      lds_epilogue_tail<BM, BN, NT, true>(pe, Os, b, oy0, n0, BM, tid, none, false);
+      lds_epilogue_tail<BM, BN, NT, true, TWP>(pe, Os, b, oy0, n0, BM, tid, none, false);
     }
     RS_STAMP(tt6);
     RS_ADD(9, tt5, tt6);
@@ -376,7 +445,7 @@ __global__ __launch_bounds__(512) void conv_rs_bf16(const C3P p) {
     rs_sum[11] += 1;
 #endif
     if (!has_next) break;
-    ++item; nt = nnt; b = nb; oy0 = noy0; n0 = nn0;
+    ++item; nt = nnt; b = nb; half = nhalf; oy0 = noy0; n0 = nn0;
   }
   RS_FLUSH;
 }
@@ -390,8 +459,9 @@ namespace {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------- host
-const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;
+const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;          // 0 off, 1 two 256-thread workgroups per CU, 2 one of 512
 const int g_rs_min = getenv("IDF_CONV_RS_MIN") ? atoi(getenv("IDF_CONV_RS_MIN")) : 128;     // work items below which the launch leaves most CUs idle
+const int g_rs_skew = getenv("IDF_CONV_RS_SKEW") ? atoi(getenv("IDF_CONV_RS_SKEW")) : 2;   // start delay of a CU's second workgroup, ~1 us units
 
 // tiles per image (= T of the statistics partials) or 0 when the form does not cover the shape
 int rs_tiles(int B, int H, int W, int Cin, int Cout) {
@@ -400,7 +470,7 @@ int rs_tiles(int B, int H, int W, int Cin, int Cout) {
   if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31) || (long)Cout * 9 * Cin >= (1L << 31)) return 0;
   const int T = H / (256 / W);
   if ((long)B * T * (Cout / 64) < g_rs_min) return 0;
-  return T;
+  return g_rs == 2 ? T : 2 * T;
 }
 
 int rs_ncu() {
@@ -413,34 +483,42 @@ int rs_ncu() {
   return ncu;
 }
 
-template <int W, int CIN, bool PRO, int EPI>
+template <int W, int CIN, bool PRO, int EPI, int NPH>
 int launch_rs(C3P& p, hipStream_t st) {
-  using G = RsGeo<W>;
-  p.R = G::R; p.tiles_per_img = p.H / G::R; p.n_tiles = p.Cout / 64;
+  using G = RsGeo<W, NPH>;
+  constexpr int halves = 3 - NPH;
+  p.R = G::R; p.rs_halves = halves; p.tiles_per_img = (p.H / G::R) * halves; p.n_tiles = p.Cout / 64;
   p.rs_total = p.B * p.tiles_per_img * p.n_tiles;
-  const int ncu = rs_ncu();
-  p.rs_per = idf_cdiv(p.rs_total, ncu);
+  p.rs_skew = g_rs_skew;
+  const int slots = rs_ncu() * halves;               // workgroups resident at once
+  p.rs_per = idf_cdiv(p.rs_total, slots);
   const int grid = idf_cdiv(p.rs_total, p.rs_per);
   size_t lds = (size_t)(CIN / 32) * G::CHB;
   p.rs_os_off = (int)lds;
-  lds += (size_t)256 * (64 + 4) * sizeof(float);
+  lds += (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
   p.aux_off = (int)lds;
-  lds += (size_t)8 * 64 * 8;                      // wave partials of the statistics
+  lds += (size_t)4 * NPH * 64 * 8;                // wave partials of the statistics
   p.rs_cof_off = (int)lds;
   if (PRO) lds += (size_t)CIN * 16;
-  if (lds > 160 * 1024) return 1;
-  auto kern = conv_rs_bf16<W, CIN, PRO, EPI>;
+  if (lds > 160 * 1024 / halves) return 1;
+  auto kern = conv_rs_bf16<W, CIN, PRO, EPI, NPH>;
   static IdfLdsGrant grant;
   if (idf_ensure_lds((const void*)kern, lds, grant) != hipSuccess) return 2;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * NPH), lds, st, p);
   return 0;
 }
 
 template <bool PRO, int EPI>
 int dispatch_rs(C3P& p, hipStream_t st) {
-  if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, PRO, EPI>(p, st);
-  if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, PRO, EPI>(p, st);
-  if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, PRO, EPI>(p, st);
+  if (g_rs == 2) {
+    if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, PRO, EPI, 2>(p, st);
+    if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, PRO, EPI, 2>(p, st);
+    if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, PRO, EPI, 2>(p, st);
+    return 3;
+  }
+  if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, PRO, EPI, 1>(p, st);
+  if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, PRO, EPI, 1>(p, st);
+  if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, PRO, EPI, 1>(p, st);
   return 3;
 }
 
@@ -452,13 +530,13 @@ int dispatch_rs(C3P& p, hipStream_t st) {
 extern "C" int idf_conv_rs_tiles(int B, int H, int W, int Cin, int Cout) { return rs_tiles(B, H, W, Cin, Cout); }
 
 // y = conv3x3(dropout(SiLU(FiLM(GroupNorm(x))))) + bias (+ res): idf_conv_gn_bf16's contract (taps 9, one source) with the weights
-// fragment-major (idf_pack_conv_weights_batched's w_frag: [Cin / 64][Cout / 16][tap][half][lane][8]).  T1 <= 16.
+// fragment-major (idf_pack_conv_weights_batched's w_frag: [Cin / 64][Cout / 16][tap][half][lane][8]).  T1 <= 32.
 extern "C" int idf_conv_rs_gn_bf16(const void* x, const float* st1, int T1, const float* gamma, const float* beta, const float* film_t,
                                    const float* film_a, int ld_t, int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt,
                                    float p_drop, const void* w_frag, const float* bias, const void* res, void* y, void* a_out,
                                    float* mean, float* rstd, float* sc, float* sh, float* st_out, int B, int H, int W, int Cin,
                                    int Cout, void* stream) {
-  if (!rs_tiles(B, H, W, Cin, Cout) || T1 < 1 || T1 > 16)
+  if (!rs_tiles(B, H, W, Cin, Cout) || T1 < 1 || T1 > 32)
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_gn_bf16: B%d H%d W%d Cin%d Cout%d T1 %d not covered", B, H, W, Cin, Cout, T1);
   if (!x || !st1 || !w_frag || !y) IDF_FAIL(IDF_ERR_BADARG, "conv_rs_gn_bf16: null argument");
   if (act != 1 && act != 2) IDF_FAIL(IDF_ERR_BADARG, "conv_rs_gn_bf16: act must be 1 or 2");

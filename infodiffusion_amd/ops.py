@@ -289,7 +289,7 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
              _p(wfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout, _st())
         return y, a, mean, rstd, sc, sh, st
     rfrag = None
-    if taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 16:
+    if taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 32:
         rfrag = _rs_frag(shadows, 2, B, H, W, Cin, Cout)
     if rfrag is not None:
         # 64x64 / 32x32: weights fragment-major into registers, whole-K halo image in LDS, row reuse, persistent over the CU's tiles

@@ -632,7 +632,7 @@ def test_conv_rs_groupnorm_prologue_conv_vs_pytorch(case):
     seed = torch.tensor([123456789], dtype=torch.int64, device=DEV) if p_drop else None
     sh_ = _FragShadows(w)
     T = ops.rs_tiles(B, H, H, C, Cout)
-    assert T == H // (256 // H), (case, T)
+    assert T in (H // (256 // H), 2 * (H // (256 // H))), (case, T)      # whole-row tiles, or two half-width tiles per strip
     st1 = ops.gn_partials_raw(x1)
     if st1.shape[1] > 16:         # the form takes what a conv producer leaves: <= 16 partials per image (regrouped sums are partials too)
         st1 = st1.view(B, 16, st1.shape[1] // 16, C, 2).sum(dim=2).contiguous()
@@ -702,7 +702,7 @@ def test_conv_rs_backward_chain_du_epilogue_vs_pytorch_autograd(case):
     want = _gn_act_conv_reference(xc, gam, bet, ft, fa, act, mask, wgt, dy, res)
     mean, rstd, sc, sh = ops.gn_coef_fwd_raw(xc, gam, bet, ft, fa)
     T = ops.rs_tiles(B, H, W, Cin, C)
-    assert T == H // (256 // H)
+    assert T in (H // (256 // H), 2 * (H // (256 // H)))
     names = []
     orig = ops.call
     ops.call = lambda n, *a: (names.append(n), orig(n, *a))[1]

@@ -69,6 +69,9 @@ struct RsGeo {
                                                 // two chunks a ds_write_b128 lane group covers fall into different halves of the 32 store banks
   static constexpr int NCB = W / 32;            // 16-pixel column blocks per wave
   static constexpr int TWS = TW == 64 ? 6 : (TW == 32 ? 5 : 4);
+  static constexpr bool ALIAS_OS(int cin) {
+    return NPH == 1 && (size_t)(cin / 32) * CHB + (size_t)R * TW * 68 * 4 + 4 * NPH * 64 * 8 + (size_t)cin * 16 > 80 * 1024;
+  }
   static_assert(W == 64 || W == 32, "64x64 / 32x32 maps");
   static_assert(NPH == 1 || NPH == 2, "one or two pixel halves");
 };
@@ -96,6 +99,9 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   constexpr int NEV = HR * 2 * PIECES, NE = (NEV + NT - 1) / NT;                      // the two halo columns: vectors, rounds
   constexpr int TWP = NPH == 2 ? 0 : TWS;                                             // the tails' pixel map: whole rows / half-width tiles
   constexpr bool DUE = EPI == 2;
+  // two workgroups per CU have 80 KB of LDS each: where the chunk images and the fp32 epilogue tile do not fit side by side the
+  // tile takes the images' place (the next tile's rows then wait in registers until the epilogue has read it)
+  constexpr bool ALIAS = G::ALIAS_OS(CIN);
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel pairs");
   static_assert(PXK == RPK * TW && HV * RPK == HR, "whole halo rows per staging round");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
           *reinterpret_cast<float4*>(O + pl * PF + cg * 16 + fq * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
     }
-    if (has_next) {
+    if (!ALIAS && has_next) {
       if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
       write_rows(nb, noy0, nhalf * TW, PRO && p.a_out != nullptr && nn0 == 0);
     }
@@ -445,6 +451,12 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     rs_sum[11] += 1;
 #endif
     if (!has_next) break;
+    if constexpr (ALIAS) {
+      lds_barrier();                                   // the fp32 tile has been read: the images' place is free again
+      if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
+      write_rows(nb, noy0, nhalf * TW, PRO && p.a_out != nullptr && nn0 == 0);
+      lds_barrier();
+    }
     ++item; nt = nnt; b = nb; half = nhalf; oy0 = noy0; n0 = nn0;
   }
   RS_FLUSH;
@@ -494,8 +506,9 @@ int launch_rs(C3P& p, hipStream_t st) {
   p.rs_per = idf_cdiv(p.rs_total, slots);
   const int grid = idf_cdiv(p.rs_total, p.rs_per);
   size_t lds = (size_t)(CIN / 32) * G::CHB;
-  p.rs_os_off = (int)lds;
-  lds += (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
+  const size_t osz = (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
+  if (G::ALIAS_OS(CIN)) { p.rs_os_off = 0; if (osz > lds) lds = osz; }
+  else { p.rs_os_off = (int)lds; lds += osz; }
   p.aux_off = (int)lds;
   lds += (size_t)4 * NPH * 64 * 8;                // wave partials of the statistics
   p.rs_cof_off = (int)lds;

@@ -122,8 +122,8 @@ __device__ __forceinline__ void store_out(bf16_t* __restrict__ dst, int ld, cons
   bf16_t* p = dst + (size_t)(lane & 15) * ld + (lane >> 4) * 4;
 #pragma unroll
   for (int c = 0; c < ACfg<D>::CT; ++c) {
-    uint32_t lo = (uint32_t)f32_to_bf16(out[c][0] * alpha) | ((uint32_t)f32_to_bf16(out[c][1] * alpha) << 16);
-    uint32_t hi = (uint32_t)f32_to_bf16(out[c][2] * alpha) | ((uint32_t)f32_to_bf16(out[c][3] * alpha) << 16);
+    uint32_t lo = idf_pack_bf16(out[c][0] * alpha, out[c][1] * alpha);
+    uint32_t hi = idf_pack_bf16(out[c][2] * alpha, out[c][3] * alpha);
     *reinterpret_cast<uint2*>(p + c * 16) = make_uint2(lo, hi);
   }
 }
@@ -369,7 +369,7 @@ __device__ __forceinline__ void ab_unpack(const uint4& r, float* o) {
   for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 __device__ __forceinline__ uint32_t ab_pack2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  return idf_pack_bf16(lo, hi);
 }
 // the B fragments of a product contracting over channels, from accumulator tiles that hold channels 16 c + 4 (lane >> 4) + r:
 // k slot (g, e) of step s = channel 32 s + 4 g + e (e < 4) / 32 s + 16 + 4 g + e - 4

@@ -65,6 +65,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t*>(&h);
 }
 
+// two floats -> one dword of bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN), where two scalar
+// casts cost two conversions, a shift and an or
+typedef __attribute__((ext_vector_type(2))) float idf_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 idf_bf16x2_t;
+__device__ __forceinline__ uint32_t idf_pack_bf16(float lo, float hi) {
+  const idf_f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, idf_bf16x2_t));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;  // elements per 16-byte vector
@@ -102,7 +111,7 @@ template <> struct Vec16<bf16_t> {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+      w[i] = idf_pack_bf16(o[2 * i], o[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + e) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
-          uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-          uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+          uint32_t lo = idf_pack_bf16(o[0], o[1]);
+          uint32_t hi = idf_pack_bf16(o[2], o[3]);
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Y) + e) = make_uint2(lo, hi);
         }
       } else {

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
           for (int i = 0; i < 4; ++i) {
             const float lo = av[2 * i] * __uint_as_float(d4[i] << 16) + k1v[2 * i] * __uint_as_float(x4[i] << 16) + k0v[2 * i];
             const float hi = av[2 * i + 1] * __uint_as_float(d4[i] & 0xffff0000u) + k1v[2 * i + 1] * __uint_as_float(x4[i] & 0xffff0000u) + k0v[2 * i + 1];
-            o4[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+            o4[i] = idf_pack_bf16(lo, hi);
           }
           hreg[k] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
           if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.dyp_out + (unsigned)(hoff[k] + ck * CK)) = hreg[k];
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
               o[0] += __uint_as_float(rr[a].x << 16); o[1] += __uint_as_float(rr[a].x & 0xffff0000u);
               o[2] += __uint_as_float(rr[a].y << 16); o[3] += __uint_as_float(rr[a].y & 0xffff0000u);
             }
-            const uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-            const uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            const uint32_t lo = idf_pack_bf16(o[0], o[1]);
+            const uint32_t hi = idf_pack_bf16(o[2], o[3]);
             *reinterpret_cast<uint2*>(stg + fr * SROW + (a * 16 + fq * 4) * 2) = make_uint2(lo, hi);
             if (wants) {                                    // wave-uniform: statistics of the rounded values
               const f32x4_t rv = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),

@@ -73,7 +73,6 @@ struct C3P {
   // (cout tile, pixel tile) items of the rs_total; LDS: chunk images | fp32 epilogue tile at rs_os_off | statistics scratch at
   // aux_off | coefficients at rs_cof_off
   int rs_per, rs_total, rs_os_off, rs_cof_off;
-  int rs_skew;                     // start delay of the workgroup in a CU's second wave slots (units of ~1 us)
   int rs_x0, rs_tidx, rs_halves;   // half-width tiles (two 256-thread workgroups per CU): first column and statistics-tile index of the current tile; tiles per row strip
 #ifdef IDF_PS_DBG
   int ps_dbg;                   // timing-only ablation build (tools/build_variant.sh ... -DIDF_PS_DBG; env IDF_CONV_PS_DBG;
@@ -201,6 +200,19 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
                                // DDIM-100 at B = 256 297 -> 287 img/s (registers: 143 -> 214): the per-chunk 1.2 us is not load latency
 #endif
 
+// the same with the activation / dropout switches as template arguments (resolved once per tile by the caller: straight-line code)
+template <bool SILU, bool DROP>
+__device__ __forceinline__ uint4 pro_vec_t(const uint4 raw, const float (&scv)[8], const float (&shv)[8], uint64_t seedv, uint32_t salt,
+                                           uint32_t thr, float dscale, uint32_t vec) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  const uint32_t h = DROP ? idf_vec_hash(seedv, salt, vec) : 0u;
+  idf_act_vec_t<8, SILU, DROP>(v, scv, shv, h, 0, thr, dscale);
+  return make_uint4(idf_pack_bf16(v[0], v[1]), idf_pack_bf16(v[2], v[3]), idf_pack_bf16(v[4], v[5]), idf_pack_bf16(v[6], v[7]));
+}
+
 template <int G = 8>
 __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8], const float (&shv)[8], int act, bool drop,
                                          uint64_t seedv, uint32_t salt, uint32_t thr, float dscale, uint32_t vec) {
@@ -213,7 +225,7 @@ __device__ __forceinline__ uint4 pro_vec(const uint4 raw, const float (&scv)[8],
   for (int g0 = 0; g0 < 8; g0 += G) idf_act_vec<G>(v + g0, scv + g0, shv + g0, act, drop, h, g0, thr, dscale);
   uint32_t o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) o[i] = idf_pack_bf16(v[2 * i], v[2 * i + 1]);
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
@@ -279,14 +291,17 @@ __device__ __forceinline__ void lds_epilogue_tail(const C3P& p, unsigned char* s
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += r[k];
     }
+    uint32_t ow[4];                                // rounded once, as pairs (v_cvt_pk_bf16_f32)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ow[k] = idf_pack_bf16(o[2 * k], o[2 * k + 1]);
     if (p.st_out) {                                // statistics of the values a reader of y will see (bf16-rounded)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        o[k] = bf16_to_f32(f32_to_bf16(o[k]));
-        ssum[k] += o[k]; ssq[k] += o[k] * o[k];
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(ow[k] << 16), hi = __uint_as_float(ow[k] & 0xffff0000u);
+        ssum[2 * k] += lo; ssq[2 * k] += lo * lo; ssum[2 * k + 1] += hi; ssq[2 * k + 1] += hi * hi;
       }
     }
-    Vec16<bf16_t>::store(p.y + e, o);
+    *reinterpret_cast<uint4*>(p.y + e) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
   }
   if (p.st_out) {
     // lanes CPR apart hold the same couts: fold them, then the waves through LDS (outside the fp32 tile)
@@ -583,12 +598,14 @@ __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char*
 #pragma unroll
       for (int g0 = 0; g0 < 8; g0 += 4)
         idf_dact_vec_t<4, SILU, DROP>(dav + g0, xv + g0, scv + g0, shv + g0, h, g0, p.thr, p.dscale, du + g0);
+      uint32_t dw[4];                              // rounded once, as pairs; the sums are of what the consumer of du will read
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        du[e] = bf16_to_f32(f32_to_bf16(du[e]));
-        s1[e] += du[e]; s2[e] += du[e] * xv[e];
+      for (int e = 0; e < 4; ++e) {
+        dw[e] = idf_pack_bf16(du[2 * e], du[2 * e + 1]);
+        const float lo = __uint_as_float(dw[e] << 16), hi = __uint_as_float(dw[e] & 0xffff0000u);
+        s1[2 * e] += lo; s2[2 * e] += lo * xv[2 * e]; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * xv[2 * e + 1];
       }
-      Vec16<bf16_t>::store(p.y + e0, du);
+      *reinterpret_cast<uint4*>(p.y + e0) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
     }
   }
   // lanes CPR apart hold the same channels: fold them, then the waves through LDS (outside the fp32 tile)

@@ -28,6 +28,7 @@
 // summation order inside the MFMA accumulators.
 #include "idf_conv3x3_parts.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -123,21 +124,6 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   float* const chs = cof + 2 * CIN;
   C3P pe = p;                                          // the epilogue tails address their scratch relative to the fp32 tile
   pe.aux_off = p.aux_off - p.rs_os_off;
-
-#ifndef IDF_RS_SKEW
-#define IDF_RS_SKEW 1
-#endif
-  if constexpr (NPH == 1 && IDF_RS_SKEW) {
-    // two workgroups per CU that start together stay in lockstep -- both in their MFMA loops, both in their epilogues.  The one in
-    // the CU's second wave slots (HW_ID.WAVE_ID odd: the later arrival) starts half a tile period late; from then on one's vector
-    // phases face the other's matrix phases.
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));
-    if (hwid & 1) {
-#pragma unroll 1
-      for (int i = 0; i < p.rs_skew; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-  }
 
   // ---- this thread's slot in the row staging: round k = halo row(s) RPK k (+ prl), pixel ppx of the tile's TW columns, 8-channel
   // piece tid % PIECES (the same piece in every round: its coefficients stay in registers)
@@ -272,7 +258,8 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   uint64_t seedv = 0;
   bool drop = false;
   if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
-  auto write_rows = [&](int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
+  auto write_rows_t = [&](auto silu_c, auto drop_c, int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
+    constexpr bool SILU = decltype(silu_c)::value, DROP = decltype(drop_c)::value;
     float scv[8], shv[8];
     auto coefs = [&](int pc) __attribute__((always_inline)) {
 #pragma unroll
@@ -293,7 +280,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
           if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {
             coefs(ep);
             const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + ix) * CIN + ep * 8);
-            const uint4 a4 = pro_vec<8>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+            const uint4 a4 = pro_vec_t<SILU, DROP>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
             v = u32x4_t{a4.x, a4.y, a4.z, a4.w};
           }
           *reinterpret_cast<u32x4_t*>(smem + (ep >> 2) * CHB + (ly * WH + hx) * 64 + (((ep & 3) ^ (((hx >> 2) & 1) << 1)) << 4)) = v;
@@ -316,7 +303,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
       if constexpr (PRO) {
         if ((unsigned)iy < (unsigned)p.H) {            // rows outside the image stay zero (the reference pads the ACTIVATED tensor)
           const unsigned e0 = (unsigned)(((bb * p.H + iy) * W + x0 + ppx) * CIN + piece * 8);
-          const uint4 a4 = pro_vec<8>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
+          const uint4 a4 = pro_vec_t<SILU, DROP>(make_uint4(v[0], v[1], v[2], v[3]), scv, shv, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
           v = u32x4_t{a4.x, a4.y, a4.z, a4.w};
           if (keep_a && ly >= 1 && ly <= R) *reinterpret_cast<u32x4_t*>(p.a_out + e0) = v;
         }
@@ -324,6 +311,14 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
       *reinterpret_cast<u32x4_t*>(smem + pch * CHB + (ly * WH + hx) * 64 + ((pq ^ (((hx >> 2) & 1) << 1)) << 4)) = v;
       if constexpr (PRO) __builtin_amdgcn_sched_barrier(0);      // one vector's exp / rcp chains at a time: interleaving all HV of them spills
     }
+  };
+  // the activation / dropout switches are launch-uniform: one branch per tile, straight-line bodies
+  auto write_rows = [&](int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
+    using T = std::true_type;
+    using F = std::false_type;
+    if (!PRO || p.act != 2) write_rows_t(F{}, F{}, bb, oy, x0, keep_a);
+    else if (drop) write_rows_t(T{}, T{}, bb, oy, x0, keep_a);
+    else write_rows_t(T{}, F{}, bb, oy, x0, keep_a);
   };
 
   RS_DECL;
@@ -473,7 +468,6 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------- host
 const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;          // 0 off, 1 two 256-thread workgroups per CU, 2 one of 512
 const int g_rs_min = getenv("IDF_CONV_RS_MIN") ? atoi(getenv("IDF_CONV_RS_MIN")) : 128;     // work items below which the launch leaves most CUs idle
-const int g_rs_skew = getenv("IDF_CONV_RS_SKEW") ? atoi(getenv("IDF_CONV_RS_SKEW")) : 2;   // start delay of a CU's second workgroup, ~1 us units
 
 // tiles per image (= T of the statistics partials) or 0 when the form does not cover the shape
 int rs_tiles(int B, int H, int W, int Cin, int Cout) {
@@ -501,7 +495,6 @@ int launch_rs(C3P& p, hipStream_t st) {
   constexpr int halves = 3 - NPH;
   p.R = G::R; p.rs_halves = halves; p.tiles_per_img = (p.H / G::R) * halves; p.n_tiles = p.Cout / 64;
   p.rs_total = p.B * p.tiles_per_img * p.n_tiles;
-  p.rs_skew = g_rs_skew;
   const int slots = rs_ncu() * halves;               // workgroups resident at once
   p.rs_per = idf_cdiv(p.rs_total, slots);
   const int grid = idf_cdiv(p.rs_total, p.rs_per);

@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const GemmP p) {
       if (vec_out && n + 3 < p.N) {
         if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + e) = make_float4(o[0], o[1], o[2], o[3]);
         else {
-          uint32_t lo = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-          uint32_t hi = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+          uint32_t lo = idf_pack_bf16(o[0], o[1]);
+          uint32_t hi = idf_pack_bf16(o[2], o[3]);
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + e) = make_uint2(lo, hi);
         }
       } else {

@@ -71,7 +71,7 @@ __device__ __forceinline__ uint4 act_vec(const uint4 raw, const float (&scv)[8],
   idf_act_vec<8>(v, scv, shv, 2, drop, h, 0, thr, dscale);
   uint32_t o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) o[i] = idf_pack_bf16(v[2 * i], v[2 * i + 1]);
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
       }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      res[i].x = (uint32_t)f32_to_bf16(sacc[i][0]) | ((uint32_t)f32_to_bf16(sacc[i][1]) << 16);
-      res[i].y = (uint32_t)f32_to_bf16(sacc[i][2]) | ((uint32_t)f32_to_bf16(sacc[i][3]) << 16);
+      res[i].x = idf_pack_bf16(sacc[i][0], sacc[i][1]);
+      res[i].y = idf_pack_bf16(sacc[i][2], sacc[i][3]);
     }
     rb_barrier();            // the raw image has been read (and cof is complete)
   } else {
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
         o[0] += __uint_as_float(res[i].x << 16); o[1] += __uint_as_float(res[i].x & 0xffff0000u);
         o[2] += __uint_as_float(res[i].y << 16); o[3] += __uint_as_float(res[i].y & 0xffff0000u);
       }
-      hp[i].x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-      hp[i].y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      hp[i].x = idf_pack_bf16(o[0], o[1]);
+      hp[i].y = idf_pack_bf16(o[2], o[3]);
       hr[i][0] = __uint_as_float(hp[i].x << 16); hr[i][1] = __uint_as_float(hp[i].x & 0xffff0000u);
       hr[i][2] = __uint_as_float(hp[i].y << 16); hr[i][3] = __uint_as_float(hp[i].y & 0xffff0000u);
 #pragma unroll
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
       const uint32_t h = drop ? idf_vec_hash(seedv, nx.salt, e0 >> 3) : 0u;
       float v[4] = {hr[i][0], hr[i][1], hr[i][2], hr[i][3]};
       idf_act_vec<4>(v, scv, shv, 2, drop, h, (int)(c0 & 7), thr, dscale);
-      ap[i].x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      ap[i].y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      ap[i].x = idf_pack_bf16(v[0], v[1]);
+      ap[i].y = idf_pack_bf16(v[2], v[3]);
       if (nx.a_out) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(nx.a_out) + e0) = ap[i];
     }
     rb_barrier();              // every wave is past its last read of the activated image
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(NT) void resblock8_bwd_kernel(const RbBK k_in) {
           o[2] += __uint_as_float(r2.y << 16); o[3] += __uint_as_float(r2.y & 0xffff0000u);
         }
       }
-      ov[i].x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-      ov[i].y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      ov[i].x = idf_pack_bf16(o[0], o[1]);
+      ov[i].y = idf_pack_bf16(o[2], o[3]);
       *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(s.dx) + e0) = ov[i];
     }
     if (!more_stages) return;
@@ -806,8 +806,8 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(const WrP p) {
         o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
       }
       uint2 hp2;
-      hp2.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-      hp2.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      hp2.x = idf_pack_bf16(o[0], o[1]);
+      hp2.y = idf_pack_bf16(o[2], o[3]);
       *reinterpret_cast<uint2*>(p.y + e) = hp2;
       const float h0 = __uint_as_float(hp2.x << 16), h1 = __uint_as_float(hp2.x & 0xffff0000u);
       const float h2 = __uint_as_float(hp2.y << 16), h3 = __uint_as_float(hp2.y & 0xffff0000u);
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(const WrP p) {
         o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
       }
       uint2 ov;
-      ov.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-      ov.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+      ov.x = idf_pack_bf16(o[0], o[1]);
+      ov.y = idf_pack_bf16(o[2], o[3]);
       *reinterpret_cast<uint2*>(p.y + e0) = ov;
     }
   }

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(512) void upconv_bf16_kernel(const UpP p) {
     for (int i = 0; i < 4; ++i) {
       const int q = i * 16 + r16, ly = q >> p.wlshift, lx = q & (Wl - 1);
       const int pl = (2 * ly + py) * W + 2 * lx + px;
-      const uint32_t lo = (uint32_t)f32_to_bf16(acc[a][i][0] + bv.x) | ((uint32_t)f32_to_bf16(acc[a][i][1] + bv.y) << 16);
-      const uint32_t hi = (uint32_t)f32_to_bf16(acc[a][i][2] + bv.z) | ((uint32_t)f32_to_bf16(acc[a][i][3] + bv.w) << 16);
+      const uint32_t lo = idf_pack_bf16(acc[a][i][0] + bv.x, acc[a][i][1] + bv.y);
+      const uint32_t hi = idf_pack_bf16(acc[a][i][2] + bv.z, acc[a][i][3] + bv.w);
       *reinterpret_cast<uint2*>(tileo + pl * UP_TP + col) = make_uint2(lo, hi);
     }
   }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void upconv_dgrad_bf16_kernel(const UpDP p) {
     const int Yl = pxl >> p.wlshift, Xl = pxl & (Wl - 1);
     uint32_t w4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)f32_to_bf16(o[2 * j]) | ((uint32_t)f32_to_bf16(o[2 * j + 1]) << 16);
+    for (int j = 0; j < 4; ++j) w4[j] = idf_pack_bf16(o[2 * j], o[2 * j + 1]);
     *reinterpret_cast<uint4*>(p.dx + ((size_t)(b * p.Hl + Y0 + Yl) * Wl + Xl) * p.Cin + n0 + v * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
   }
 }
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(512) void downconv_dgrad_bf16_kernel(const DnP p) {
         v0 += __uint_as_float(rs.x << 16); v1 += __uint_as_float(rs.x & 0xffff0000u);
         v2 += __uint_as_float(rs.y << 16); v3 += __uint_as_float(rs.y & 0xffff0000u);
       }
-      const uint32_t lo = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-      const uint32_t hi = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+      const uint32_t lo = idf_pack_bf16(v0, v1);
+      const uint32_t hi = idf_pack_bf16(v2, v3);
       *reinterpret_cast<uint2*>(tileo + pl * UP_TP + col) = make_uint2(lo, hi);
     }
   }

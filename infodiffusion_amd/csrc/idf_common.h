@@ -65,13 +65,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t*>(&h);
 }
 
-// two floats -> one dword of bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN), where two scalar
-// casts cost two conversions, a shift and an or
-typedef __attribute__((ext_vector_type(2))) float idf_f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 idf_bf16x2_t;
+// two floats -> one dword of bf16 (lo in bits 0..15), round-to-nearest-even, NaN stays NaN.  NOT as one two-source v_cvt_pk_bf16_f32
+// (__builtin_convertvector of a float2): measured on MI355X / ROCm 7.2, that form in the 256-thread halo conv's du epilogue gave a few
+// wrong elements per launch, different ones every launch (0 of 12 launches clean; 12 of 12 clean with the two single conversions
+// below -- tools/_dbg2.py history in profiles/r05_cvt_pk_hazard.txt), so every pack goes through this one function.
 __device__ __forceinline__ uint32_t idf_pack_bf16(float lo, float hi) {
-  const idf_f32x2_t f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, idf_bf16x2_t));
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
 template <typename T> struct Elem;

@@ -246,6 +246,7 @@ def _wr_frag(shadows, j, B, H, W, Cin, Cout, whole):
 
 
 _RS = os.environ.get('IDF_CONV_RS', '1') != '0'          # the big-map ResBlock convs in the register-weights / row-reuse form (idf_conv_rs_*)
+_RS_FWD_ALL = os.environ.get('IDF_CONV_RS_FWD', '0') != '0'   # ... for every covered forward conv too (default: where it measured faster)
 
 
 @functools.lru_cache(maxsize=None)
@@ -289,7 +290,11 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
              _p(wfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(st), B, H, W, Cin, Cout, _st())
         return y, a, mean, rstd, sc, sh, st
     rfrag = None
-    if taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 32:
+    # forward: the row-reuse form where it measured faster than the halo / direct-to-LDS kernels -- the channel-changing convs of the
+    # 32x32 maps (64->128: 17.3 vs 19.0 us, 128->64: 19.0 vs 25.2 us); at 64->64 @64x64 and 128->128 @32x32 the GroupNorm transform is
+    # vector-bound either way (29.4 vs 28.2 us, 28.3 vs 27.8 us: profiles/r05_conv_rs.txt) and the older kernels stay
+    if (taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 32
+            and (_RS_FWD_ALL or Cin != Cout)):
         rfrag = _rs_frag(shadows, 2, B, H, W, Cin, Cout)
     if rfrag is not None:
         # 64x64 / 32x32: weights fragment-major into registers, whole-K halo image in LDS, row reuse, persistent over the CU's tiles

@@ -19,6 +19,7 @@
 #include "idf_conv3x3_parts.h"
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -201,14 +202,22 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
         float4 t4 = *reinterpret_cast<const float4*>(cof + 2 * cb + 4 * q);
         scv[2 * q] = t4.x; shv[2 * q] = t4.y; scv[2 * q + 1] = t4.z; shv[2 * q + 1] = t4.w;
       }
+      // the activation / dropout switches are launch-uniform: resolved once per chunk, each case straight-line (inside pro_vec they
+      // cost a branch, register shuffles and a partial copy of the body per vector: ~200 instructions per vector instead of ~110)
+      auto xform = [&](auto silu_c, auto drop_c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < HV; ++k)
-        if (hoff[k] >= 0) {
-          const unsigned e0 = DUAL ? (unsigned)(hoff[k] >> 2) * (unsigned)p.Cin + (unsigned)cb
-                                   : (unsigned)(hoff[k] + ck * CK);
-          hreg[k] = pro_vec<IDF_HALO_PRO_G>(hreg[k], scv, shv, p.act, drop, seedv, p.salt, p.thr, p.dscale, e0 >> 3);
-          if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.a_out + e0) = hreg[k];
-        }
+        for (int k = 0; k < HV; ++k)
+          if (hoff[k] >= 0) {
+            const unsigned e0 = DUAL ? (unsigned)(hoff[k] >> 2) * (unsigned)p.Cin + (unsigned)cb
+                                     : (unsigned)(hoff[k] + ck * CK);
+            hreg[k] = pro_vec_t<decltype(silu_c)::value, decltype(drop_c)::value, IDF_HALO_PRO_G>(hreg[k], scv, shv, seedv, p.salt, p.thr,
+                                                                                                  p.dscale, e0 >> 3);
+            if ((amask >> k) & 1u) *reinterpret_cast<uint4*>(p.a_out + e0) = hreg[k];
+          }
+      };
+      if (p.act != 2) xform(std::false_type{}, std::false_type{});
+      else if (drop) xform(std::true_type{}, std::true_type{});
+      else xform(std::true_type{}, std::false_type{});
     }
 #pragma unroll
     for (int k = 0; k < HV; ++k)
@@ -478,6 +487,8 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
       }
       // the plan is recomputed per chunk (a magic-number division per vector) rather than kept in registers:
       // two of these blocks must fit a CU
+      // (the once-per-chunk switch of the halo kernel was tried here: at this kernel's 128-register budget -- two blocks per CU -- the
+      // straight-line bodies spill, 28.2 -> 35.1 us at 64->64 @64x64; the element-wise runtime form stays)
 #pragma unroll 1
       for (int k = 0; k < HVD; ++k) {
         const int pix = (tid + k * NT) >> 2;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void pro_coef_kernel(const C3P p, float* __res
 #endif
 
 // the same with the activation / dropout switches as template arguments (resolved once per tile by the caller: straight-line code)
-template <bool SILU, bool DROP>
+template <bool SILU, bool DROP, int G = 8>
 __device__ __forceinline__ uint4 pro_vec_t(const uint4 raw, const float (&scv)[8], const float (&shv)[8], uint64_t seedv, uint32_t salt,
                                            uint32_t thr, float dscale, uint32_t vec) {
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -209,7 +209,8 @@ __device__ __forceinline__ uint4 pro_vec_t(const uint4 raw, const float (&scv)[8
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
   const uint32_t h = DROP ? idf_vec_hash(seedv, salt, vec) : 0u;
-  idf_act_vec_t<8, SILU, DROP>(v, scv, shv, h, 0, thr, dscale);
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += G) idf_act_vec_t<G, SILU, DROP>(v + g0, scv + g0, shv + g0, h, g0, thr, dscale);
   return make_uint4(idf_pack_bf16(v[0], v[1]), idf_pack_bf16(v[2], v[3]), idf_pack_bf16(v[4], v[5]), idf_pack_bf16(v[6], v[7]));
 }
 

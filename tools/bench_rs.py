@@ -13,6 +13,7 @@ from infodiffusion_amd import ops
 from tools.bench_gnbwd import timeit
 
 DEV, CL = 'cuda', torch.channels_last
+ops._RS_FWD_ALL = True      # measure the form at every covered forward shape
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 
 

@@ -9,12 +9,16 @@ from oracle import infodiff_oracle as O  # noqa: E402
 from tests.helpers import args_of, gold, make_infodiff, manifest, rel, rel_l2  # noqa: E402
 
 DEV = 'cuda'
-# epsilon-hat in bf16 against the fp32 reference.  north_star asks 1e-2; measured 1.5e-2 (max-abs / max-abs) on CelebA:
-# every tensor handed from one kernel to the next is rounded to bf16 (~0.15 % rms each), the roundings of ~110
-# tensors along the backbone add up like a random walk -- 0.5 % after the first ResBlock, 1.2 % after the seventh,
-# flat at ~1.5 % from the bottleneck on (profiles/r02_bf16_error_profile.txt, tools/bf16_error_profile.py): no single
-# layer loses it.  The loss (a mean over the batch) stays within 1e-2.  Held here at 2e-2.
-BF16_EPS_TOL = 2e-2
+# epsilon-hat in bf16 against the fp32 reference.  north_star asks 1e-2; NOT reachable with bf16 MFMA operands: rounding only the
+# operands of the convs (every stored tensor fp32) already gives 9.8e-3 max-norm / 1.18e-2 rel-L2, bf16 inner tensors with an fp32
+# residual trunk / skips 1.29e-2 / 1.49e-2 (tools/bf16_rounding_study.py, profiles/r03_bf16_error_profile.txt) -- the experiment the
+# round-4 verdict asked for, so the trunk stays bf16.  The bounds below are MEASURED + 15 % (tools/bf16_eps_measured.py,
+# profiles/r05_bf16_eps.txt: CelebA 1.52e-2 max-norm / 1.84e-2 rel-L2 in the steady state, config5's UNet 1.69e-2 on its first pass,
+# fmnist 2.82e-2), not round numbers: a kernel that loses accuracy moves them.
+BF16_EPS_TOL = 1.75e-2          # CelebA, max-norm
+BF16_EPS_TOL_L2 = 2.1e-2        # CelebA, rel-L2
+BF16_EPS_TOL_C5 = 1.95e-2       # config5 (CIFAR-shaped vanilla UNet), max-norm, first pass
+BF16_EPS_TOL_FMNIST = 3.25e-2   # 32-wide fmnist nets: one channel per GroupNorm group at the first level
 
 
 def _load_block(mod, man):
@@ -158,8 +162,7 @@ def test_bf16_train_step_close():
     loss.backward()
     with torch.no_grad():
         e17 = model(g['samp_x'].to(DEV), 17, g['samp_a'].to(DEV))
-    # 32-wide fmnist nets: one channel per GroupNorm group at the first level -- noisier than CelebA's 2.3e-2 measured
-    assert rel(e17, g['samp_eps17']) < 3e-2, rel(e17, g['samp_eps17'])
+    assert rel(e17, g['samp_eps17']) < BF16_EPS_TOL_FMNIST, rel(e17, g['samp_eps17'])
 
 
 def test_dropout_train_mode_vs_oracle():
@@ -413,7 +416,7 @@ def test_config5_cifar_vs_reference_fixture(dtype, tol):
     m2.eval()
     with torch.no_grad():
         y = m2(g['x'].to(DEV), 2)
-    assert rel(y, g['y2']) < (tol if dtype == 'fp32' else BF16_EPS_TOL), rel(y, g['y2'])
+    assert rel(y, g['y2']) < (tol if dtype == 'fp32' else BF16_EPS_TOL_C5), rel(y, g['y2'])
     m1 = InfoDiff(args_of(cfg, act_dtype=dtype), DEV, cfg.shape)
     m1.load_state_dict(O.synth_state_dict([(k, list(v.shape)) for k, v in m1.state_dict().items()]))
     m1.eval()
@@ -421,7 +424,7 @@ def test_config5_cifar_vs_reference_fixture(dtype, tol):
     nz = iter(list(g['noise']))
     proc._randn_like = lambda x: next(nz).to(DEV)
     fin = proc.sampling(2, xT=g['xT'].to(DEV), a=g['a'].to(DEV))
-    assert rel(fin, g['final']) < (2e-4 if dtype == 'fp32' else 2 * BF16_EPS_TOL), rel(fin, g['final'])
+    assert rel(fin, g['final']) < (2e-4 if dtype == 'fp32' else 2 * BF16_EPS_TOL_C5), rel(fin, g['final'])
     if dtype != 'fp32':
         return
     cfgl = O.Cfg(a_dim=256, is_latent=True, diffusion_steps=4, input_size=32, deterministic=True)
@@ -581,7 +584,7 @@ def test_bf16_train_step_celeba(a_dim):
         with torch.no_grad():
             e17 = model(g['samp_x'].to(DEV), 17, g['samp_a'].to(DEV))
         assert rel(e17, g['samp_eps17']) < BF16_EPS_TOL, rel(e17, g['samp_eps17'])
-        assert rel_l2(e17, g['samp_eps17']) < BF16_EPS_TOL, rel_l2(e17, g['samp_eps17'])
+        assert rel_l2(e17, g['samp_eps17']) < BF16_EPS_TOL_L2, rel_l2(e17, g['samp_eps17'])
 
 
 def _product_dropout_masks(model, seed, B):

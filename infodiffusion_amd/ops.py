@@ -293,8 +293,10 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
     # forward: the row-reuse form where it measured faster than the halo / direct-to-LDS kernels -- the channel-changing convs of the
     # 32x32 maps (64->128: 17.3 vs 19.0 us, 128->64: 19.0 vs 25.2 us); at 64->64 @64x64 and 128->128 @32x32 the GroupNorm transform is
     # vector-bound either way (29.4 vs 28.2 us, 28.3 vs 27.8 us: profiles/r05_conv_rs.txt) and the older kernels stay
+    # ... and every covered shape in inference (no activated tensor kept: DDIM-100 at B = 256 335 -> 349 img/s, the coefficient fold
+    # runs once per workgroup and image half instead of in a launch of its own)
     if (taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 32
-            and (_RS_FWD_ALL or Cin != Cout)):
+            and (_RS_FWD_ALL or Cin != Cout or not keep_a)):
         rfrag = _rs_frag(shadows, 2, B, H, W, Cin, Cout)
     if rfrag is not None:
         # 64x64 / 32x32: weights fragment-major into registers, whole-K halo image in LDS, row reuse, persistent over the CU's tiles

@@ -984,7 +984,9 @@ class _FusedConv(torch.autograd.Function):
         st = None
         w_fwd = cfg['shadows'](x.dtype, train)[0]
         Cout = weight.shape[0]
-        need = ctx.needs_input_grad
+        # needs_input_grad follows the inputs' requires_grad even under no_grad(): without the mode check every inference conv kept
+        # the activated tensor and the GroupNorm coefficients "for the backward pass" (one extra tensor write per conv: sampling)
+        need = ctx.needs_input_grad if slots is not None else (False,) * len(ctx.needs_input_grad)
         bias_k = cfg.get('bias_values')          # the values the kernel adds (AttnBlock: the folded (bq | bk | b')); `bias` routes gradients
         if bias_k is None:
             bias_k = bias
@@ -1217,7 +1219,7 @@ class _BlockEntryCat(torch.autograd.Function):
         x1, x2 = _nhwc(x1), _nhwc(x2)
         B, C1, H, W = x1.shape
         C = C1 + x2.shape[1]
-        need = ctx.needs_input_grad
+        need = ctx.needs_input_grad if slots is not None else (False,) * len(ctx.needs_input_grad)     # (no_grad(): see _FusedConv)
         w_fwd = cfg['shadows'](x1.dtype, train)[0]
         st = None
         if st1 is not None and st2 is not None and conv_gn_ok(x1, x2, 9, w.shape[0]):

@@ -61,7 +61,7 @@ def make_args(a):
 # s per train step (steps 2-4) / s per backbone evaluation -- 8 threads 3.8-4.7 / 0.28, 16 threads 3.0-4.6 / 0.16, 32 threads
 # 4.7-5.8 / 0.31 (profiles/r04_cpu_baseline_threads.txt, tools/cpu_threads_sweep.sh); 64 threads 8.7-10, 128 threads 18-25
 # (profiles/r03_cpu_baseline_threads.txt).  16 is the fastest measured: the default.  IDF_CPU_THREADS overrides for a sweep
-CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '16'))
+CPU_THREADS = int(os.environ.get('IDF_CPU_THREADS', '16'))      # (infodiffusion_amd/knobs.py lists it; read here before the package loads)
 CPU_BATCH = 32        # the benchmarked batch, CPU_WARMUP warm-ups + 3 timed steps; then 3 backbone evaluations
 CPU_WARMUP = 3        # the series is still falling at step 4 with one warm-up (round-4 verdict)
 

@@ -330,12 +330,6 @@ int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* 
                         int target_blocks, int blk0, int* blocks_out, int* lds_out);
 int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
                                 void* stream);
-/* the same launch on part of the chip: max_blocks > 0 bounds the grid to max_blocks CUs' worth of workgroups (rounded up to a
- * multiple of 8), each looping over the table's work items -- for a launch issued on a side stream beside the data-gradient
- * chain, whose own launches need free CUs.  max_blocks <= 0: one workgroup per work item (idf_conv_wgrad_bf16_batched). */
-int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
-                                       int max_blocks, void* stream);
-
 /* UpSample's forward (modules.py:78-93: nearest x2, then conv3x3 pad 1) as four 2x2 convs on the LOW-resolution input -- the
  * sub-pixel form of the same sum, 16 tap products per four outputs instead of 36 (round 4; data gradient:
  * idf_upconv_dgrad_bf16 below; the weight gradient stays the UP2 class of idf_conv_wgrad_bf16_batched).  x [B, Hl, Wl, Cin] bf16; y [B, 2 Hl, 2 Wl, Cout];

@@ -8,9 +8,11 @@ import os
 
 import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch ships, not load a second one
 
+from . import knobs
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 # IDF_LIB: another build of the same library (A/B of compile-time variants, tools/build_variant.sh); same no-fallback rule
-LIB_PATH = os.environ.get('IDF_LIB') or os.path.join(HERE, 'libinfodiff_hip.so')
+LIB_PATH = knobs.raw('IDF_LIB') or os.path.join(HERE, 'libinfodiff_hip.so')
 
 F32, BF16 = 0, 1
 ERR_UNSUPPORTED, ERR_BADARG = 1001, 1002
@@ -92,7 +94,6 @@ SIGNATURES = {
     'idf_wgrad_upsub_ok': ([_i, _i], C.c_int),
     'idf_wgrad_desc_fill': ([_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 11 + [_p, _p], C.c_int),
     'idf_conv_wgrad_bf16_batched': ([_p, _i, _i, _i, _i, _i, _p], C.c_int),
-    'idf_conv_wgrad_bf16_batched_capped': ([_p, _i, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 12 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),
     'idf_temb_film_fwd': ([_p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i] + [_p] * 8 + [_i, _p],

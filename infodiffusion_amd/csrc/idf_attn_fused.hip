@@ -852,7 +852,7 @@ template <int D, int AN>
 hipError_t launch_fwd(const void* qkv, void* o, float* lse, int B, float scale, hipStream_t st) {
   if (hipError_t e = raise_lds_once<D, AN>(); e != hipSuccess) return e;
   const size_t lds = ACfg<D, AN>::LDS;
-  static const int rb_min_b = getenv("IDF_ATTN_RB_MINB") ? atoi(getenv("IDF_ATTN_RB_MINB")) : 128;
+  static const int rb_min_b = 128;
   const int rb = (B >= rb_min_b) ? AN / 64 : 1;       // whole image per workgroup once the batch alone fills the chip
   hipLaunchKernelGGL((attn_fwd_kernel<D, AN>), dim3(AN / 64 / rb, B), dim3(ANT), lds, st, (const bf16_t*)qkv,
                      (bf16_t*)o, lse, scale, rb);
@@ -952,7 +952,7 @@ extern "C" int idf_attnblock_fwd(const void* x, const float* st, int T, const fl
 // tiles: statistics tiles per image (st_out [B][tiles][D][2]); 0: shape not covered (the shapes of idf_attn_fused_ok)
 extern "C" int idf_attn_res_tiles(int B, int N, int D, int dtype) {
   if (!idf_attn_fused_ok(N, D, dtype)) return 0;
-  static const int rb_min_b = getenv("IDF_ATTN_RB_MINB") ? atoi(getenv("IDF_ATTN_RB_MINB")) : 128;
+  static const int rb_min_b = 128;
   return (N == 256 && B < rb_min_b) ? 4 : 1;
 }
 

@@ -360,7 +360,7 @@ extern "C" int idf_debug_dlds_stamps(void** dev_addr) {
 // other block's MFMA phase runs beside this VALU phase.
 // DUAL: the input is the never-materialised concatenation x | x2 -- a chunk's per-lane source addresses point into
 // the tensor the chunk lies in.
-template <int KS, bool PRO = false, bool DUAL = false, bool DUE = false>
+template <int KS, bool PRO = false, bool DUAL = false>
 __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
   constexpr int TM = 4, BN = 64, NWM = 4, NT = 512, TN = 2;
   constexpr int TAPS = KS * KS, HALO = KS / 2, BM = 256;
@@ -533,12 +533,7 @@ __global__ __launch_bounds__(512, 4) void conv_dlds_bf16(const C3P p) {
 
   // epilogue through LDS (Cout % 8 == 0 is a launch condition)
   DLDS_STAMP(t4);
-  if constexpr (DUE) {      // backward chain: du + partials
-    uint4 due_xr[BM * (BN / 8) / NT];
-    due_fetch_x<BM, BN, NT>(p, due_xr, b, oy0, n0, KT, tid);
-    due_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, due_xr);
-  }
-  else {
+  {
     uint4 none[(BM * (BN / 8) + NT - 1) / NT];
     lds_epilogue<TM, TN, BM, BN, NT>(p, acc, smem, b, oy0, n0, KT, tid, wm0, wn0, none, false);
   }
@@ -736,7 +731,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
     }
     unsigned char* const stg = reinterpret_cast<unsigned char*>(stw + 512) + wave * (16 * SROW);
     float* const swv = stw + wave * 128;                    // this wave's statistics [64 couts][2]
-    const bool wants = p.st_out != nullptr && !PS_DBG(p, 16);
+    const bool wants = p.st_out != nullptr;
 
     PsPos pos;
     pos.init(p, w0);
@@ -761,7 +756,6 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
       const unsigned char* Xs = Hring + hs * HSZ;
       const unsigned char* Ws = Wring + (s & 1) * WSZ;
       hs = hs == 2 ? 0 : hs + 1;
-      if (!PS_DBG(p, 2))
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
         const int toff = (tap / KS) * WH + (tap % KS);
@@ -779,7 +773,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
           for (int i = 0; i < 4; ++i)
             acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i], acc[a][i], 0, 0, 0);
       }
-      if (pos.ck + 1 == nchunks && !PS_DBG(p, 32)) {
+      if (pos.ck + 1 == nchunks) {
         // ------------------------------------------------ epilogue of work item pos.wi
         // A lane holds 4 couts of a pixel (8 bytes): stored as they stand, 32-byte pieces land in 16 different
         // lines per instruction and the memory side crawls (5.7 us per tile measured).  Each wave therefore passes
@@ -793,7 +787,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
         u32x4_t rres0[4], rres1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          rowok[i] = (b0 + rimg[i]) < p.B && colok && !PS_DBG(p, 4);
+          rowok[i] = (b0 + rimg[i]) < p.B && colok;
           erow[i] = ((size_t)(b0 * p.H + oy0) * W + rpix[i]) * p.Cout + n0 + rcol;
           if constexpr (RES) {                              // residual rows of all four slices first: one round trip
             const bf16_t* rp = rowok[i] ? p.res + erow[i] : zero;
@@ -1018,7 +1012,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
     int nh_now = 0;
     if (sL < S) {
       if (pL.ck == 0) plan(pL);
-      if (!PS_DBG(p, 1) || sL == 0) {
+      {
         issue_halo(hL, pL.ck * CK);
         nh_now = nhg;
         nissued += nhg;
@@ -1037,7 +1031,7 @@ __global__ __launch_bounds__(512) void conv_ps_bf16(const C3P p) {
           bT = pT.b0;
         }
         wait_vmcnt(nissued);                               // everything older than this period's loads has landed
-        if (!PS_DBG(p, 8)) transform(hT, pT.ck * CK);
+        transform(hT, pT.ck * CK);
       }
       hT = hT == 2 ? 0 : hT + 1;
       ++sT;
@@ -1156,20 +1150,6 @@ void launch_dlds(C3P& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
 }
 
-// the du-epilogue data-gradient conv in the direct-to-LDS form (two 512-thread blocks per CU: one block's epilogue
-// arithmetic runs beside the other's loads and MFMAs)
-void launch_dlds_due(C3P& p, hipStream_t st) {
-  const int npix_h = (p.R + 2) * (p.W + 2);
-  size_t lds = ((size_t)((npix_h + 15) / 16) * 16 + 9 * 64) * 64;
-  size_t olds = (size_t)256 * (64 + 4) * sizeof(float);
-  if (olds > lds) lds = olds;
-  p.aux_off = (int)lds;
-  lds += (size_t)8 * 64 * 8;                                            // wave partials
-  auto kern = conv_dlds_bf16<3, false, false, true>;
-  IDF_ENSURE_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
-}
-
 template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false, bool PRO = false>
 void launch(C3P& p, hipStream_t st) {
   size_t lds = ((MODE == 1 ? (size_t)(2 * p.R + 1) * (2 * p.W + 1) : (size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2))) +
@@ -1226,27 +1206,22 @@ void clear_pro(C3P& p) {
   p.main_blocks = p.aux_blocks = 0; p.aux_x = p.aux_x2 = p.aux_w = nullptr; p.aux_C1 = p.aux_Cin = 0; p.aux_bias = nullptr;
   p.aux_y = nullptr; p.aux_Cout = p.aux_n_tiles = 0;
   p.ps_NI = 0; p.ps_rwshift = 0; p.ps_npi = 0; p.ps_magic_img = 0; p.ps_nptiles = p.ps_work = 0; p.ps_hbytes = 0;
-#ifdef IDF_PS_DBG
-  static const int dbg = getenv("IDF_CONV_PS_DBG") ? atoi(getenv("IDF_CONV_PS_DBG")) : 0;
-  p.ps_dbg = dbg;
-#endif
 }
 
 // ---- persistent form: geometry and the decision to use it
-const int g_ps = getenv("IDF_CONV_PS") ? atoi(getenv("IDF_CONV_PS")) : 1;
-const int g_ps_min = getenv("IDF_CONV_PS_MIN") ? atoi(getenv("IDF_CONV_PS_MIN")) : 256;   // work items (one per CU) below which the small-tile kernels spread better
+#define g_ps (idf_knobs().conv_ps)
+const int g_ps_min = 256;   // work items (one per CU) below which the small-tile kernels spread better
 // The GroupNorm prologue in this form runs on the four producer waves alone -- one wave per SIMD issues a vector
 // instruction every 4 cycles at best, beside a consumer wave whose MFMAs hold half the issue slots -- and is
 // 2.5-3.6 us per stage against 1 us of MFMAs: measured equal to or slower than the two-blocks-per-CU kernels
 // (64->64 @64^2: 38.7 vs 30.4 us at B = 32, 190 vs 196 us at B = 256).  Off unless asked for.
-const int g_ps_pro = getenv("IDF_CONV_PS_PRO") ? atoi(getenv("IDF_CONV_PS_PRO")) : 0;
 
 struct PsPlan { int R, NI, rwshift, npi, hgroups, nptiles, work, T; unsigned magic_img, magic_row; size_t lds; int aux_off; };
 
 // stride-1 3x3 / 1x1 (mode 0) only.  pro: GroupNorm prologue; want_st: statistics epilogue
 bool ps_plan(int B, int H, int W, int Cin, int Cout, int KS, bool pro, bool want_st, PsPlan* o) {
   if (!g_ps || (Cout & 7) || (Cin % CK) || W < 8 || W > 64 || (W & (W - 1)) || (H & (H - 1)) || H < 1) return false;
-  if ((KS == 3 && !(g_ps & 1)) || (KS == 1 && !(g_ps & 2)) || (pro && !g_ps_pro)) return false;
+  if ((KS == 3 && !(g_ps & 1)) || (KS == 1 && !(g_ps & 2)) || pro) return false;      // the GroupNorm prologue in this form lost (below): never taken
   const int HW = H * W, halo = KS / 2;
   int R, NI;
   if (HW >= 256) { R = 256 / W; NI = 1; if (R < 1 || H % R) return false; }
@@ -1300,11 +1275,9 @@ void launch_ps(C3P& p, const PsPlan& pl, hipStream_t st) {
 bool plan3(int B, int H, int W, int Cout, int mode, int* BM_, int* R_) {
   // 128-pixel tiles when the problem is big enough to still fill the chip, else 64
   long M = (long)B * H * W;
-  static const int force_bm = getenv("IDF_CONV_BM") ? atoi(getenv("IDF_CONV_BM")) : 0;
   int BM = ((M / 128) * idf_cdiv(Cout, 64) >= 256 && H * W >= 128) ? 128 : 64;
   // 512-thread blocks (256 pixels share one weight slab) once the grid still covers the chip
   if ((M / 256) * idf_cdiv(Cout, 64) >= 256 && H * W >= 256 && Cout > 32) BM = 256;
-  if (force_bm && H * W >= force_bm && !(force_bm == 256 && Cout <= 32)) BM = force_bm;
   if (mode == 1) BM = 64;                       // the stride-2 halo tile is 4x the output tile
   int R;
   for (;;) {
@@ -1342,15 +1315,17 @@ bool shape1_ok(int W, int Cin, int Cout) {
   return !((Cin % CK) || W < 4 || (W & (W - 1)) || W > 128 || (Cout & 7));
 }
 
-const int g_dlds = getenv("IDF_CONV_DLDS") ? atoi(getenv("IDF_CONV_DLDS")) : 3;
-const long g_dlds_min = getenv("IDF_CONV_DLDS_MIN") ? atol(getenv("IDF_CONV_DLDS_MIN")) : 1536;
-const long g_dlds_min_pro = getenv("IDF_CONV_DLDS_MIN_PRO") ? atol(getenv("IDF_CONV_DLDS_MIN_PRO")) : 512;
+const int g_dlds = 3;
+#define g_dlds_min (idf_knobs().conv_dlds_min)
+const long g_dlds_min_pro = 512;
 
 // dispatch of a 3x3 launch whose C3P is filled in (PRO / DUAL only for mode 0)
 template <bool DUAL, bool PRO>
 void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
   PsPlan pl;
-  if (mode == 0 && ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 3, PRO, p.st_out != nullptr, &pl)) { launch_ps<3, DUAL, PRO>(p, pl, st); return; }
+  if constexpr (!PRO) {       // (the persistent form with the GroupNorm prologue lost to the two-blocks-per-CU kernels: not instantiated)
+    if (mode == 0 && ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 3, false, p.st_out != nullptr, &pl)) { launch_ps<3, DUAL, false>(p, pl, st); return; }
+  }
   const bool bn32 = p.Cout <= 32;
   p.n_tiles = idf_cdiv(p.Cout, bn32 ? 32 : 64);
 #define IDF_C3_LAUNCH(MODE)                                              \
@@ -1374,7 +1349,9 @@ void dispatch3(C3P& p, int mode, int BM, hipStream_t st) {
 template <bool DUAL, bool PRO>
 void dispatch1(C3P& p, int BM, hipStream_t st) {
   PsPlan pl;
-  if (ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 1, PRO, p.st_out != nullptr, &pl)) { launch_ps<1, DUAL, PRO>(p, pl, st); return; }
+  if constexpr (!PRO) {
+    if (ps_plan(p.B, p.H, p.W, p.Cin, p.Cout, 1, false, p.st_out != nullptr, &pl)) { launch_ps<1, DUAL, false>(p, pl, st); return; }
+  }
   p.n_tiles = idf_cdiv(p.Cout, 64);
   const long blocks = (long)p.B * p.tiles_per_img * p.n_tiles;
   if (BM == 256 && (g_dlds & 2) && blocks >= (PRO ? g_dlds_min_pro : g_dlds_min)) launch_dlds<1, PRO, DUAL>(p, st);
@@ -1487,7 +1464,7 @@ extern "C" int idf_conv1x1_bf16(const void* x, const void* x2, int C1, const voi
 
 // ---- data-gradient conv with the GroupNorm backward as its epilogue (the 16x16 / 8x8 / 4x4 levels: a tile = one image)
 namespace {
-const int g_dgn_maxhw = getenv("IDF_DGRAD_GN_MAXHW") ? atoi(getenv("IDF_DGRAD_GN_MAXHW")) : 256;
+const int g_dgn_maxhw = 256;
 bool dgrad_gn_plan(int H, int W, int Cin, int Cout, int taps, int* BM) {       // coverage (not the policy)
   if ((taps != 9 && taps != 1) || H * W > 256 || (Cout % 64) || (Cin % CK) || W < 4 || (W & (W - 1))) return false;
   *BM = H * W <= 64 ? 64 : (H * W <= 128 ? 128 : 256);
@@ -1505,7 +1482,7 @@ extern "C" int idf_conv_dgrad_gn_ok(int B, int H, int W, int Cin, int Cout, int 
   if (!dgrad_gn_plan(H, W, Cin, Cout, taps, &BM)) return 0;
   // the attention block's q/k/v data gradient (1x1, 3C -> C) with its GroupNorm backward as the epilogue: 12 launches fewer per
   // CelebA step, 9.376 -> 9.347 ms (same-box A/B, profiles/r04_conv_wr.txt); IDF_DGRAD_GN_1X1=0: du epilogue + apply pass
-  static const int one = getenv("IDF_DGRAD_GN_1X1") ? atoi(getenv("IDF_DGRAD_GN_1X1")) : 1;
+  static const int one = 1;
   return ((taps == 9 || one) && H * W <= g_dgn_maxhw) ? 1 : 2;
 }
 
@@ -1552,7 +1529,7 @@ extern "C" int idf_conv_dgrad_gn_bf16(const void* dy, const void* w, const void*
   // whole-image tiles of 64 couts are B * Cout / 64 workgroups -- 64 or 128 of them at the benchmark's batch on 256 CUs: 32-cout
   // tiles (complete GroupNorm groups still: 32 % (Cout / 32) == 0) double the grid while it stays under one workgroup per CU
   // (IDF_GNB_BN32=0: off; profiles/r04_conv_wr.txt)
-  static const int bn32 = getenv("IDF_GNB_BN32") ? atoi(getenv("IDF_GNB_BN32")) : 1;
+  static const int bn32 = 1;
   const int cpg = Cout >> 5;
   const bool half = bn32 && BM == 256 && (long)B * (Cout / 64) < 256 && cpg >= 1 && cpg <= 32 && 32 % cpg == 0;
   if (half) p.n_tiles = Cout / 32;
@@ -1595,11 +1572,7 @@ extern "C" int idf_conv_tiles(int B, int H, int W, int Cin, int Cout, int mode, 
 //   two or more cout tiles on >= 1536 pixel-tile blocks (128->128 @32^2 at B = 256: 130 vs 112 us),
 //   ragged cout counts (epsilon / latent heads: 32-cout tiles of 128 pixels) on >= 2^19 pixels (263 vs 167 us).
 extern "C" int idf_conv_gn_advice(int B, int H, int W, int Cin, int Cout, int taps) {
-  static const int force = getenv("IDF_GN_FUSE_FORCE") ? atoi(getenv("IDF_GN_FUSE_FORCE")) : -1;
-  if (force >= 0) return force;
-  static const int minpix = getenv("IDF_GN_FUSE_MINPIX") ? atoi(getenv("IDF_GN_FUSE_MINPIX")) : 0;
   const long M = (long)B * H * W;
-  if (H * W < minpix && M < 32768) return 0;
   if (taps == 9) {
     if ((Cout & 7) && M >= (1L << 19)) return 0;
     if (idf_cdiv(Cout, 64) >= 2 && (M / 256) * idf_cdiv(Cout, 64) >= 1536) return 0;
@@ -1652,7 +1625,7 @@ static int conv_gn_impl(const void* x, const void* x2, int C1, const float* st1,
   if ((long)B * H * W * Cin >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_gn_bf16: tensor too large for 32-bit offsets");
   hipStream_t st = (hipStream_t)stream;
   // many tiles per image: fold the coefficients once per image in a launch of their own
-  static const long coef_min = getenv("IDF_GN_COEF_MIN") ? atol(getenv("IDF_GN_COEF_MIN")) : 1024;
+  static const long coef_min = 1024;
   if (coef_ws && (long)B * p.tiles_per_img * idf_cdiv(Cout, 64) >= coef_min && p.tiles_per_img >= 4) {
     hipLaunchKernelGGL(pro_coef_kernel, dim3(B), dim3(256), (size_t)Cin * 16, st, p, coef_ws);
     IDF_CHECK_LAUNCH();
@@ -1748,17 +1721,10 @@ extern "C" int idf_conv_gn_sc_bf16(const void* x, const void* x2, int C1, const 
 //   idf_gn_bwd_apply, or to the next call of this function as (dy, in_part).
 // bf16, Cin % 32 == 0, Cout % 64 == 0, W a power of two in [4, 128].
 namespace {
-// pixel tile of a chain launch: the forward kernels' plan, or a smaller tile when asked for (IDF_CHAIN_BM = 128 / 64: two or
-// three 256-thread blocks share a CU and one block's epilogue arithmetic overlaps its neighbours' MFMA phases)
+// pixel tile of a chain launch: the forward kernels' plan (forcing smaller tiles -- 128 / 64 pixels, two or three 256-thread blocks per
+// CU -- measured slower: 10.42 / 11.01 vs 10.33 ms per step, profiles/r03_e_ab_chain_knobs.txt; the switch is gone)
 bool chain_plan(int B, int H, int W, int Cout, int taps, int* BM, int* R) {
   if (!(taps == 9 ? plan3(B, H, W, Cout, 0, BM, R) : plan1(B, H, W, Cout, BM, R))) return false;
-  static const int force = getenv("IDF_CHAIN_BM") ? atoi(getenv("IDF_CHAIN_BM")) : 0;
-  if ((force == 128 || force == 64) && force < *BM && H * W >= force) {
-    int r = force / W;
-    if (r < 1) r = 1;
-    while (H % r) --r;
-    *BM = force; *R = r;
-  }
   return true;
 }
 }  // namespace
@@ -1829,14 +1795,6 @@ static int dgrad_chain_impl(const void* dy, const void* in_x, const float* in_pa
   }
   hipStream_t st = (hipStream_t)stream;
   const int bwd = (in_x ? 1 : 0) | (x ? 2 : 0);
-  // IDF_CHAIN_DLDS: launches of at least this many blocks take the direct-to-LDS form (0 = never)
-  static const long chain_dlds = getenv("IDF_CHAIN_DLDS") ? atol(getenv("IDF_CHAIN_DLDS")) : 0;
-  if (chain_dlds > 0 && bwd == 2 && taps == 9 && BM == 256 && !sc_dy && (long)B * p.tiles_per_img * p.n_tiles >= chain_dlds &&
-      ((p.R + 2) * (p.W + 2) + 15) / 16 + 36 <= 72) {
-    launch_dlds_due(p, st);
-    IDF_CHECK_LAUNCH();
-    return IDF_OK;
-  }
 #define IDF_CHAIN(KS)                                                                                     \
   do {                                                                                                    \
     if (BM == 256) { if (bwd == 3) launch_bwd_chain<4, 4, KS, 3>(p, st); else if (bwd == 2) launch_bwd_chain<4, 4, KS, 2>(p, st); else launch_bwd_chain<4, 4, KS, 1>(p, st); } \

@@ -74,18 +74,7 @@ struct C3P {
   // aux_off | coefficients at rs_cof_off
   int rs_per, rs_total, rs_os_off, rs_cof_off;
   int rs_x0, rs_tidx, rs_halves;   // half-width tiles (two 256-thread workgroups per CU): first column and statistics-tile index of the current tile; tiles per row strip
-#ifdef IDF_PS_DBG
-  int ps_dbg;                   // timing-only ablation build (tools/build_variant.sh ... -DIDF_PS_DBG; env IDF_CONV_PS_DBG;
-                                // results are wrong when set): 1 no halo loads after a block's first stage, 2 no MFMAs,
-                                // 4 no epilogue stores, 8 no prologue arithmetic, 16 no statistics, 32 no epilogue
-#endif
 };
-// the shipped library has no ablation switches: PS_DBG() folds to false
-#ifdef IDF_PS_DBG
-#define PS_DBG(p, bit) (((p).ps_dbg & (bit)) != 0)
-#else
-#define PS_DBG(p, bit) false
-#endif
 
 // Workgroups go round-robin over the 8 XCDs (block b on XCD b % 8): with the map below every XCD owns one CONTIGUOUS eighth of the
 // tile order, so row tiles that share halo rows -- and the cout tiles of one pixel tile -- meet in one L2 (speed only).

@@ -466,8 +466,8 @@ namespace {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------- host
-const int g_rs = getenv("IDF_CONV_RS") ? atoi(getenv("IDF_CONV_RS")) : 1;          // 0 off, 1 two 256-thread workgroups per CU, 2 one of 512
-const int g_rs_min = getenv("IDF_CONV_RS_MIN") ? atoi(getenv("IDF_CONV_RS_MIN")) : 128;     // work items below which the launch leaves most CUs idle
+#define g_rs (idf_knobs().conv_rs)          // 0 off, 1 two 256-thread workgroups per CU, 2 one of 512
+const int g_rs_min = 128;     // work items below which the launch leaves most CUs idle
 
 // tiles per image (= T of the statistics partials) or 0 when the form does not cover the shape
 int rs_tiles(int B, int H, int W, int Cin, int Cout) {

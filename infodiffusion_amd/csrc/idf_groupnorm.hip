@@ -803,8 +803,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_part(const bf16_t* __restric
 // CS/VE a power of two <= 64) and the block size.  Largest slice that still gives >= ~256 blocks.
 struct SmallPlan { int CS, NT, VS; };   // VS = lanes per pixel (power of two >= CS / VE)
 bool small_plan(int B, int HW, int C, int VE, SmallPlan* plan, int C1 = 0) {
-  static const int max_hw = getenv("IDF_GN_SMALL_MAXHW") ? atoi(getenv("IDF_GN_SMALL_MAXHW")) : 4096;
-  static const int want = getenv("IDF_GN_SMALL_BLOCKS") ? atoi(getenv("IDF_GN_SMALL_BLOCKS")) : 256;
+  static const int max_hw = 4096;
+  static const int want = 256;
   if (C % G || C % VE || C > 1024 || HW > max_hw || HW < 1) return false;
   const int cpg = C / G;
   int unit = cpg;                       // lcm(cpg, VE)
@@ -1038,11 +1038,11 @@ extern "C" int idf_gn_fused_bwd(const void* dA, const void* x, const void* x2, i
   size_t lds = ((size_t)(sp.NT / 64) * sp.CS * 2 + sp.CS * 2 + G * 2) * sizeof(float);
   ld_t = ld_t ? ld_t : 2 * C; ld_a = ld_a ? ld_a : 2 * C;
   hipStream_t st = (hipStream_t)stream;
-  static const int keep_env = getenv("IDF_GN_KEEP") ? atoi(getenv("IDF_GN_KEEP")) : 1;
+  static const int keep_env = 1;
   const int nvt = idf_cdiv((long)HW * sp.VS, sp.NT);             // vectors per thread
   const bool keep = keep_env && nvt <= 4;
   const bool keep2 = keep && nvt <= 2;      // small maps: half the kept vectors, the coefficient phase's parameters prefetched
-  static const int pre = getenv("IDF_GN_PREFETCH_RES") ? atoi(getenv("IDF_GN_PREFETCH_RES")) : 1;
+  static const int pre = 1;
 #define IDF_GN_BWD(T, K)                                                                                          \
   hipLaunchKernelGGL((gn_small_bwd<T, K>), dim3(B, C / sp.CS), dim3(sp.NT), lds, st, (const T*)dA, (const T*)x,   \
                      (const T*)x2, C1, (const T*)dres, (const T*)dres2, (T*)dx, (T*)dx2, gamma, beta, film_t, film_a, ld_t, ld_a, mean, rstd, sc, sh, dfilm_t, \
@@ -1076,7 +1076,7 @@ extern "C" int idf_gn_bwd_apply(const void* du, const float* part, int T, const 
   f.dfilm_t = dfilm_t; f.dfilm_a = dfilm_a; f.dgb = dgb; f.dgam = dgamma_acc; f.dbet = dbeta_acc; f.C = C; f.HW = HW;
   const int lanes = 256 / (C / 8);
   const size_t lds = (size_t)C * 6 * sizeof(float);
-  static const long small_max = getenv("IDF_GN_APPLY_SMALL") ? atol(getenv("IDF_GN_APPLY_SMALL")) : (1L << 22);
+  static const long small_max = (1L << 22);
   if ((long)B * HW * C <= small_max) {
     // a thread streams NV (4, or 2 to keep >= 256 blocks) pixels of one 16-byte channel slot, all fetched before the fold
     int nv = (long)B * idf_cdiv(HW, lanes * 4) >= 256 ? 4 : 2;
@@ -1091,7 +1091,7 @@ extern "C" int idf_gn_bwd_apply(const void* du, const float* part, int T, const 
                          (const bf16_t*)x2, C1, (const bf16_t*)dres, (const bf16_t*)dres2, (bf16_t*)dx, (bf16_t*)dx2, f, chunk);
   } else {
     // ~4 blocks per CU, all resident at once: the fold in front of every block's stream is paid once, in parallel
-    static const int want = getenv("IDF_GN_APPLY_BLOCKS") ? atoi(getenv("IDF_GN_APPLY_BLOCKS")) : 1024;
+    static const int want = 1024;
     int chunk = idf_cdiv(HW, idf_cdiv(want, B));
     if (chunk < lanes) chunk = lanes;
     if (chunk > HW) chunk = HW;

@@ -916,7 +916,8 @@ int wr_tiles(int B, int H, int W, int Cin, int Cout, int whole) {
   if (B <= 0 || H != W || (W != 8 && W != 16) || (Cin != 64 && Cin != 128 && Cin != 256) || (Cout % 64) || Cout > 256) return 0;
   if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
   if (W == 8) return 1;
-  if (whole) return Cin <= 128 ? 1 : 0;       // a 16x16 image of 256 channels does not fit LDS in one piece
+  if (whole) return 0;        // whole 16x16 images in this form measured slower than the 512-thread halo kernel (25.8 vs 19.7 us,
+                              // profiles/r04_conv_wr.txt): the form was removed in round 5
   return 4;
 }
 
@@ -978,7 +979,7 @@ extern "C" int idf_conv_wr_dgrad_gn_bf16(const void* dy, const void* w_frag, con
   p.gx = (const bf16_t*)x; p.gsc = sc; p.gsh = sh; p.gmean = mean; p.grstd = rstd;
   p.dfilm_t = dfilm_t; p.dfilm_a = dfilm_a; p.dgb = dgb; p.dgam = dgamma_acc; p.dbet = dbeta_acc;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = W == 16 ? launch_wr<true, 16, false, true>(p, s) : launch_wr<false, 4, false, true>(p, s);
+  const int rc = launch_wr<false, 4, false, true>(p, s);          // whole images: 8x8 only (wr_tiles)
   if (rc) IDF_FAIL(IDF_ERR_HIP, "conv_wr_dgrad_gn_bf16: LDS request refused (%d)", rc);
   IDF_CHECK_LAUNCH();
   return IDF_OK;

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDe
 }
 
 // IDF_WGRAD_KR3 (default 1): the batched stride-1 3x3 class runs in the shared-tile form
-const int g_kr3 = getenv("IDF_WGRAD_KR3") ? atoi(getenv("IDF_WGRAD_KR3")) : 1;
+#define g_kr3 (idf_knobs().wgrad_kr3)
 
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
@@ -583,7 +583,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
     // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
     // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
     // per atomic byte (profiles/r01_wgrad_grid_sweep.txt)
-    static const int forced = getenv("IDF_WGRAD_BLOCKS") ? atoi(getenv("IDF_WGRAD_BLOCKS")) : 0;
+    static const int forced = 0;
     const long M = (long)B * H * W, cc = (long)Cin * Cout;
     target_blocks = 512;
     if (cc <= 64 * 64 || (M <= 32768 && cc <= 128 * 128)) target_blocks = 256;
@@ -627,7 +627,7 @@ bool kr3_fits(int H, int W) {
 // 1 when the UpSample weight gradient of an H x W output map runs in the sub-pixel form (mode | IDF_WGRAD_UPSUB in
 // idf_wgrad_desc_fill / idf_conv_wgrad_bf16_batched): W / 2 in {8, 16, 32}, whole 128-pixel (64 at 8x8) low-resolution tiles
 extern "C" int idf_wgrad_upsub_ok(int H, int W) {
-  static const int on = getenv("IDF_WGRAD_UPSUB") ? atoi(getenv("IDF_WGRAD_UPSUB")) : 1;
+  static const int on = 1;
   if (!on || H <= 0 || W < 16 || (W & (W - 1)) || ((H | W) & 1)) return 0;
   const int Wl = W / 2, Hl = H / 2;
   int RL = 128 / Wl;
@@ -681,17 +681,17 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   WgDesc d;
   memset(&d, 0, sizeof(d));
   size_t lds;
-  static const int forced = getenv("IDF_WGRAD_BATCH_BLOCKS") ? atoi(getenv("IDF_WGRAD_BATCH_BLOCKS")) : 0;
+  static const int forced = 0;
   if (forced > 0) target_blocks = forced;
-  static const int tpb = getenv("IDF_WGRAD_TPB") ? atoi(getenv("IDF_WGRAD_TPB")) : 16;      // re-swept for the 1x1 / stride-2 / up-sampling classes: profiles/r03_wgrad_tpb_sweep.txt
-  static const int minb = getenv("IDF_WGRAD_MINB") ? atoi(getenv("IDF_WGRAD_MINB")) : 96;
-  static const int tpb_up = getenv("IDF_WGRAD_TPB_UP") ? atoi(getenv("IDF_WGRAD_TPB_UP")) : 16;   // sub-pixel UpSample class: tiles are 128 LOW-resolution pixels
+  static const int tpb = 16;      // re-swept for the 1x1 / stride-2 / up-sampling classes: profiles/r03_wgrad_tpb_sweep.txt
+  static const int minb = 96;
+  static const int tpb_up = 16;   // sub-pixel UpSample class: tiles are 128 LOW-resolution pixels
   // pixel tiles per block of the shared-tile 3x3 class: 128 (round 4; 64 before) halves the pixel splits of the 64x64 / 32x32 problems
   // at a slightly shorter step (9.088 -> 9.065 ms; 192 / 256: the same; profiles/r04_wgrad_tpb3.txt).  The launch's atomic bytes
   // barely move (291 -> 281 MB by the WRITE_SIZE counter): they are the 16x16 / 8x8 problems' (590 KB - 1.2 MB of dW each, split by
   // the 16-block minimum, IDF_WGRAD_MINB3), not the big maps' (147 KB each)
-  static const int tpb3 = getenv("IDF_WGRAD_TPB3") ? atoi(getenv("IDF_WGRAD_TPB3")) : 128;
-  static const int minb3 = getenv("IDF_WGRAD_MINB3") ? atoi(getenv("IDF_WGRAD_MINB3")) : 16;
+  static const int tpb3 = idf_knobs().wgrad_tpb3;
+  static const int minb3 = 16;
   const bool rowsplit = (mode & 16) != 0;         // IDF_WGRAD_ROWSPLIT: the caller keeps this problem out of the shared-tile class
   const bool upsub = (mode & 32) != 0;            // IDF_WGRAD_UPSUB: the UpSample class in its sub-pixel form
   mode &= 15;
@@ -702,7 +702,7 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
                    a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : (upsub ? tpb_up : tpb)), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
-  static const int xcd = getenv("IDF_WGRAD_XCD") ? atoi(getenv("IDF_WGRAD_XCD")) : 1;
+  static const int xcd = 1;
   d.xcd = (xcd && (blk0 % 8) == 0 && d.gy >= 8) ? 1 : 0;
   memcpy((char*)host_table + (size_t)index * sizeof(WgDesc), &d, sizeof(d));
   *blocks_out = d.xcd ? d.gx * ((d.gy + 7) / 8 * 8) : d.gx * d.gy;
@@ -711,8 +711,8 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   return IDF_OK;
 }
 
-extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
-                                                  int mode, int max_blocks, void* stream) {
+extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
+                                           int mode, void* stream) {
   if (n <= 0 || total_blocks <= 0) return IDF_OK;
   const bool rowsplit = (mode & 16) != 0, upsub = (mode & 32) != 0;
   mode &= 15;
@@ -721,13 +721,7 @@ extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, 
   hipStream_t st = (hipStream_t)stream;
   const WgDesc* tab = (const WgDesc*)dev_table;
   const bool kr3 = taps == 9 && mode == 0 && g_kr3 && !rowsplit;
-  // max_blocks counts 768-thread blocks (one per CU); the 256-thread classes fit three to a CU
-  int grid = total_blocks;
-  if (max_blocks > 0) {
-    const int cap = kr3 ? max_blocks : 3 * max_blocks;
-    if (grid > cap) grid = (cap + 7) / 8 * 8;              // whole rounds of the 8 XCDs: item -> XCD stays what the table assumes
-    if (grid > total_blocks) grid = total_blocks;
-  }
+  const int grid = total_blocks;                     // one workgroup per work item
   dim3 g(grid);
   if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   else if (kr3) {
@@ -747,9 +741,4 @@ extern "C" int idf_conv_wgrad_bf16_batched_capped(const void* dev_table, int n, 
   else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
-}
-
-extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
-                                           int mode, void* stream) {
-  return idf_conv_wgrad_bf16_batched_capped(dev_table, n, total_blocks, lds_bytes, taps, mode, 0, stream);
 }

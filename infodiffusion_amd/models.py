@@ -118,12 +118,7 @@ class _UNetSkeleton(nn.Module):
             first = False
         for layer in self.upblocks:
             if isinstance(layer, UpSample):
-                small = h.shape[-1] <= _WGRAD_POINT_MAXW
                 h = layer(h)
-                if alias_mode and small and h.shape[-1] > _WGRAD_POINT_MAXW:
-                    # the backward pass leaves the big maps here: the weight gradients queued so far start on the side
-                    # stream and fill the CUs the small-map launches leave idle (ops.WgradBatch.flush_async)
-                    h = ops.wgrad_point(h)
             else:
                 h = block_call(layer, (h, skips.pop()))      # the block reads the pair in place (no torch.cat)
         assert len(skips) == 0
@@ -134,8 +129,6 @@ class _UNetSkeleton(nn.Module):
         self._shadow_set.settle(self.ctx.act_dtype, torch.is_grad_enabled())
         return y
 
-
-_WGRAD_POINT_MAXW = int(os.environ.get('IDF_WGRAD_POINT_MAXW', '16'))
 
 
 class UNet(_UNetSkeleton):
@@ -465,8 +458,6 @@ class InfoDiff(nn.Module):
             leaf = lat.detach().requires_grad_(True)
             self._latent_cut = (lat, leaf)
             lat = a = leaf
-        elif torch.is_grad_enabled() and lat.requires_grad:
-            lat = ops.wgrad_point(lat)       # the backbone's backward is through: its weight gradients run beside the encoder's
         output = self.backbone(x_tilde, idx, lat)
         if getattr(self, '_shadow_all', None) is not None:
             self._shadow_all.settle(self.backbone.ctx.act_dtype, torch.is_grad_enabled())

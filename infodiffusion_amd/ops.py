@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, knobs
 from ._lib import call, F32, BF16
 from .grad_arena import slot_of, ParamGroup  # noqa: F401  (modules.py reaches ParamGroup through ops)
 
@@ -118,7 +118,7 @@ def uses_halo_kernel(dtype, taps, act, mode, B, Cin, Cout, Ho, Wo):
     return _halo_fits(Ho, Wo, B, Cout)
 
 
-_CONV1X1 = os.environ.get('IDF_CONV1X1', '1') != '0'
+_CONV1X1 = True
 
 
 @functools.lru_cache(maxsize=None)
@@ -136,7 +136,7 @@ def _new_stats(B, Ho, Wo, Cin, Cout, mode, taps, device, pro=0):
     return torch.empty((B, T, Cout, 2), dtype=torch.float32, device=device) if T > 0 else None
 
 
-_FEWC = os.environ.get('IDF_CONV_FEWC', '1') != '0'       # the head conv (Cin <= 3) as one MFMA K-step (idf_conv3x3_fewc_bf16)
+_FEWC = True       # the head conv (Cin <= 3) as one MFMA K-step (idf_conv3x3_fewc_bf16)
 
 
 @functools.lru_cache(maxsize=None)
@@ -185,7 +185,7 @@ def conv_raw(x, w_fwd, bias, residual, sc, sh, seed, salt, p_drop, mode, taps, a
     return done()
 
 
-_GN_FUSE = os.environ.get('IDF_GN_FUSE', '1') != '0'
+_GN_FUSE = knobs.flag('IDF_GN_FUSE')
 
 
 def gn_partials_raw(x):
@@ -224,9 +224,8 @@ def _gn_advice(B, H, W, Cin, Cout, taps):
     return bool(_lib.load().idf_conv_gn_advice(B, H, W, Cin, Cout, taps))
 
 
-_WR = os.environ.get('IDF_CONV_WR', '1') != '0'          # the small-map convs with fragment-major weights (idf_conv_wr_*)
-_WR_MAXB = int(os.environ.get('IDF_CONV_WR_MAXB', '64'))   # launch-bound batches only (64 / 256 workgroups of 4 waves)
-_WR_GNB16 = os.environ.get('IDF_CONV_WR_GNB16', '0') != '0'
+_WR = knobs.flag('IDF_CONV_WR')          # the small-map convs with fragment-major weights (idf_conv_wr_*)
+_WR_MAXB = 64   # launch-bound batches only (64 / 256 workgroups of 4 waves)
 
 
 @functools.lru_cache(maxsize=None)
@@ -245,8 +244,8 @@ def _wr_frag(shadows, j, B, H, W, Cin, Cout, whole):
     return v
 
 
-_RS = os.environ.get('IDF_CONV_RS', '1') != '0'          # the big-map ResBlock convs in the register-weights / row-reuse form (idf_conv_rs_*)
-_RS_FWD_ALL = os.environ.get('IDF_CONV_RS_FWD', '0') != '0'   # ... for every covered forward conv too (default: where it measured faster)
+_RS = knobs.flag('IDF_CONV_RS')          # the big-map ResBlock convs in the register-weights / row-reuse form (idf_conv_rs_*)
+_RS_FWD_ALL = knobs.flag('IDF_CONV_RS_FWD')   # ... for every covered forward conv too (default: where it measured faster)
 
 
 @functools.lru_cache(maxsize=None)
@@ -413,7 +412,7 @@ def gn_apply2_raw(x, x2, sc, sh, seed, salt, p_drop, act):
     return a
 
 
-_GN_STREAM_MINPIX = int(os.environ.get('IDF_GN_STREAM_MINPIX', str(1 << 18)))     # B * H * W from which the unfused GroupNorm streams
+_GN_STREAM_MINPIX = 1 << 18     # B * H * W from which the unfused GroupNorm streams
 
 
 def _gn_acc(acc):
@@ -505,7 +504,7 @@ def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, see
     return dx, dgam[:C], dgam[C:], dft, dfa
 
 
-_DGRAD_GN = os.environ.get('IDF_DGRAD_GN', '1') != '0'
+_DGRAD_GN = knobs.flag('IDF_DGRAD_GN')
 
 
 @functools.lru_cache(maxsize=None)
@@ -535,9 +534,8 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
     acc = _gn_acc(acc)
     dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
     # (whole 16x16 images in this form -- 4 waves x 256 pixels -- measured SLOWER than the 512-thread register-staged kernel:
-    # 25.8 vs 19.7 us at B = 32, profiles/r04_conv_wr.txt; 8x8 only unless IDF_CONV_WR_GNB16=1)
-    wfrag = _wr_frag(shadows, 3, B, H, W, dy.shape[1], C, 1) if (taps == 9 and act == 2 and C in (128, 256) and
-                                                              (W == 8 or _WR_GNB16)) else None
+    # 25.8 vs 19.7 us at B = 32, profiles/r04_conv_wr.txt: 8x8 only)
+    wfrag = _wr_frag(shadows, 3, B, H, W, dy.shape[1], C, 1) if (taps == 9 and act == 2 and C in (128, 256) and W == 8) else None
     if wfrag is not None:
         call('idf_conv_wr_dgrad_gn_bf16', _p(dy), _p(wfrag), _p(x), _p(dres), _p(dres2), _p(dx), _p(gamma), _p(beta), _p(film_t),
              _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
@@ -558,14 +556,14 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
 
 
 # ------------------------------------------------------------ backward chain at the big maps
-_BWD_CHAIN = os.environ.get('IDF_BWD_CHAIN', '1') != '0'     # du epilogue + streaming apply instead of the one-launch GroupNorm backward
+_BWD_CHAIN = knobs.flag('IDF_BWD_CHAIN')     # du epilogue + streaming apply instead of the one-launch GroupNorm backward
 # ... and the apply pass folded into the NEXT data-gradient conv's prologue (LazyGrad).  Built, tested against fp32 autograd, measured, and
 # OFF by default: the prologue (in-block coefficient fold + two tensors staged per vector + the side write of dy) costs the
 # conv +25 us at 64->64 @64^2, B = 32, against the 12 us streaming pass it removes -- 10.89 vs 10.43 ms per step on one box
 # (profiles/r03_c_ab_chain_lazy.txt, r03_d_step_inventory_chain_lazy.txt)
-_SC_FUSE = os.environ.get('IDF_SC_FUSE', '1') != '0'       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
-_SC_FUSE_MAXPIX = int(os.environ.get('IDF_SC_FUSE_MAXPIX', '8192'))   # ... where those launches leave CUs idle: B * H * W up to 32 x 16 x 16
-_BWD_LAZY = os.environ.get('IDF_BWD_LAZY', '0') != '0'
+_SC_FUSE = knobs.flag('IDF_SC_FUSE')       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
+_SC_FUSE_MAXPIX = 8192   # ... where those launches leave CUs idle: B * H * W up to 32 x 16 x 16
+_BWD_LAZY = knobs.flag('IDF_BWD_LAZY')
 
 
 @functools.lru_cache(maxsize=None)
@@ -733,25 +731,14 @@ class WgradBatch:
     convolution's (a, dy, arena slots) and ONE launch per (taps, mode) class at the end of the
     backward pass computes them all (`idf_conv_wgrad_bf16_batched`): no per-conv launch, small
     problems share the chip, one problem's atomic tail overlaps its neighbours' loads."""
-    enabled = os.environ.get('IDF_WGRAD_BATCH', '1') != '0'
+    enabled = knobs.flag('IDF_WGRAD_BATCH')
     pending = []       # (a, dy, dW address, db address, B, H, W, Cin, Cout, taps, mode, a2, C1, Cin_w, Cout_w)
     _bufs = {}         # key of a flush -> [pinned host table, device table, key, launch plan, copy event]   (eager: LRU, insertion-ordered)
     _LRU = 6
     _graph_bufs = []   # tables referenced by captured graphs: never touched again
 
-    # Flushes issued DURING backward (`flush_async`, from `wgrad_point` hooks the networks plant where the backward pass leaves
-    # the big maps) can run on a side stream next to the data-gradient chain; the end-of-backward flush joins it again.  Such a
-    # launch is CAPPED (`side_cap` CUs' worth of blocks, each looping over the work items), because an uncapped one takes every
-    # CU for ~100 us per block and the chain's launches queue behind it.
-    # OFF by default -- measured three ways, never a gain on one GPU: round 3 uncapped 10.11 -> 10.25 ms (one early flush) and
-    # 11.2 ms (a flush every 8 convs), profiles/r03_v_ab_wgrad_side.txt; round 4 capped at 128 CUs from the two points the
-    # backward pass leaves the big maps: 9.35 -> 9.41 ms (cap 64: 9.50, cap 192: 9.65), profiles/r04_wgrad_side_capped.txt --
-    # the launches do overlap (kernel trace: 2.06 ms of 11.04 ms kernel time concurrent), but the latency-bound chain
-    # launches slow down by as much beside a 3-TB/s neighbour.  IDF_WGRAD_SIDE=1 opts in.
-    side_enabled = os.environ.get('IDF_WGRAD_SIDE', '0') != '0'
-    side_cap = int(os.environ.get('IDF_WGRAD_SIDE_CAP', '128'))
-    _side = None
-    _inflight = []     # operands of side-stream flushes, kept alive until the join
+    # (Flushing part of the queue mid-backward on a side stream -- uncapped in round 3, as a capped persistent grid in round 4 --
+    # never gained on one GPU: profiles/r03_v_ab_wgrad_side.txt, r04_wgrad_side_capped.txt.  Removed in round 5.)
     _cb_queued = False
     _task = -1         # autograd graph task that queued the flush
 
@@ -787,42 +774,15 @@ class WgradBatch:
     def _drop(cls):
         cls.pending = []
         cls._cb_queued = False
-        if cls._inflight:
-            if cls._side is not None and cls._inflight[0][0].is_cuda and not torch.cuda.is_current_stream_capturing():
-                torch.cuda.current_stream().wait_stream(cls._side)     # their operands may be freed now
-            cls._inflight = []
-
-    @classmethod
-    def side_stream(cls):
-        """The stream mid-backward flushes run on (None when there is none in flight)."""
-        return cls._side if cls._inflight else None
-
-    @classmethod
-    def flush_async(cls):
-        """Launch what is queued so far on the side stream (capped grid); the current stream carries on with backward.
-        Without a side stream (IDF_WGRAD_SIDE=0, CPU tensors, outside a backward pass) nothing happens: the items wait
-        for the end-of-backward flush."""
-        if not cls.pending or not cls.side_enabled or not cls._cb_queued or not cls.pending[0][0].is_cuda:
-            return
-        cur = torch.cuda.current_stream()
-        if cls._side is None:
-            cls._side = torch.cuda.Stream()
-        cls._side.wait_stream(cur)
-        cls._inflight.extend(cls.pending)       # the caching allocator must not recycle them before the join
-        with torch.cuda.stream(cls._side):
-            cls._flush_pending(cls.side_cap)
 
     @classmethod
     def flush(cls):
-        """End of backward (or an explicit barrier): launch the rest on the current stream and join the side stream."""
+        """End of a backward pass (or an explicit barrier): launch what is queued on the current stream."""
         cls._cb_queued = False
         cls._flush_pending()
-        if cls._inflight:
-            torch.cuda.current_stream().wait_stream(cls._side)
-            cls._inflight = []
 
     @classmethod
-    def _flush_pending(cls, cap=0):
+    def _flush_pending(cls):
         items, cls.pending = cls.pending, []
         if not items:
             return
@@ -895,18 +855,7 @@ class WgradBatch:
         base = buf[1].data_ptr()
         plan = buf[3]
         for off, n, blk, lds, taps, mode in plan:
-            call('idf_conv_wgrad_bf16_batched_capped', base + off * nb, n, blk, lds, taps, mode, cap, _st())
-
-
-def wgrad_point(h):
-    """Mark `h` as a point of the backward pass where the weight gradients queued so far may start on the side stream
-    (`WgradBatch.flush_async`): the hook fires when the gradient of `h` is complete, i.e. when every consumer of `h` --
-    everything downstream of it in the forward pass -- has run its backward."""
-    if WgradBatch.enabled and WgradBatch.side_enabled and h.requires_grad and h.is_cuda:
-        def _go(g):
-            WgradBatch.flush_async()
-        h.register_hook(_go)
-    return h
+            call('idf_conv_wgrad_bf16_batched', base + off * nb, n, blk, lds, taps, mode, _st())
 
 
 def conv_wgrad_bias_raw(a, dy, mode, taps, want_bias, w_slot=None, b_slot=None, defer=False):
@@ -1158,8 +1107,6 @@ def fused_conv(x, weight, bias, cfg, gn_w=None, gn_b=None, film_t=None, film_a=N
     op's GroupNorm backward kernel (or its data-gradient epilogue).
     want_stats: the conv's epilogue leaves the GroupNorm statistics of y behind (y._gn), so the GroupNorm-fused
     conv that consumes y needs no statistics pass."""
-    if passthrough and os.environ.get('IDF_PASSTHROUGH', '1') == '0':
-        return (fused_conv(x, weight, bias, cfg, gn_w, gn_b, film_t, film_a, residual, seed, want_stats=want_stats),) + (x,) * int(passthrough)
     train = torch.is_grad_enabled() and x.requires_grad   # the data-gradient shadow will be needed
     # x_single_use: the caller promises that this op is the ONLY reader of x.  When x came out of a conv whose data-gradient
     # launch can form its own input gradient (lazy_in_ok), this op's GroupNorm backward may hand (du, partials) back
@@ -1341,12 +1288,12 @@ def block_entry_cat(x1, x2, conv, gn, shortcut, cfg, cfg_sc):
 
 
 # ------------------------------------------- image-resident ResBlock at the 8x8 maps
-_RB_SMALL = os.environ.get('IDF_RB_SMALL', '1') != '0'
+_RB_SMALL = knobs.flag('IDF_RB_SMALL')
 # one workgroup per image.  Measured up to B = 256 (profiles/r04_resblock_small.txt): DDIM-100 at B = 256 291 -> 303 img/s, the
 # B = 128 train step 4958 -> 4994 img/s against a limit of 64; the per-conv fragment-major form (_WR_MAXB) LOSES beyond 64 (276 img/s)
-_RB_SMALL_MAXB = int(os.environ.get('IDF_RB_SMALL_MAXB', '256'))
-_RB_SMALL_BWD = os.environ.get('IDF_RB_SMALL_BWD', '1') != '0'      # ... and its backward (idf_resblock_small_bwd)
-_RB_WFRAG = os.environ.get('IDF_RB_WFRAG', '1') != '0'              # fragment-major weights (modules._Shadows.request_frag): 35.5 -> 23.2 us per block
+_RB_SMALL_MAXB = knobs.num('IDF_RB_SMALL_MAXB')
+_RB_SMALL_BWD = True      # ... and its backward (idf_resblock_small_bwd)
+_RB_WFRAG = True              # fragment-major weights (modules._Shadows.request_frag): 35.5 -> 23.2 us per block
 
 
 @functools.lru_cache(maxsize=None)
@@ -1631,7 +1578,7 @@ def resblock_small(x, x2, stages, shortcut, film_t, film_a, film_stage, seed, p_
 
 
 # ------------------------------------------------------------------ attention
-_ATTN_BWD_ONE = os.environ.get('IDF_ATTN_BWD_ONE', '1') != '0'      # query and key-value halves of the backward in one launch
+_ATTN_BWD_ONE = True      # query and key-value halves of the backward in one launch
 
 
 class _Attention(torch.autograd.Function):
@@ -1695,9 +1642,9 @@ def attention(qkv, pre=None):
 
 
 # ------------------------------------------------- UpSample at inference: four 2x2 convs on the low-resolution input
-_UPCONV = os.environ.get('IDF_UPCONV', '1') != '0'
-_UPCONV_DGRAD = os.environ.get('IDF_UPCONV_DGRAD', '1') != '0'
-_DOWN_DGRAD = os.environ.get('IDF_DOWN_DGRAD', '1') != '0'
+_UPCONV = knobs.flag('IDF_UPCONV')
+_UPCONV_DGRAD = True
+_DOWN_DGRAD = True
 _UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))          # S(parity, tap): the 3x3 kernel rows / columns a low-resolution tap stands for
 
 
@@ -1744,10 +1691,10 @@ def upconv_raw(x, w_sub_frag, bias, Cout, tiles):
 
 
 # ------------------------------------------------- the attention block's proj conv folded into V
-_ATTN_FOLD = os.environ.get('IDF_ATTN_FOLD', '1') != '0'
+_ATTN_FOLD = knobs.flag('IDF_ATTN_FOLD')
 # 1 = autograd hands the attention / objective nodes zero-filled gradients for their statistics / terms outputs (13 fill launches
 # per step; the A/B switch of profiles/r04_conv_wr.txt)
-_MATERIALIZE = os.environ.get('IDF_MATERIALIZE_GRADS', '0') == '1'
+_MATERIALIZE = False
 
 
 def attn_res_tiles(qkv):
@@ -1890,11 +1837,11 @@ def fold_proj_v(wcat, bcat, wp, bp, wv, bv):
 
 
 # ------------------------------------------------- the attention block in one launch
-_ATTN_BLOCK = os.environ.get('IDF_ATTN_BLOCK', '1') != '0'
+_ATTN_BLOCK = True
 # One 4-wave workgroup per image: a win only once the batch alone fills the chip (DDIM-100 at B = 256: 306 -> 310.5 img/s).  At
 # B = 32 the launch is 32 workgroups of one wave per SIMD -- every LDS and memory latency exposed -- and the block costs ~70 us
 # against 30 us for the three per-op launches (train step 9.35 -> 9.74 ms with it at every batch; profiles/r04_attn_block.txt)
-_ATTN_BLOCK_MINB = int(os.environ.get('IDF_ATTN_BLOCK_MINB', '256'))
+_ATTN_BLOCK_MINB = knobs.num('IDF_ATTN_BLOCK_MINB')
 
 
 def attn_block_ok(x, policy=True):
@@ -2040,7 +1987,7 @@ def linear(x, weight, bias=None, silu_in=False):
 
 
 # ------------------------------------------------- conditioning path (time / latent embedding -> FiLM)
-_TEMB_FUSED = os.environ.get('IDF_TEMB_FUSED', '1') != '0'
+_TEMB_FUSED = knobs.flag('IDF_TEMB_FUSED')
 
 
 def _grad_dst(slot, like):

@@ -10,7 +10,7 @@ from . import ops
 from .grad_arena import GradArena
 from ._lib import call
 
-_CHUNK = int(os.environ.get('IDF_OPT_CHUNK', '8192'))    # elements per workgroup: 65536 ran at 3.3 TB/s, 8192 at 4.9 (tools/bench_optim.py)
+_CHUNK = 8192    # elements per workgroup: 65536 ran at 3.3 TB/s, 8192 at 4.9 (tools/bench_optim.py)
 
 
 class FusedClipAdamW(torch.optim.Optimizer):

@@ -16,14 +16,14 @@ import sys
 
 import torch
 
-from . import ops
+from . import knobs, ops
 
 _DDPM, _DDIM, _REV = 0, 1, 2
 ETA = 0.01     # sampling.py:45
-GRAPH = os.environ.get('IDF_SAMPLER_GRAPH', '1') != '0'
-STRICT_GRAPH = os.environ.get('IDF_SAMPLER_GRAPH_STRICT', '0') != '0'     # a failed capture raises instead of stepping eagerly
+GRAPH = knobs.flag('IDF_SAMPLER_GRAPH')
+STRICT_GRAPH = knobs.flag('IDF_SAMPLER_GRAPH_STRICT')     # a failed capture raises instead of stepping eagerly
 GRAPH_MIN_STEPS = 8
-GRAPH_MAX_PIXELS = int(os.environ.get('IDF_SAMPLER_GRAPH_MAXPIX', 256 * 64 * 64))   # batch x H x W up to which a step is replayed (256 CelebA images:
+GRAPH_MAX_PIXELS = knobs.num('IDF_SAMPLER_GRAPH_MAXPIX')   # batch x H x W up to which a step is replayed (256 CelebA images:
                                                                                      # 5.5 % of an eagerly issued B = 256 step is host gap)
 
 

@@ -739,15 +739,14 @@ def test_conv_rs_backward_chain_du_epilogue_vs_pytorch_autograd(case):
 
 @pytest.mark.parametrize('case', [
     # (B, channels of dy, C of x, H, film, p_drop, n_res)
-    (3, 128, 128, 16, True, 0.1, 1), (2, 128, 128, 8, True, 0.1, 2), (2, 128, 256, 8, True, 0.0, 1), (33, 128, 128, 16, False, 0.0, 0),
-    (2, 64, 128, 16, False, 0.1, 1),
+    (3, 128, 128, 8, True, 0.1, 1), (2, 128, 128, 8, True, 0.1, 2), (2, 128, 256, 8, True, 0.0, 1), (33, 128, 128, 8, False, 0.0, 0),
+    (2, 64, 128, 8, False, 0.1, 1),
 ])
-def test_conv_wr_dgrad_with_groupnorm_backward_vs_pytorch_autograd(case, monkeypatch):
+def test_conv_wr_dgrad_with_groupnorm_backward_vs_pytorch_autograd(case):
     """idf_conv_wr_dgrad_gn_bf16 (whole-image data-gradient conv with the GroupNorm / FiLM / SiLU / dropout backward in the
     wave's registers) against fp32 PyTorch autograd of conv(dropout(SiLU(FiLM(GroupNorm(x))))) with the product's dropout
     mask: dx (+ branch gradients), dgamma, dbeta, dFiLM_t, dFiLM_a <= 4e-2 -- the bound idf_conv_dgrad_gn_bf16 is held to."""
     B, Cin, C, H, film, p_drop, n_res = case
-    monkeypatch.setattr(ops, '_WR_GNB16', True)       # the whole-16x16-image form is covered here, off by default (slower)
     x = (0.3 + rnd(1, B, C, H, H)).to(DEV).bfloat16().contiguous(memory_format=CL)
     dy = rnd(2, B, Cin, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
     wgt = (rnd(3, Cin, C, 3, 3) / (C * 9) ** 0.5).to(DEV).bfloat16().float()
@@ -924,7 +923,8 @@ def test_wgrad_batch_survives_a_backward_pass_that_raised():
 def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
     """All weight gradients of a backward pass from ONE table-driven launch per (taps, mode) class
     (idf_conv_wgrad_bf16_batched, accumulating into gradient-arena slots) == the per-conv launches.  `split`: the first
-    `split` convs are flushed mid-backward on the side stream (WgradBatch.flush_async), the rest at the end, which joins."""
+    `split` convs are flushed by an early barrier (the data-parallel step flushes the backbone's gradients before the encoder's
+    backward pass), the rest at the end."""
     from infodiffusion_amd.grad_arena import GradArena, slot_of
     cases = [(4, 32, 32, 32, 32, 9, ops.S1), (4, 64, 16, 16, 128, 9, ops.S1), (2, 128, 8, 8, 128, 1, ops.S1),
              (4, 32, 32, 32, 64, 9, ops.S1), (4, 128, 8, 8, 128, 9, ops.S1), (2, 64, 16, 16, 64, 9, ops.S2),
@@ -950,16 +950,13 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
         outs.append(ops.conv_wgrad_bias_raw(a, dy, c[6], c[5], True, slot_of(w), slot_of(b), True))
         if split and i + 1 == split:
             assert all(float(o[0].abs().max()) == 0.0 for o in outs)      # nothing launched yet
-            monkeypatch.setattr(ops.WgradBatch, 'side_enabled', True)
-            # a grid of 8 (3x3 shared-tile class) / 24 workgroups looping over every work item of its class
-            # (idf_conv_wgrad_bf16_batched_capped): same sums as one workgroup per item
-            monkeypatch.setattr(ops.WgradBatch, 'side_cap', 8)
-            ops.WgradBatch.flush_async()
-            assert not ops.WgradBatch.pending and ops.WgradBatch.side_stream() is not None
+            ops.WgradBatch.flush()
+            assert not ops.WgradBatch.pending
+            ops.WgradBatch._cb_queued = True
     assert len(ops.WgradBatch.pending) == len(cases) - split
     assert all(float(o[0].abs().max()) == 0.0 for o in outs[split:])      # nothing launched yet
     ops.WgradBatch.flush()
-    assert not ops.WgradBatch.pending and ops.WgradBatch.side_stream() is None
+    assert not ops.WgradBatch.pending
     for (rW, rb), (oW, ob) in zip(refs, outs):
         assert arena.holds(oW) and arena.holds(ob)
         assert rel(oW.cpu(), rW.cpu()) < 1e-5 and rel(ob.cpu(), rb.cpu()) < 1e-5

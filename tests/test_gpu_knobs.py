@@ -43,6 +43,7 @@ def test_every_switch_is_listed():
 def test_switch_at_its_non_default_value(name, value, test):
     env = dict(os.environ)
     env[name] = value
+    env['IDF_TEST_NONDEFAULT'] = '1'       # test_gpu_model.py: the non-default paths keep the looser epsilon-hat bound
     r = subprocess.run([sys.executable, '-m', 'pytest', test, '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, '%s=%s: %s' % (name, value, (r.stdout + r.stderr)[-3000:])

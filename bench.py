@@ -237,6 +237,23 @@ class LaunchRecorder:
                 if a[21]:
                     bufs.append((21, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_rs_gn_bf16':          # round 5: the GroupNorm-prologue conv of the big maps in the row-reuse form
+            B, H, W, Cin, Cout = a[24:29]
+            px = B * H * W
+            bufs = [(0, px * Cin * 2), (17, px * Cout * 2)]
+            if a[16]:
+                bufs.append((16, px * Cout * 2))
+            if a[18]:
+                bufs.append((18, px * Cin * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_rs_dgrad_chain_bf16':  # ... and the data-gradient conv with the du epilogue
+            B, H, W, Cin, Cout = a[13:18]
+            px = B * H * W
+            C1 = a[4] if a[3] else Cout
+            bufs = [(0, px * Cin * 2), (11, px * Cout * 2), (2, px * C1 * 2)]
+            if a[3]:
+                bufs.append((3, px * (Cout - C1) * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
         if name == 'idf_conv_dgrad_chain_sc_bf16':  # ... with the block shortcut's data gradient riding in the launch
             B, H, W, Cin, Cout = a[13:18]
             sc_Cin = a[22]
@@ -618,14 +635,14 @@ def main():
         if 'conv3x3' in fam:
             n, ms, fl, by = fam['conv3x3']
             ach = fl / (ms * 1e-3) / 1e12
-            out['roofline'] = {'kernel': '3x3 conv family (conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16 / conv3x3_fewc_bf16, the sub-pixel UpSample / DownSample kernels upconv_bf16 / '
+            out['roofline'] = {'kernel': '3x3 conv family (conv_rs_bf16 / conv_ps_bf16 / conv_dlds_bf16 / conv3x3_halo_bf16 / conv3x3_fewc_bf16, the sub-pixel UpSample / DownSample kernels upconv_bf16 / '
                                          'upconv_dgrad_bf16 / downconv_dgrad_bf16 -- counted with the reference\'s 3x3 FLOPs, of which they execute 4/9, 4/9 and 1/1 --, and on the '
                                          'small maps conv_wr_kernel / resblock8_fwd_kernel / resblock8_bwd_kernel, whose launches hold 2-3 convs: '
                                          'forward incl. GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
                                          'GroupNorm backward (small maps) or its du / partial-sum half (big maps))',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
-                               'traffic': pmc_traffic_file(['conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel', 'upconv_', 'downconv_',
+                               'traffic': pmc_traffic_file(['conv_rs_bf16', 'conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel', 'upconv_', 'downconv_',
                                                             'resblock8_fwd_kernel', 'resblock8_bwd_kernel']),
                                'launches_per_step': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                                'timing': 'cold: each replayed launch on its own buffer set, sets > 256 MB together',

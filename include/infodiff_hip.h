@@ -327,7 +327,14 @@ int idf_wgrad_kr3_ok(int H, int W);
 int idf_wgrad_desc_bytes(void);
 int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy, float* dW,
                         float* db, int B, int H, int W, int Cin, int Cout, int Cin_w, int Cout_w, int taps, int mode,
-                        int target_blocks, int blk0, int* blocks_out, int* lds_out);
+                        int target_blocks, int blk0, int* blocks_out, int* lds_out, float* ws, int red_blk0,
+                        long* ws_floats_out, int* red_blocks_out);
+/* Deterministic accumulation (round 5; the reference's convolution_backward is deterministic under --deterministic, utils.py:64-71):
+ * with ws != NULL every pixel split of the entry writes its partial dW | db into its own slab of ws (plain stores, one writer per
+ * element; *ws_floats_out floats, 16-byte aligned) instead of fp32 atomics, and idf_wgrad_reduce_batched -- one launch over the
+ * WHOLE table of a flush, after its class launches -- adds the slabs to dW / db in slab order.  red_blk0 = running sum of the
+ * *red_blocks_out values of the entries before this one; a first call with ws = NULL and host_table scratch sizes the workspace. */
+int idf_wgrad_reduce_batched(const void* dev_table, int n, int total_red_blocks, void* stream);
 int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps, int mode,
                                 void* stream);
 /* UpSample's forward (modules.py:78-93: nearest x2, then conv3x3 pad 1) as four 2x2 convs on the LOW-resolution input -- the

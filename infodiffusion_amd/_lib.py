@@ -92,7 +92,8 @@ SIGNATURES = {
     'idf_wgrad_desc_bytes': ([], C.c_int),
     'idf_wgrad_kr3_ok': ([_i, _i], C.c_int),
     'idf_wgrad_upsub_ok': ([_i, _i], C.c_int),
-    'idf_wgrad_desc_fill': ([_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 11 + [_p, _p], C.c_int),
+    'idf_wgrad_desc_fill': ([_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _i, _p, _p], C.c_int),
+    'idf_wgrad_reduce_batched': ([_p, _i, _i, _p], C.c_int),
     'idf_conv_wgrad_bf16_batched': ([_p, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_gn_coef_bwd': ([_p] * 8 + [_i, _i] + [_p] * 12 + [_p, _u32, _f, _i, _i, _i, _i, _i, _p], C.c_int),
     'idf_bgemm': ([_p, _p, _p, _p, _p, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p], C.c_int),

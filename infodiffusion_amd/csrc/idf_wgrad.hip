@@ -38,6 +38,11 @@ struct WgP {
   int wshift;         // log2(W) (W is a power of two); sub-pixel UP2 form: log2(W / 2)
   int upsub;          // MODE 2 in the sub-pixel form (wgrad_block_upsub): R = LOW-resolution rows per tile
   unsigned wh_magic;  // (pix * wh_magic) >> 16 == pix / WH over the staged tile's pixels (checked on the host)
+  // two-stage, deterministic accumulation (batched launches): every pixel split writes ITS partial dW | db into its own slab of
+  // `ws` with plain stores (slab s at ws + s * ws_stride floats: dW [Nw][taps][Cw], then db [Nw]; every element of a slab has
+  // exactly one writer), and idf_wgrad_reduce_batched adds the slabs to dW / db in slab order.  ws == null: fp32 atomics into dW.
+  float* ws;
+  int ws_stride, ws_dboff;      // floats per slab (multiple of 4); offset of db inside a slab (= Nw * taps * Cw)
 };
 
 #ifndef IDF_WGRAD_BLOCKS
@@ -56,6 +61,19 @@ __device__ __forceinline__ uint4 gload16(const bf16_t* p) {      // (the cast go
 }
 __device__ __forceinline__ void gatomic_add(float* p, float v) {
   __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void gstore(float* p, float v) {
+  *(__attribute__((address_space(1))) float*)(unsigned long long)p = v;
+}
+// one partial-sum element: into the split's slab (deterministic path) or onto the gradient with an atomic
+__device__ __forceinline__ void wg_emit(const WgP& p, int slab, size_t idx, float v) {
+  if (p.ws) gstore(p.ws + (size_t)slab * p.ws_stride + idx, v);
+  else gatomic_add(p.dW + idx, v);
+}
+__device__ __forceinline__ void wg_emit_db(const WgP& p, int slab, int n, float v) {
+  if (p.ws) gstore(p.ws + (size_t)slab * p.ws_stride + p.ws_dboff + n, v);
+  else gatomic_add(p.db + n, v);
 }
 
 __device__ __forceinline__ s16x4_t tr_read(const bf16_t* lds_ptr) {
@@ -263,7 +281,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
-          if (n < p.Nw) gatomic_add(p.dW + ((size_t)n * ntaps + ky * KW + kx) * p.Cw + c, acc[kx][i][j][r]);
+          if (n < p.Nw) wg_emit(p, by, ((size_t)n * ntaps + ky * KW + kx) * p.Cw + c, acc[kx][i][j][r]);
         }
       }
     }
@@ -277,7 +295,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
     if (tid < 64 && n0 + tid < p.Nw) {
       float s = 0.f;
       for (int k = 0; k < NT / 8; ++k) s += red[k * 64 + tid];
-      gatomic_add(p.db + n0 + tid, s);
+      wg_emit_db(p, by, n0 + tid, s);
     }
   }
 }
@@ -435,7 +453,7 @@ __device__ __forceinline__ void wgrad_block_upsub(const WgP& p, int bx, const in
           for (int r = 0; r < 4; ++r) {
             const int n = n0 + wn0 + i * 16 + (lane >> 4) * 4 + r;
             if (n < p.Nw) {
-              for (int kk = 0; kk < nky; ++kk) gatomic_add(p.dW + ((size_t)n * 9 + (ky0 + kk) * 3 + kx) * p.Cw + c, v[r]);
+              for (int kk = 0; kk < nky; ++kk) wg_emit(p, by * 2 + py, ((size_t)n * 9 + (ky0 + kk) * 3 + kx) * p.Cw + c, v[r]);      // slab per (split, row parity): S(py, 0) and S(py, 1) are disjoint, one writer per element
             }
           }
         }
@@ -448,7 +466,7 @@ __device__ __forceinline__ void wgrad_block_upsub(const WgP& p, int bx, const in
     if (tid < 64 && n0 + tid < p.Nw) {
       float sacc = 0.f;
       for (int k = 0; k < NT / 8; ++k) sacc += red[k * 64 + tid];
-      gatomic_add(p.db + n0 + tid, sacc);
+      wg_emit_db(p, by * 2 + py, n0 + tid, sacc);
     }
   }
 }
@@ -465,6 +483,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16(const WgP p) {
 struct WgDesc {
   WgP p;
   int blk0, gx, gy, xcd;   // xcd = 1: blocks [blk0, blk0 + gx * roundup8(gy)) in XCD-major order
+  int red_blk0, nslab;     // two-stage accumulation: first block of this entry in idf_wgrad_reduce_batched's grid, slabs to add
 };
 
 // `total` work items (the 1-D block ids of the table) over a grid of gridDim.x <= total blocks: block b takes items b, b + grid, ...
@@ -531,6 +550,36 @@ __global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDe
   }
 }
 
+// Second stage of the deterministic accumulation: dW[i] += sum over this entry's slabs of ws[slab][i], in slab order (and db likewise):
+// a fixed order of fp32 additions, so two runs of a step give the same bits (the reference's convolution_backward under
+// --deterministic: utils.py:64-71).  One workgroup = 1024 consecutive floats of one entry's slab; float4 slab loads.
+constexpr int WG_RED = 1024;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgDesc* __restrict__ tab, int n) {
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (tab[mid].red_blk0 <= bid) lo = mid; else hi = mid;
+  }
+  const WgDesc* d = tab + lo;
+  const WgP& p = d->p;
+  if (!p.ws) return;
+  const int i0 = (bid - d->red_blk0) * WG_RED + threadIdx.x * 4;
+  if (i0 >= p.ws_stride) return;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  const float* src = p.ws + i0;
+  for (int k = 0; k < d->nslab; ++k) {
+    const f32x4_t v = *(const __attribute__((address_space(1))) f32x4_t*)(unsigned long long)(src + (size_t)k * p.ws_stride);
+    s += v;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + e;
+    if (i < p.ws_dboff) p.dW[i] += s[e];
+    else if (p.db && i < p.ws_dboff + p.Nw) p.db[i - p.ws_dboff] += s[e];
+  }
+}
+
 // IDF_WGRAD_KR3 (default 1): the batched stride-1 3x3 class runs in the shared-tile form
 #define g_kr3 (idf_knobs().wgrad_kr3)
 
@@ -556,6 +605,7 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   if (a2 && (C1 <= 0 || C1 >= Cin || (C1 % 64) || mode != 0))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: two-source input needs C1 %% 64 == 0 (C1 %d) and stride 1", C1);
   p.a = (const bf16_t*)a; p.dy = (const bf16_t*)dy; p.dW = dW; p.db = db;
+  p.ws = nullptr; p.ws_stride = 0; p.ws_dboff = 0;
   p.a2 = (const bf16_t*)a2; p.C1 = a2 ? C1 : Cin;
   if (Cin_w < 0 || Cin_w > Cin || Cout_w < 0 || Cout_w > Cout)
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16: gradient extents %d x %d exceed the operands' %d x %d", Cout_w, Cin_w, Cout, Cin);
@@ -675,7 +725,8 @@ extern "C" int idf_wgrad_desc_bytes(void) { return (int)sizeof(WgDesc); }
 
 extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, const void* a2, int C1, const void* dy,
                                    float* dW, float* db, int B, int H, int W, int Cin, int Cout, int Cin_w, int Cout_w,
-                                   int taps, int mode, int target_blocks, int blk0, int* blocks_out, int* lds_out) {
+                                   int taps, int mode, int target_blocks, int blk0, int* blocks_out, int* lds_out, float* ws,
+                                   int red_blk0, long* ws_floats_out, int* red_blocks_out) {
   if (!host_table || index < 0 || !blocks_out || !lds_out) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: null argument");
   if (B <= 0) IDF_FAIL(IDF_ERR_BADARG, "wgrad_desc_fill: empty batch");
   WgDesc d;
@@ -702,6 +753,18 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
                    a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : (upsub ? tpb_up : tpb)), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
+  {
+    // two-stage accumulation: one slab per pixel split (two per split in the sub-pixel UpSample form: one per row parity)
+    const long nW = (long)d.p.Nw * taps * d.p.Cw;
+    d.p.ws_dboff = (int)nW;
+    d.p.ws_stride = (int)((nW + d.p.Nw + 3) / 4 * 4);
+    d.nslab = d.gy * (d.p.upsub ? 2 : 1);
+    d.p.ws = ws;
+    d.red_blk0 = red_blk0;
+    if (nW + d.p.Nw >= (1L << 31)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_desc_fill: gradient too large");
+    if (ws_floats_out) *ws_floats_out = (long)d.nslab * d.p.ws_stride;
+    if (red_blocks_out) *red_blocks_out = (d.p.ws_stride + WG_RED - 1) / WG_RED;
+  }
   static const int xcd = 1;
   d.xcd = (xcd && (blk0 % 8) == 0 && d.gy >= 8) ? 1 : 0;
   memcpy((char*)host_table + (size_t)index * sizeof(WgDesc), &d, sizeof(d));
@@ -739,6 +802,17 @@ extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int tot
     hipLaunchKernelGGL(conv_wgrad_up_sub_batched, g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   }
   else hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<3, 2>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// Second stage of the batched weight gradients when idf_wgrad_desc_fill was given workspaces: adds every entry's slabs to its dW / db
+// in slab order (deterministic).  dev_table: ALL entries of the flush (every class), n of them; total_red_blocks = sum of the
+// red_blocks_out values.  Entries filled with ws = NULL (fp32 atomics) are skipped.
+extern "C" int idf_wgrad_reduce_batched(const void* dev_table, int n, int total_red_blocks, void* stream) {
+  if (n <= 0 || total_red_blocks <= 0) return IDF_OK;
+  if (!dev_table) IDF_FAIL(IDF_ERR_BADARG, "wgrad_reduce_batched: null table");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_red_blocks), dim3(256), 0, (hipStream_t)stream, (const WgDesc*)dev_table, n);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

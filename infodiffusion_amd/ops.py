@@ -564,6 +564,7 @@ _BWD_CHAIN = knobs.flag('IDF_BWD_CHAIN')     # du epilogue + streaming apply ins
 _SC_FUSE = knobs.flag('IDF_SC_FUSE')       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
 _SC_FUSE_MAXPIX = 8192   # ... where those launches leave CUs idle: B * H * W up to 32 x 16 x 16
 _BWD_LAZY = knobs.flag('IDF_BWD_LAZY')
+_WGRAD_DET = knobs.flag('IDF_WGRAD_DET')        # batched weight gradients: slab partials + ordered reduce instead of fp32 atomics
 
 
 @functools.lru_cache(maxsize=None)
@@ -806,12 +807,26 @@ class WgradBatch:
         key = tuple((it[0].data_ptr(), it[1].data_ptr()) + it[2:11] + (_p(it[11]), it[12], it[13], it[14])
                     for _, grp in classes for it in grp)
         buf = cls._bufs.pop(key, None)
+        ws_off, ws_tot = [], 0
+        if _WGRAD_DET and (buf is None or buf[2] != key or capturing):
+            # deterministic accumulation: every pixel split writes its partial into a slab of its own, one reduce launch adds the
+            # slabs in a fixed order.  Sizing pass: slab floats per entry (the plan does not depend on the workspace address).
+            scratch = ctypes.create_string_buffer(nb)
+            nblk, nlds, nws, nred = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0), ctypes.c_int(0)
+            for (taps, mode), grp in classes:
+                for (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1, Cin_w, Cout_w) in grp:
+                    _lib.check(lib.idf_wgrad_desc_fill(ctypes.addressof(scratch), 0, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout,
+                                                       Cin_w, Cout_w, taps, mode, 0, 0, ctypes.byref(nblk), ctypes.byref(nlds), None,
+                                                       0, ctypes.byref(nws), ctypes.byref(nred)), 'idf_wgrad_desc_fill')
+                    ws_off.append(ws_tot)
+                    ws_tot += nws.value
         if buf is None:
             reuse = None
             if capturing:
                 # no pinned allocation inside a capture: take over a table an eager step made (the capture's own
                 # warm-up pass left one of the right size; the capture follows a device-wide synchronisation)
-                fit = [k for k, v in cls._bufs.items() if v[0].numel() >= total * nb]
+                fit = [k for k, v in cls._bufs.items() if v[0].numel() >= total * nb and
+                       (not _WGRAD_DET or (len(v) > 5 and v[5] is not None and v[5].numel() >= ws_tot))]
                 if fit:
                     reuse = cls._bufs.pop(fit[-1])
             elif len(cls._bufs) >= cls._LRU:
@@ -836,17 +851,30 @@ class WgradBatch:
                 # device-wide synchronisation, and the pair is retired to the graph)
             plan, off = [], 0
             nblk, nlds = ctypes.c_int(0), ctypes.c_int(0)
+            nws, nred = ctypes.c_long(0), ctypes.c_int(0)
+            if _WGRAD_DET and (len(buf) < 6 or buf[5] is None or buf[5].numel() < ws_tot):
+                if capturing:
+                    raise RuntimeError('WgradBatch: run one eager step before capture (weight-gradient workspace)')
+                while len(buf) < 6:
+                    buf.append(None)
+                buf[5] = torch.empty((ws_tot,), dtype=torch.float32, device=items[0][0].device)
+            k, red = 0, 0
             for (taps, mode), grp in classes:
                 host = buf[0].data_ptr() + off * nb
                 blk, lds = 0, 0
                 for i, (a, dy, dW, db, B, H, W, Cin, Cout, _, _, a2, C1, Cin_w, Cout_w) in enumerate(grp):
+                    ws = buf[5].data_ptr() + 4 * ws_off[k] if _WGRAD_DET else None
                     _lib.check(lib.idf_wgrad_desc_fill(host, i, _p(a), _p(a2), C1, _p(dy), dW, db, B, H, W, Cin, Cout, Cin_w,
-                                                       Cout_w, taps, mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds)),
+                                                       Cout_w, taps, mode, 0, blk, ctypes.byref(nblk), ctypes.byref(nlds), ws, red,
+                                                       ctypes.byref(nws), ctypes.byref(nred)),
                                'idf_wgrad_desc_fill')
                     blk += nblk.value
                     lds = max(lds, nlds.value)
+                    red += nred.value
+                    k += 1
                 plan.append((off, len(grp), blk, lds, taps, mode))
                 off += len(grp)
+            plan.append(('reduce', total, red if _WGRAD_DET else 0))
             buf[1][:total * nb].copy_(buf[0][:total * nb], non_blocking=True)
             buf[2], buf[3] = key, plan
             if not capturing:               # eager runs can be a step ahead of the GPU: guard the table's next rewrite
@@ -854,7 +882,12 @@ class WgradBatch:
                 buf[4].record()
         base = buf[1].data_ptr()
         plan = buf[3]
-        for off, n, blk, lds, taps, mode in plan:
+        for ent in plan:
+            if ent[0] == 'reduce':
+                if ent[2]:
+                    call('idf_wgrad_reduce_batched', base, ent[1], ent[2], _st())
+                continue
+            off, n, blk, lds, taps, mode = ent
             call('idf_conv_wgrad_bf16_batched', base + off * nb, n, blk, lds, taps, mode, _st())
 
 

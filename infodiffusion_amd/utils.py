@@ -71,6 +71,9 @@ def seed_everything(r_seed):
     torch.manual_seed(r_seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(r_seed)
+    # utils.py:71 sets torch.backends.cudnn.deterministic = True: the counterpart here is the ordered form of every accumulation that
+    # otherwise uses fp32 atomics (weight gradients, GroupNorm parameter gradients) -- two runs of a step give the same bits
+    ops.set_deterministic(True)
 
 
 class AverageMeter:

@@ -1042,6 +1042,46 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
             dist.destroy_process_group()
 
 
+def test_deterministic_mode_gives_bit_identical_training_steps():
+    """ops.set_deterministic(True) -- what utils.seed_everything switches on, as the reference's sets cudnn.deterministic
+    (utils.py:64-71): two runs of the benchmarked configuration (CelebA, bf16, dropout on, B = 8, eager steps, the captured step and
+    replays through GraphedTrainStep) give the SAME BITS in every loss, every gradient norm and every parameter after 6 steps;
+    the default mode (fp32 atomics in the weight-gradient and GroupNorm-parameter accumulations) is only required to train."""
+    from infodiffusion_amd import ops
+    from infodiffusion_amd.optim import FusedClipAdamW
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    cfg = O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1)
+    gx = torch.Generator(device='cpu')
+    gx.manual_seed(9)
+    x = (torch.rand(8, *cfg.shape, generator=gx) * 2 - 1).to(DEV)
+
+    def run():
+        torch.manual_seed(123)
+        torch.cuda.manual_seed_all(123)
+        model, args, sd = make_infodiff(cfg, DEV, 'bf16', 'manifest_celeba')
+        model.train()
+        opt = FusedClipAdamW(model.parameters(), lr=2e-4, weight_decay=1e-5, max_norm=1.0)
+        step = GraphedTrainStep(model, args_of(cfg), opt)
+        out = []
+        for k in range(6):
+            lv = step(x, 0)
+            out.append((float(lv), float(opt.total_norm())))
+        assert step.graph is not None
+        torch.cuda.synchronize()
+        return out, [p.detach().clone() for p in model.parameters()]
+    prev = ops._WGRAD_DET
+    try:
+        ops.set_deterministic(True)
+        assert ops._WGRAD_DET
+        a, pa = run()
+        b, pb = run()
+        assert a == b, (a, b)
+        assert all(torch.equal(u, v) for u, v in zip(pa, pb))
+        assert a[-1][0] < a[0][0]
+    finally:
+        ops.set_deterministic(prev)
+
+
 def test_graphed_train_step_other_objectives_and_short_batches():
     """The capture paths the InfoDiff/regular-prior tests do not reach: (1) the latent Diff model (its timestep draw
     used to be a CPU draw + blocking copy: not capturable); (2) --use_C: the KL capacity follows the epoch through

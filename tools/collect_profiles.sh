@@ -19,6 +19,9 @@ python tools/pmc_traffic.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/$
 # MFMA-pipe counters of the same eager steps (their own pass: --pmc with --kernel-trace only)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $out/${tag}_MFMA -- python3 bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-sampling --no-large-batch > $out/${tag}_MFMA.log 2>&1
 python tools/pmc_mfma.py $out/${tag}_MFMA $out/${tag}_pmc_mfma.json > $out/${tag}_pmc_mfma.txt
-rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_MFMA
+# wave-state / vector-issue counters (their own pass): is a kernel vector-bound?
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/${tag}_VALU -- python3 bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-sampling --no-large-batch > $out/${tag}_VALU.log 2>&1
+python tools/pmc_valu.py $out/${tag}_VALU $out/${tag}_pmc_valu.json > $out/${tag}_pmc_valu.txt
+rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_MFMA $out/${tag}_VALU
 rm -rf $out/${tag}_p1 $out/${tag}_p2      # the databases are large; the summaries above are what is kept
 ls -la $out | grep ${tag}_

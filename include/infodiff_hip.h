@@ -222,6 +222,24 @@ int idf_conv_rs_dgrad_chain_bf16(const void* dy, const void* w_frag, const void*
                                  const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, void* out,
                                  float* part_out, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* The same data-gradient conv with the WHOLE GroupNorm / FiLM / SiLU / dropout backward behind it in one launch
+ * (/root/reference/modules.py:312-320, 283-288 backward: idf_conv_rs_dgrad_chain_bf16 + idf_gn_bwd_apply, with du held in
+ * registers while the workgroups that own the tiles of one (image, 64-channel slice) meet at a counter and fold each other's
+ * partial sums).  idf_conv_rs_dgrad_gn_tiles: T of the partials workspace when the form covers the shape on this device (the
+ * grid must be a whole number of groups and resident at once), else 0.  dres / dres2: residual / skip gradients (dense
+ * [B,H,W,Cout]) or null; dx | dx2 as x | x2; part: workspace [B][T][Cout][2]; dfilm_t / dfilm_a [B][2 Cout], dgb [B][2][Cout]
+ * or dgam / dbet (accumulated) as idf_gn_bwd_apply's.  Launches of this entry must not overlap each other (one counter set per
+ * process).  idf_conv_rs_sync_timeouts: workgroups that gave up waiting since the last reset (0 in a healthy process; reads the
+ * device: synchronises). */
+int idf_conv_rs_dgrad_gn_tiles(int B, int H, int W, int Cin, int Cout);
+int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x, const void* x2, int C1, const float* sc,
+                              const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, const void* dres,
+                              const void* dres2, void* dx, void* dx2, float* part, const float* gamma, const float* beta,
+                              const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean, const float* rstd,
+                              float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet, int B, int H, int W, int Cin,
+                              int Cout, void* stream);
+int idf_conv_rs_sync_timeouts(int reset);
+
 /* The backward of the same blocks: the data-gradient convs of stages nstage-1 .. first with the GroupNorm / FiLM / SiLU / dropout
  * backward behind each (what idf_conv_wr_dgrad_gn_bf16 computes per stage) in ONE launch, one workgroup per image; every stage
  * has 128 channels.  Stage i: x = its GroupNorm input (h_{i-1}; the block input for stage 0), w_frag = the data-gradient weights

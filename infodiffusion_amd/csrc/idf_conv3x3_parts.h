@@ -73,6 +73,9 @@ struct C3P {
   // (cout tile, pixel tile) items of the rs_total; LDS: chunk images | fp32 epilogue tile at rs_os_off | statistics scratch at
   // aux_off | coefficients at rs_cof_off
   int rs_per, rs_total, rs_os_off, rs_cof_off;
+  // group-synchronised du epilogue (EPI 3): the GroupNorm backward applied in the launch -- y = dx (x | x2 sources: y | rs_dx2),
+  // res / gnb_res2 = the residual-branch gradients (dense, Cout channels), dyp_f = the fold's parameters (part = st_out)
+  bf16_t* rs_dx2; unsigned* rs_sync; unsigned* rs_sync_err;
   int rs_x0, rs_tidx, rs_halves;   // half-width tiles (two 256-thread workgroups per CU): first column and statistics-tile index of the current tile; tiles per row strip
 };
 
@@ -560,7 +563,11 @@ __device__ __forceinline__ void due_fetch_coef(const C3P& p, int b, int n0, int 
 }
 
 // second half of due_epilogue: dA [BM][BN + 4] is in LDS (the caller's barrier is behind it).  LDSONLY as lds_epilogue_tail's.
-template <int BM, int BN, int NT, bool LDSONLY, bool SILU, bool DROP, int TWS = 0>
+// KEEP (idf_conv_rs.hip's group-synchronised form): du stays in LDS (packed bf16, in the slot of the dA it came from: a thread's own
+// slots) instead of going to memory, and the
+// partials are published write-through (one 8-byte `sc1` store per channel, whole 128-byte lines per instruction of wave 0) for
+// the other workgroups of the image to read inside this launch.
+template <int BM, int BN, int NT, bool LDSONLY, bool SILU, bool DROP, int TWS = 0, bool KEEP = false>
 __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
                                                     const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
                                                     uint64_t seedv) {
@@ -595,7 +602,8 @@ __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char*
         const float lo = __uint_as_float(dw[e] << 16), hi = __uint_as_float(dw[e] & 0xffff0000u);
         s1[2 * e] += lo; s2[2 * e] += lo * xv[2 * e]; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * xv[2 * e + 1];
       }
-      *reinterpret_cast<uint4*>(p.y + e0) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+      if constexpr (KEEP) *reinterpret_cast<uint4*>(Os + pl * PF + cc) = make_uint4(dw[0], dw[1], dw[2], dw[3]);   // in place of the dA it came from
+      else *reinterpret_cast<uint4*>(p.y + e0) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
     }
   }
   // lanes CPR apart hold the same channels: fold them, then the waves through LDS (outside the fp32 tile)
@@ -621,21 +629,26 @@ __device__ __forceinline__ void due_epilogue_tail_t(const C3P& p, unsigned char*
     float a = 0.f, q = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { a += part[(w * BN + c) * 2]; q += part[(w * BN + c) * 2 + 1]; }
-    reinterpret_cast<float2*>(p.st_out)[((size_t)b * p.tiles_per_img + (TWS ? p.rs_tidx : oy0 / R)) * C + n0 + c] = make_float2(a, q);
+    float2* dst = reinterpret_cast<float2*>(p.st_out) + ((size_t)b * p.tiles_per_img + (TWS ? p.rs_tidx : oy0 / R)) * C + n0 + c;
+    if constexpr (KEEP) {
+      const unsigned long long v = ((unsigned long long)__float_as_uint(q) << 32) | __float_as_uint(a);
+      __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) unsigned long long*>(reinterpret_cast<uintptr_t>(dst)), v,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else *dst = make_float2(a, q);
   }
 }
 
 
 // the activation / dropout switches are launch-uniform: resolved ONCE per tile, each case straight-line (with the conditions inside
 // the vector loop hipcc emitted a branch, a wait and a partial copy of the body per 4 elements)
-template <int BM, int BN, int NT, bool LDSONLY = false, int TWS = 0>
+template <int BM, int BN, int NT, bool LDSONLY = false, int TWS = 0, bool KEEP = false>
 __device__ __forceinline__ void due_epilogue_tail(const C3P& p, unsigned char* smem, int b, int oy0, int n0, int KT, int tid,
                                                   const uint4 (&xr)[BM * (BN / 8) / NT], const float (&scv)[8], const float (&shv)[8],
                                                   uint64_t seedv) {
   if (p.act == 2) {
-    if (p.seed != nullptr) due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, true, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
-    else due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, false, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
-  } else due_epilogue_tail_t<BM, BN, NT, LDSONLY, false, false, TWS>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+    if (p.seed != nullptr) due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, true, TWS, KEEP>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+    else due_epilogue_tail_t<BM, BN, NT, LDSONLY, true, false, TWS, KEEP>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
+  } else due_epilogue_tail_t<BM, BN, NT, LDSONLY, false, false, TWS, KEEP>(p, smem, b, oy0, n0, KT, tid, xr, scv, shv, seedv);
 }
 
 template <int TM, int TN, int BM, int BN, int NT>

@@ -89,7 +89,16 @@ __device__ __forceinline__ void rs_group_stats(double a, double d, double inv_n,
   *mean = (float)mu;
 }
 
-// EPI: 0 plain (bias, residual, statistics partials of y), 2 the backward chain's du epilogue (idf_conv_dgrad_chain_bf16's)
+// EPI: 0 plain (bias, residual, statistics partials of y), 2 the backward chain's du epilogue (idf_conv_dgrad_chain_bf16's),
+// 3 the du epilogue + the GroupNorm backward itself, GROUP-SYNCHRONISED: the workgroups that hold the tiles of one (image, 64-channel
+// slice) publish their (sum du, sum du x) partials, meet at a counter, fold everybody's partials into (K1, K0) and write
+// dx = A du + K1 x + K0 (+ dres + dres2) from the du and x they still hold in registers -- du never goes to memory and the streaming
+// pass idf_gn_bwd_apply (3 reads + 1 write of the tensor) does not exist.  Workgroups walk the items in lock step (item = round *
+// grid + workgroup; the grid is a whole number of groups and resident at once: host), so a group's members always sit in the same
+// round; the hand-off is MI355X_MICROARCH.md's counter form: `sc1` partial stores by wave 0, its vmcnt(0), one agent-scope add,
+// an `sc1` poll by that wave, the workgroup's barrier, `sc1` loads.  The counter only ever grows (64 per completed group, whatever
+// the group size), so no launch has to zero it and a replayed graph needs no per-launch state; the spin is bounded (a workgroup
+// that gives up raises *rs_sync_err and the host reports it: results of that launch are garbage, the process does not hang).
 template <int W, int CIN, bool PRO, int EPI, int NPH>
 __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   using G = RsGeo<W, NPH>;
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   constexpr int RPK = PXK / TW;                                                       // halo rows per round (1, or 2 for 64 channels at 32x32)
   constexpr int NEV = HR * 2 * PIECES, NE = (NEV + NT - 1) / NT;                      // the two halo columns: vectors, rounds
   constexpr int TWP = NPH == 2 ? 0 : TWS;                                             // the tails' pixel map: whole rows / half-width tiles
-  constexpr bool DUE = EPI == 2;
+  constexpr bool DUE = EPI == 2 || EPI == 3, SYN = EPI == 3;
+  static_assert(!SYN || NPH == 1, "the synchronised form is built for two workgroups per CU");
   // two workgroups per CU have 80 KB of LDS each: where the chunk images and the fp32 epilogue tile do not fit side by side the
   // tile takes the images' place (the next tile's rows then wait in registers until the epilogue has read it)
   constexpr bool ALIAS = G::ALIAS_OS(CIN);
@@ -112,9 +122,11 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int cg = wave & 3, ph = wave >> 2;            // cout group of 16, pixel half (NPH = 1: always 0)
   const int wgid = xcd_tile_id(blockIdx.x, gridDim.x);
-  int item = wgid * p.rs_per;
-  const int item_end = min(item + p.rs_per, p.rs_total);
+  const int istep = SYN ? (int)gridDim.x : 1;         // SYN: lock-step rounds over the grid; else rs_per consecutive items
+  int item = SYN ? wgid : wgid * p.rs_per;
+  const int item_end = SYN ? p.rs_total : min(item + p.rs_per, p.rs_total);
   if (item >= item_end) return;
+  bool first_item = true;
   const int TR = p.H / R, halves = p.rs_halves;      // row strips per image; tiles per strip (1 or 2)
   const int npt = p.B * halves * TR;                  // pixel tiles: ((image, half), strip) -- a workgroup's consecutive items are
                                                       // vertically adjacent tiles of one image half
@@ -346,20 +358,25 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
 
   for (;;) {
     RS_STAMP(tt0);
-    const bool has_next = item + 1 < item_end;
+    const bool has_next = item + istep < item_end;
     int nnt = nt, nb = b, nhalf = half, noy0 = oy0, nn0 = n0;
-    if (has_next) decode(item + 1, nnt, nb, nhalf, noy0, nn0);
+    if (has_next) decode(item + istep, nnt, nb, nhalf, noy0, nn0);
     pe.rs_x0 = half * TW; pe.rs_tidx = (oy0 / R) * halves + half;
     // ---- what the epilogue reads from memory, then the next tile's rows (vmcnt is in order: the epilogue's operands first)
     uint4 due_xr[DUE ? BM * (BN / 8) / NT : 1];
     float dscv[8], dshv[8];
     uint64_t dseed = 0;
+    constexpr int DNI = BM * (BN / 8) / NT;
+    uint4 drr[SYN ? DNI : 1];                             // SYN: the residual-branch gradient of this thread's vectors
+    float gpar[7];                                        // SYN: this channel's fold parameters (threads < 64)
     if constexpr (DUE) {
       due_fetch_x<BM, BN, NT, TWP>(pe, due_xr, b, oy0, n0, BM, tid);
       due_fetch_coef<BN>(p, b, n0, tid, dscv, dshv, dseed);
     }
     const bool refold = PRO && has_next && nb != b;       // the workgroup crosses into the next image (never at one or two tiles per CU)
-    if (has_next) issue_rows(nb, noy0, nhalf * TW);
+    // (ALIAS && SYN: the rows would sit in registers across the tail, the wait and the apply -- 40 of them at 128 channels; that
+    // form runs one round at the training shapes, so its next tile, when there is one, is fetched behind the apply instead)
+    if (has_next && !(ALIAS && SYN)) issue_rows(nb, noy0, nhalf * TW);
     RS_STAMP(tt1);
     RS_ADD(4, tt0, tt1);
 
@@ -433,7 +450,136 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     lds_barrier();
     RS_STAMP(tt5);
     RS_ADD(8, tt4, tt5);
-    if constexpr (DUE) {
+    if constexpr (SYN) {
+      // what the apply reads besides du and x: issued behind the tail (its arithmetic needs every register), in front of the wait
+      auto fetch_apply_operands = [&]() __attribute__((always_inline)) {
+        const int cc = (tid & 7) * 8;
+#pragma unroll
+        for (int k = 0; k < DNI; ++k) {
+          drr[k] = make_uint4(0, 0, 0, 0);
+          if (p.res) drr[k] = *reinterpret_cast<const uint4*>(p.res + (unsigned)(tile_pix<TWP>(pe, b, oy0, (tid + k * NT) >> 3) * p.Cout + n0 + cc));
+        }
+        if (tid < 64) {
+          const GnFoldP& f = p.dyp_f;
+          const int c = n0 + tid, g = c / (p.Cout >> 5);
+          gpar[0] = f.mean[b * 32 + g]; gpar[1] = f.rstd[b * 32 + g];
+          gpar[2] = f.gamma ? f.gamma[c] : 1.f; gpar[3] = f.beta ? f.beta[c] : 0.f;
+          gpar[4] = gpar[5] = gpar[6] = 0.f;
+          if (f.film_t) { gpar[4] = f.film_t[(size_t)b * f.ld_t + c]; gpar[5] = f.film_t[(size_t)b * f.ld_t + p.Cout + c]; }
+          if (f.film_a) gpar[6] = f.film_a[(size_t)b * f.ld_a + c];
+        }
+      };
+      due_epilogue_tail<BM, BN, NT, true, TWP, true>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
+      // ---- publish (wave 0 stored the partials), meet the other tiles of (image b, channels n0 .. n0 + 63)
+      const GnFoldP& f = p.dyp_f;
+      const int C = p.Cout, T = p.tiles_per_img;
+      if (wave == 0) {
+        auto* cnt = reinterpret_cast<__attribute__((address_space(1))) unsigned*>(reinterpret_cast<uintptr_t>(p.rs_sync + b * p.n_tiles + nt));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt, (unsigned)(64 / T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_apply_operands();
+        const unsigned target = ((unsigned)__builtin_amdgcn_readfirstlane((int)old) & ~63u) + 64u;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21)) { if (lane == 0) atomicOr(p.rs_sync_err, 1u); break; }
+        }
+      } else fetch_apply_operands();
+      lds_barrier();
+      // ---- fold: S1, S2 of this channel over the group's T tiles (thread = channel x tile quarter; fixed order), then the
+      // per-channel / per-group arithmetic of gn_bwd_fold (idf_gnfold.h)
+      float* red = reinterpret_cast<float*>(smem + p.aux_off);        // [4][64][2] | pc [64][2] | kk [64][2] (du stays in the fp32 tile's place)
+      float* pc = red + 512;
+      float* kk = pc + 128;
+      {
+        const int c = tid & 63, tq = tid >> 6;
+        auto* src = reinterpret_cast<__attribute__((address_space(1))) const unsigned*>(
+            reinterpret_cast<uintptr_t>(p.st_out + (((size_t)b * T) * C + n0 + c) * 2));
+        unsigned vs[8], vq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = min(tq + 4 * i, T - 1);
+          vs[i] = __hip_atomic_load(src + (size_t)t * C * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          vq[i] = __hip_atomic_load(src + (size_t)t * C * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = tq + 4 * i < T;
+          s_ += in ? __uint_as_float(vs[i]) : 0.f; q_ += in ? __uint_as_float(vq[i]) : 0.f;
+        }
+        red[(tq * 64 + c) * 2] = s_; red[(tq * 64 + c) * 2 + 1] = q_;
+      }
+      lds_barrier();
+      const int cpg = C >> 5;
+      if (tid < 64) {
+        const int cl = tid, c = n0 + cl;
+        const float S1 = (red[cl * 2] + red[(64 + cl) * 2]) + (red[(128 + cl) * 2] + red[(192 + cl) * 2]);
+        const float S2 = (red[cl * 2 + 1] + red[(64 + cl) * 2 + 1]) + (red[(128 + cl) * 2 + 1] + red[(192 + cl) * 2 + 1]);
+        const float mu = gpar[0], r = gpar[1], ga = gpar[2], be = gpar[3], st = gpar[4], bt = gpar[5], sa = gpar[6];
+        const float D1 = S1, D2 = r * (S2 - mu * S1);
+        const float fm = (1.f + st) * (1.f + sa);
+        if (pe.rs_tidx == 0) {                            // one workgroup per group stores the parameter / FiLM gradients
+          const float Gf = ga * D2 + be * D1, Ge = D1;
+          if (f.dfilm_t) { f.dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); f.dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
+          if (f.dfilm_a) { f.dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; f.dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
+          if (f.dgb) { f.dgb[((size_t)b * 2 + 0) * C + c] = fm * D2; f.dgb[((size_t)b * 2 + 1) * C + c] = fm * D1; }
+          if (f.dgam) atomicAdd(f.dgam + c, fm * D2);
+          if (f.dbet) atomicAdd(f.dbet + c, fm * D1);
+        }
+        pc[2 * cl] = ga * fm * D1; pc[2 * cl + 1] = ga * fm * D2;
+      }
+      lds_barrier();
+      if (tid < 64) {
+        const int cl = tid, gl = cl / cpg;
+        float P1 = 0.f, P2 = 0.f;
+        for (int k = gl * cpg; k < (gl + 1) * cpg; ++k) { P1 += pc[2 * k]; P2 += pc[2 * k + 1]; }
+        const float mu = gpar[0], r = gpar[1], invN = 1.f / ((float)f.HW * cpg);
+        kk[2 * cl] = -r * r * P2 * invN;
+        kk[2 * cl + 1] = (-r * P1 + r * r * mu * P2) * invN;
+      }
+      lds_barrier();
+      // ---- dx = A du + K1 x + K0 (+ dres + dres2): gn_bwd_apply_loop's arithmetic on registers
+      {
+        const int cc = (tid & 7) * 8;
+        float k1v[8], k0v[8];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(kk + 2 * cc + 4 * q4);
+          k1v[2 * q4] = t4.x; k0v[2 * q4] = t4.y; k1v[2 * q4 + 1] = t4.z; k0v[2 * q4 + 1] = t4.w;
+        }
+        bf16_t* dst = p.y;
+        int opitch = C, oc = n0 + cc;
+        if (p.due_x2) {
+          if (n0 < p.due_C1) opitch = p.due_C1;
+          else { dst = p.rs_dx2; opitch = C - p.due_C1; oc -= p.due_C1; }
+        }
+#pragma unroll
+        for (int k = 0; k < DNI; ++k) {
+          const int pl = (tid + k * NT) >> 3, pix = tile_pix<TWP>(pe, b, oy0, pl);
+          float o[8];
+          const uint4 duk = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + pl * (BN + 4) + cc);
+          const uint32_t xw[4] = {due_xr[k].x, due_xr[k].y, due_xr[k].z, due_xr[k].w}, dw[4] = {duk.x, duk.y, duk.z, duk.w};
+          const uint32_t rw[4] = {drr[k].x, drr[k].y, drr[k].z, drr[k].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x0 = __uint_as_float(xw[i] << 16), x1 = __uint_as_float(xw[i] & 0xffff0000u);
+            const float d0 = __uint_as_float(dw[i] << 16), d1 = __uint_as_float(dw[i] & 0xffff0000u);
+            o[2 * i] = dscv[2 * i] * d0 + k1v[2 * i] * x0 + k0v[2 * i] + __uint_as_float(rw[i] << 16);
+            o[2 * i + 1] = dscv[2 * i + 1] * d1 + k1v[2 * i + 1] * x1 + k0v[2 * i + 1] + __uint_as_float(rw[i] & 0xffff0000u);
+          }
+          if (p.gnb_res2) {
+            const uint4 r2 = *reinterpret_cast<const uint4*>(p.gnb_res2 + (unsigned)(pix * C + n0 + cc));
+            const uint32_t r2w[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[2 * i] += __uint_as_float(r2w[i] << 16); o[2 * i + 1] += __uint_as_float(r2w[i] & 0xffff0000u); }
+          }
+          *reinterpret_cast<uint4*>(dst + (unsigned)(pix * opitch + oc)) =
+              make_uint4(idf_pack_bf16(o[0], o[1]), idf_pack_bf16(o[2], o[3]), idf_pack_bf16(o[4], o[5]), idf_pack_bf16(o[6], o[7]));
+        }
+      }
+    } else if constexpr (DUE) {
       due_epilogue_tail<BM, BN, NT, true, TWP>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
     } else {
       uint4 none[(BM * (BN / 8) + NT - 1) / NT];
@@ -441,18 +587,20 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     }
     RS_STAMP(tt6);
     RS_ADD(9, tt5, tt6);
-    RS_ADD(10, (item == wgid * p.rs_per ? ts0 : tt0), tt6);
+    RS_ADD(10, (first_item ? ts0 : tt0), tt6);
+    first_item = false;
 #ifdef IDF_RS_STAMP
     rs_sum[11] += 1;
 #endif
     if (!has_next) break;
     if constexpr (ALIAS) {
+      if constexpr (SYN) issue_rows(nb, noy0, nhalf * TW);
       lds_barrier();                                   // the fp32 tile has been read: the images' place is free again
       if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
       write_rows(nb, noy0, nhalf * TW, PRO && p.a_out != nullptr && nn0 == 0);
       lds_barrier();
     }
-    ++item; nt = nnt; b = nb; half = nhalf; oy0 = noy0; n0 = nn0;
+    item += istep; nt = nnt; b = nb; half = nhalf; oy0 = noy0; n0 = nn0;
   }
   RS_FLUSH;
 }
@@ -489,29 +637,63 @@ int rs_ncu() {
   return ncu;
 }
 
+// the group-synchronised form's counters: one per (image, 64-channel slice) of a launch, shared by every launch of the process
+// (launches that use them must not overlap: the package issues its compute on one stream)
+constexpr int RS_SYNC_MAX = 8192;
+__device__ unsigned g_rs_sync[RS_SYNC_MAX];
+__device__ unsigned g_rs_sync_err;
+
 template <int W, int CIN, bool PRO, int EPI, int NPH>
-int launch_rs(C3P& p, hipStream_t st) {
+int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
   using G = RsGeo<W, NPH>;
   constexpr int halves = 3 - NPH;
   p.R = G::R; p.rs_halves = halves; p.tiles_per_img = (p.H / G::R) * halves; p.n_tiles = p.Cout / 64;
   p.rs_total = p.B * p.tiles_per_img * p.n_tiles;
   const int slots = rs_ncu() * halves;               // workgroups resident at once
   p.rs_per = idf_cdiv(p.rs_total, slots);
-  const int grid = idf_cdiv(p.rs_total, p.rs_per);
+  int grid = idf_cdiv(p.rs_total, p.rs_per);
+  if (EPI == 3) {
+    // lock-step rounds: every workgroup of a group (tiles_per_img items) in the same round, the whole grid resident
+    grid = p.rs_total < slots ? p.rs_total : slots;
+    // ... and a 64-channel slice must hold whole GroupNorm groups (Cout / 32 channels each: not at 192 channels)
+    if (grid % p.tiles_per_img || 64 % p.tiles_per_img || 64 % (p.Cout >> 5) || p.B * p.n_tiles > RS_SYNC_MAX) return 4;
+    if (hipGetSymbolAddress((void**)&p.rs_sync, HIP_SYMBOL(g_rs_sync)) != hipSuccess ||
+        hipGetSymbolAddress((void**)&p.rs_sync_err, HIP_SYMBOL(g_rs_sync_err)) != hipSuccess) return 5;
+  }
   size_t lds = (size_t)(CIN / 32) * G::CHB;
   const size_t osz = (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
   if (G::ALIAS_OS(CIN)) { p.rs_os_off = 0; if (osz > lds) lds = osz; }
   else { p.rs_os_off = (int)lds; lds += osz; }
   p.aux_off = (int)lds;
-  lds += (size_t)4 * NPH * 64 * 8;                // wave partials of the statistics
+  lds += (size_t)4 * NPH * 64 * 8 + (EPI == 3 ? 1024 : 0);   // wave partials of the statistics (EPI 3: + the fold's scratch)
   p.rs_cof_off = (int)lds;
   if (PRO) lds += (size_t)CIN * 16;
   if (lds > 160 * 1024 / halves) return 1;
   auto kern = conv_rs_bf16<W, CIN, PRO, EPI, NPH>;
   static IdfLdsGrant grant;
   if (idf_ensure_lds((const void*)kern, lds, grant) != hipSuccess) return 2;
+  if (EPI == 3) {
+    static const int resident = [&] {
+      int n = 0;
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256 * NPH, lds) == hipSuccess ? n : 0;
+    }();
+    if (resident < halves) return 6;                 // the spin needs the whole grid on the chip
+  }
+  if (probe) return 0;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * NPH), lds, st, p);
   return 0;
+}
+
+int dispatch_rs_sync(C3P& p, hipStream_t st, bool probe) {
+  if (g_rs != 1) return 3;
+  // 64x64 (two lock-step rounds at B = 32, groups of 32 workgroups): 50.6 us against 39.5 for conv + apply -- the wait in the middle
+  // re-aligns the two workgroups of a CU, whose drift is what lets one's MFMA loop run under the other's epilogue; the 32x32
+  // shapes (one round, groups of 8) win 3-6 us per launch (profiles/r05_conv_rs_sync.txt).  IDF_CONV_RS_SYNC=2 takes it anyway.
+  if (p.W == 64 && idf_knobs().conv_rs_sync < 2) return 7;
+  if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, false, 3, 1>(p, st, probe);
+  if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, false, 3, 1>(p, st, probe);
+  if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, false, 3, 1>(p, st, probe);
+  return 3;
 }
 
 template <bool PRO, int EPI>
@@ -587,4 +769,65 @@ extern "C" int idf_conv_rs_dgrad_chain_bf16(const void* dy, const void* w_frag, 
   if (int rc = dispatch_rs<false, 2>(p, (hipStream_t)stream)) IDF_FAIL(IDF_ERR_HIP, "conv_rs_dgrad_chain_bf16: launch refused (%d)", rc);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
+}
+
+// Tiles per image (= T of the partials workspace [B][T][Cout][2]) when the group-synchronised form covers the shape on this device
+// (the grid a whole number of groups, resident at once), else 0.
+extern "C" int idf_conv_rs_dgrad_gn_tiles(int B, int H, int W, int Cin, int Cout) {
+  const int T = rs_tiles(B, H, W, Cin, Cout);
+  if (!T || !idf_knobs().conv_rs_sync) return 0;
+  C3P p;
+  memset(&p, 0, sizeof(p));
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  return dispatch_rs_sync(p, nullptr, true) == 0 ? T : 0;
+}
+
+// The backward of conv3x3(dropout(act(FiLM(GroupNorm(x))))) w.r.t. x in ONE launch (modules.py:312-320, 283-288 backward):
+// idf_conv_rs_dgrad_chain_bf16 followed by idf_gn_bwd_apply, with du kept in registers across a counter the tiles of an image
+// meet at (conv_rs_bf16, EPI 3).  dy [B,H,W,Cin] = gradient of the conv's output; x (| x2, C1 channels in x) = the GroupNorm's
+// input, Cout channels; dres / dres2 = gradients arriving over the residual / skip branches (dense [B,H,W,Cout]) or null;
+// dx (| dx2) as x (| x2); part = workspace [B][T][Cout][2] floats (T = idf_conv_rs_dgrad_gn_tiles); the parameter / FiLM
+// gradient outputs as idf_gn_bwd_apply's (dfilm_t / dfilm_a [B][2 Cout], dgb [B][2][Cout] or dgam / dbet accumulated).
+extern "C" int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x, const void* x2, int C1, const float* sc,
+                                         const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, const void* dres,
+                                         const void* dres2, void* dx, void* dx2, float* part, const float* gamma, const float* beta,
+                                         const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
+                                         const float* rstd, float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet,
+                                         int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!idf_conv_rs_dgrad_gn_tiles(B, H, W, Cin, Cout))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_dgrad_gn_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
+  if (!dy || !w_frag || !x || !sc || !sh || !dx || !part || !mean || !rstd || (act != 1 && act != 2))
+    IDF_FAIL(IDF_ERR_BADARG, "conv_rs_dgrad_gn_bf16: null argument / act");
+  if (!x2) C1 = Cout;
+  if (x2 && (C1 <= 0 || C1 >= Cout || (C1 % 64) || !dx2)) IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_dgrad_gn_bf16: C1 %d of %d", C1, Cout);
+  C3P p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)dy; p.C1 = Cin; p.w = (const bf16_t*)w_frag; p.y = (bf16_t*)dx; p.rs_dx2 = (bf16_t*)dx2;
+  p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout;
+  p.due_x = (const bf16_t*)x; p.due_x2 = (const bf16_t*)x2; p.due_C1 = C1; p.due_sc = sc; p.due_sh = sh;
+  p.st_out = part; p.res = (const bf16_t*)dres; p.gnb_res2 = (const bf16_t*)dres2;
+  p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
+  p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
+  p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
+  GnFoldP& f = p.dyp_f;
+  f.mean = mean; f.rstd = rstd; f.sc = sc; f.gamma = gamma; f.beta = beta; f.film_t = film_t; f.film_a = film_a;
+  f.ld_t = ld_t ? ld_t : 2 * Cout; f.ld_a = ld_a ? ld_a : 2 * Cout;
+  f.dfilm_t = dfilm_t; f.dfilm_a = dfilm_a; f.dgb = dgb; f.dgam = dgam; f.dbet = dbet; f.C = Cout; f.HW = H * W;
+  if (int rc = dispatch_rs_sync(p, (hipStream_t)stream, false)) IDF_FAIL(IDF_ERR_HIP, "conv_rs_dgrad_gn_bf16: launch refused (%d)", rc);
+  IDF_CHECK_LAUNCH();
+  return IDF_OK;
+}
+
+// Workgroups of the synchronised form that gave up waiting for their group since the last call with reset != 0 (a device-to-host
+// read: synchronises).  Anything but 0 means a launch's grid was not resident at once -- its results are garbage.
+extern "C" int idf_conv_rs_sync_timeouts(int reset) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rs_sync_err), sizeof(v)) != hipSuccess) return -1;
+  if (reset && v) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_sync_err), &z, sizeof(z)) != hipSuccess) return -1;
+    static unsigned zeros[RS_SYNC_MAX];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_sync), zeros, sizeof(zeros)) != hipSuccess) return -1;
+  }
+  return (int)v;
 }

@@ -662,6 +662,68 @@ def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=No
     return out, part, dy_mat
 
 
+_RS_SYNC = [True]     # the trainer turns the form off around launches that share the chip with a collective (sync_convs)
+
+
+class sync_convs:
+    """with ops.sync_convs(False): the data-gradient convs issued inside do not take the group-synchronised form
+    (idf_conv_rs_dgrad_gn_bf16): its workgroups wait for each other inside the launch and need the whole grid on the chip at
+    once -- true when nothing else runs, not beside an RCCL kernel that holds CUs for the length of an all-reduce."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _RS_SYNC[0]
+        _RS_SYNC[0] = self.on
+
+    def __exit__(self, *exc):
+        _RS_SYNC[0] = self.prev
+        return False
+
+
+def rs_sync_timeouts(reset=True):
+    """Workgroups of the synchronised form that gave up waiting for their group (0 in a healthy process)."""
+    return int(_lib.load().idf_conv_rs_sync_timeouts(1 if reset else 0))
+
+
+def conv_dgrad_gn_sync_raw(dy, Cout, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None,
+                           dres=None, dres2=None, x2=None, shadows=None):
+    """The backward of conv3x3(dropout(act(FiLM(GroupNorm(x | x2))))) w.r.t. its input in one launch on the 64x64 / 32x32 maps
+    (conv_dgrad_chain_raw + gn_bwd_apply_raw, du never written) -> what gn_bwd_apply_raw returns, or None when the form does
+    not cover the call."""
+    B, Cin, H, W = dy.shape
+    if not (_RS_SYNC[0] and act and dy.dtype == torch.bfloat16 and shadows is not None):
+        return None
+    C1 = x.shape[1] if x2 is not None else 0
+    if x2 is not None and C1 % 64:
+        return None
+    T = int(_lib.load().idf_conv_rs_dgrad_gn_tiles(B, H, W, Cin, Cout))
+    if not T:
+        return None
+    rfrag = _rs_frag(shadows, 3, B, H, W, Cin, Cout)
+    if rfrag is None:
+        return None
+    dev = x.device
+    part = torch.empty((B, T, Cout, 2), dtype=torch.float32, device=dev)
+    dx = torch.empty_like(x, memory_format=CL)
+    dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
+    dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
+    dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
+    acc = _gn_acc(acc)
+    dgb = torch.empty((B, 2 * Cout), dtype=torch.float32, device=dev) if acc is None else None
+    call('idf_conv_rs_dgrad_gn_bf16', _p(dy), _p(rfrag), _p(x), _p(x2), C1, _p(sc), _p(sh), _p(seed), salt, float(p_drop), act,
+         _p(dres), _p(dres2), _p(dx), _p(dx2), _p(part), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
+         _p(mean), _p(rstd), _p(dft), _p(dfa), _p(dgb), _p(acc[0]) if acc else None, _p(acc[1]) if acc else None,
+         B, H, W, Cin, Cout, _st())
+    if x2 is not None:
+        dx = (dx, dx2)
+    if acc:
+        return dx, acc[0], acc[1], dft, dfa
+    dgam = colsum_raw(dgb)
+    return dx, dgam[:Cout], dgam[Cout:], dft, dfa
+
+
 def gn_bwd_apply_raw(du, part, x, gamma, beta, film_t, film_a, mean, rstd, sc, acc=None, dres=None, dres2=None, x2=None):
     """dx (+ parameter / FiLM gradients) from the (du, part) pair a du-epilogue conv left behind: what gn_fused_bwd_raw
     returns, by a streaming pass (no reduction left in it)."""
@@ -1072,7 +1134,13 @@ class _FusedConv(torch.autograd.Function):
                 # big maps: the conv's epilogue emits du and the per-tile sums; what is left of the GroupNorm backward
                 # is a streaming pass -- or nothing, when the conv in front of this GroupNorm takes the pair
                 want_dy = lazy_in is not None and (need[1] or want_b or (ctx.has_res and need[7]))
-                if act:
+                got = None
+                if act and lazy_in is None and taps == 9 and not ctx.lazy_out:
+                    got = conv_dgrad_gn_sync_raw(dy, x.shape[1], x, gn_w, gn_b, film_t, film_a, mean, rstd, sc, sh, seed, salt,
+                                                 p_drop, act, gslots, dres_in, dres2_in, shadows=cfg['shadows'])
+                if got is not None:
+                    dx, dgw, dgb, dft, dfa = got
+                elif act:
                     du, part, dy_mat = conv_dgrad_chain_raw(dy, w_dgrad, taps, x.shape[1], lazy_in, want_dy, x=x, sc=sc, sh=sh,
                                                             seed=seed, salt=salt, p_drop=p_drop, act=act, shadows=cfg['shadows'])
                     gacc = _gn_acc(gslots) if (ctx.lazy_out and dres_in is None) else None
@@ -1282,16 +1350,24 @@ class _BlockEntryCat(torch.autograd.Function):
         dxs = None if ride else conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
         if ctx.chain_ok:
             # the conv's epilogue emits du and the per-tile sums over the two-source input; dx1 / dx2 by a streaming pass
+            got = None
             if ride:
                 du, part, dxs = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'],
                                                      shortcut=(ds, w_sc_dgrad))
             else:
-                du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc,
-                                                        sh=sh, act=cfg['act'], shadows=cfg['shadows'])
-                if lazy_in is not None:
-                    dh = dh_mat
-            (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, (gws, gbs),
-                                                           dres=dxs, x2=x2)
+                if lazy_in is None:
+                    got = conv_dgrad_gn_sync_raw(dh, C, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None, cfg['salt'], 0.0,
+                                                 cfg['act'], (gws, gbs), dxs, None, x2=x2, shadows=cfg['shadows'])
+                if got is None:
+                    du, part, dh_mat = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, lazy_in, lazy_in is not None, x=x1, x2=x2, sc=sc,
+                                                            sh=sh, act=cfg['act'], shadows=cfg['shadows'])
+                    if lazy_in is not None:
+                        dh = dh_mat
+            if got is not None:
+                (dx1, dx2), dgw, dgb, _, _ = got
+            else:
+                (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, (gws, gbs),
+                                                               dres=dxs, x2=x2)
         else:
             dA = conv_dgrad_raw(dh, w_dgrad, S1, 9, a.shape)
             (dx1, dx2), dgw, dgb, _, _ = gn_fused_bwd_raw(dA, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None,
@@ -1587,6 +1663,11 @@ def _entry_cat_bwd(x1, x2, dh, ds, gn_w, gn_b, mean, rstd, sc, sh, cfg, cfg_sc, 
                                                  shortcut=(ds, w_sc_dgrad))
         else:
             dxs = conv_dgrad_raw(ds, w_sc_dgrad, S1, 1, (B, C, H, W))
+            got = conv_dgrad_gn_sync_raw(dh, C, x1, gn_w, gn_b, None, None, mean, rstd, sc, sh, None, cfg['salt'], 0.0, cfg['act'],
+                                         gslots, dxs, None, x2=x2, shadows=cfg['shadows'])
+            if got is not None:
+                (dx1, dx2), dgw, dgb, _, _ = got
+                return dx1, dx2, dgw, dgb, dsW, dsb
             du, part, _ = conv_dgrad_chain_raw(dh, w_dgrad, 9, C, x=x1, x2=x2, sc=sc, sh=sh, act=cfg['act'], shadows=cfg['shadows'])
         (dx1, dx2), dgw, dgb, _, _ = gn_bwd_apply_raw(du, part, x1, gn_w, gn_b, None, None, mean, rstd, sc, gslots, dres=dxs,
                                                        x2=x2)

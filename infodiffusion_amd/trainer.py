@@ -65,14 +65,20 @@ class GraphedTrainStep:
         loss.backward()
         return loss.detach(), cut
 
-    @staticmethod
-    def _phase_b(cut):
-        """the encoder's backward pass from the gradient that arrived at the latent leaf."""
+    def _phase_b(self, cut):
+        """the encoder's backward pass from the gradient that arrived at the latent leaf.  With peers it runs beside the
+        backbone slice's all-reduce: its data-gradient convs then keep to forms whose workgroups do not wait for each other
+        inside a launch (ops.sync_convs) -- an RCCL kernel holding CUs would stall every such wait until the collective ends."""
         if cut is not None:
             lat, leaf = cut
             if leaf.grad is not None:
-                lat.backward(leaf.grad)
+                with ops.sync_convs(not self._shares_chip()):
+                    lat.backward(leaf.grad)
                 leaf.grad = None
+
+    def _shares_chip(self):
+        return (self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1)
 
     def _opt_step(self):
         if self.pre_step is not None:

@@ -684,7 +684,7 @@ def test_conv_rs_groupnorm_prologue_conv_vs_pytorch(case, monkeypatch):
     # (B, channels of dy, C1, C2 of x | x2, H, act, film, p_drop, n_res)
     (32, 64, 64, 0, 64, 2, True, 0.1, 1), (9, 64, 64, 0, 64, 2, False, 0.0, 0), (33, 64, 128, 64, 64, 2, False, 0.0, 1),
     (32, 128, 128, 0, 32, 2, True, 0.1, 2), (40, 128, 128, 128, 32, 2, False, 0.0, 1), (64, 64, 128, 0, 32, 2, True, 0.1, 0),
-    (64, 128, 64, 0, 32, 1, False, 0.0, 0),
+    (64, 128, 64, 0, 32, 1, False, 0.0, 0), (32, 64, 64, 64, 64, 2, False, 0.0, 1),
 ])
 def test_conv_rs_backward_chain_du_epilogue_vs_pytorch_autograd(case):
     """idf_conv_rs_dgrad_chain_bf16 (round 5: the data-gradient conv of the 64x64 / 32x32 maps in the register-weights form with
@@ -735,6 +735,38 @@ def test_conv_rs_backward_chain_du_epilogue_vs_pytorch_autograd(case):
             parts = [(g, r)] if g.dim() != 2 else [(g[:, :C], r[:, :C]), (g[:, C:], r[:, C:])]
             for gg, rr in parts:
                 assert rel(gg, rr) < 4e-2, (nm, rel(gg, rr))
+    # ---- the same backward in ONE launch (idf_conv_rs_dgrad_gn_bf16: du held on chip, the image's workgroups meet at a counter):
+    # against the two launches above (same du rounding; the sums differ only in their order) and against fp32 autograd; every
+    # repetition bit-identical (a stale read of another workgroup's partials would show here) and nobody gave up waiting
+    ops.rs_sync_timeouts(True)
+    names = []
+    ops.call = lambda n, *a: (names.append(n), orig(n, *a))[1]
+    try:
+        one = ops.conv_dgrad_gn_sync_raw(dy, C, x1, gam, bet, ft, fa, mean, rstd, sc, sh, seed, 5, p_drop, act, None, dres, dres2, x2=x2,
+                                         shadows=sh_)
+    finally:
+        ops.call = orig
+    if 64 % (C // 32):            # a 64-channel slice must hold whole GroupNorm groups: 192 channels stay on the two launches
+        assert one is None
+        return
+    assert one is not None and 'idf_conv_rs_dgrad_gn_bf16' in names, names
+    dx1 = torch.cat(one[0], dim=1) if C2 else one[0]
+    assert rel(dx1, dx) < 1e-2, rel(dx1, dx)          # bf16 outputs: one ulp of the largest element is 2^-7
+    for nm, g, g0, r in zip(('dx', 'dgamma', 'dbeta', 'dfilm_t', 'dfilm_a'), (dx1,) + tuple(one[1:]), (dx,) + tuple(out[1:]), want):
+        assert (g is None) == (r is None), nm
+        if g is not None:
+            parts = [(g, g0, r)] if g.dim() != 2 else [(g[:, :C], g0[:, :C], r[:, :C]), (g[:, C:], g0[:, C:], r[:, C:])]
+            for gg, g00, rr in parts:
+                assert rel(gg, rr) < 4e-2, (nm, rel(gg, rr))
+                assert rel(gg, g00) < (1e-2 if nm == 'dx' else 2e-3), (nm, rel(gg, g00))
+    for _ in range(12):
+        again = ops.conv_dgrad_gn_sync_raw(dy, C, x1, gam, bet, ft, fa, mean, rstd, sc, sh, seed, 5, p_drop, act, None, dres, dres2, x2=x2,
+                                           shadows=sh_)
+        dxa = torch.cat(again[0], dim=1) if C2 else again[0]
+        assert torch.equal(dxa, dx1)
+        for g, g0 in zip(again[1:], one[1:]):
+            assert (g is None and g0 is None) or torch.equal(g, g0)
+    assert ops.rs_sync_timeouts(True) == 0
 
 
 @pytest.mark.parametrize('case', [

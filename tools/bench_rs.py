@@ -81,6 +81,26 @@ def main():
         gf = 2.0 * B * H * H * C * 9 * Cin / 1e9
         print('dgrad, du epilogue    B %3d %3d->%3d @%2d  halo        %6.1f us   rs %6.1f us  (%.0f -> %.0f TF/s)' % (
             B, Cin, C, H, t0, t1, gf / t0 * 1e3, gf / t1 * 1e3), flush=True)
+        # the whole GroupNorm-stage backward: du-epilogue conv + streaming apply (two launches) against the group-synchronised launch
+        gam, bet = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        ft, fa = 0.1 * torch.randn(B, 2 * C, device=DEV), 0.1 * torch.randn(B, 2 * C, device=DEV)
+        mean, rstd = torch.zeros(B, 32, device=DEV), torch.ones(B, 32, device=DEV)
+        for nres in (0, 1):
+            res = [torch.randn(B, C, H, H, device=DEV).bfloat16().contiguous(memory_format=CL) for _ in range(n)] if nres else [None] * n
+
+            def two(s, r):
+                du, part, _ = bwd(s, sh)
+                return ops.gn_bwd_apply_raw(du, part, s[0], gam, bet, ft, fa, mean, rstd, s[2], dres=r)
+
+            def one(s, r):
+                return ops.conv_dgrad_gn_sync_raw(s[1], C, s[0], gam, bet, ft, fa, mean, rstd, s[2], s[3], seed, 3, 0.1, 2, None, r, None,
+                                                  shadows=sh)
+            if one(sets[0], res[0]) is None:
+                continue
+            t2 = timeit([(lambda s=s, r=r: two(s, r)) for s, r in zip(sets, res)])
+            t3 = timeit([(lambda s=s, r=r: one(s, r)) for s, r in zip(sets, res)])
+            print('   GroupNorm-stage backward (dres %d)   conv + apply %6.1f us   one synchronised launch %6.1f us' % (nres, t2, t3), flush=True)
+        assert ops.rs_sync_timeouts() == 0
 
 
 if __name__ == '__main__':

@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   constexpr int NEV = HR * 2 * PIECES, NE = (NEV + NT - 1) / NT;                      // the two halo columns: vectors, rounds
   constexpr int TWP = NPH == 2 ? 0 : TWS;                                             // the tails' pixel map: whole rows / half-width tiles
   constexpr bool DUE = EPI == 2 || EPI == 3, SYN = EPI == 3;
+  // 64x64: a workgroup owns TWO vertically adjacent tiles (B = 32: 1024 half-width tiles on 512 resident workgroups) and waits ONCE,
+  // behind the second: the first tile's du waits in LDS (packed, 16 KB), its x is read again at the apply.  (Lock-step rounds with a
+  // wait per round measured 50.6 us against 39.5 for conv + apply: the wait in the middle re-aligns the two workgroups of a CU, whose
+  // drift is what lets one's MFMA loop run under the other's epilogue.)
+  constexpr bool PAIR = SYN && W == 64, LOCK = SYN && !PAIR;
   static_assert(!SYN || NPH == 1, "the synchronised form is built for two workgroups per CU");
   // two workgroups per CU have 80 KB of LDS each: where the chunk images and the fp32 epilogue tile do not fit side by side the
   // tile takes the images' place (the next tile's rows then wait in registers until the epilogue has read it)
@@ -122,9 +127,11 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int cg = wave & 3, ph = wave >> 2;            // cout group of 16, pixel half (NPH = 1: always 0)
   const int wgid = xcd_tile_id(blockIdx.x, gridDim.x);
-  const int istep = SYN ? (int)gridDim.x : 1;         // SYN: lock-step rounds over the grid; else rs_per consecutive items
-  int item = SYN ? wgid : wgid * p.rs_per;
-  const int item_end = SYN ? p.rs_total : min(item + p.rs_per, p.rs_total);
+  const int istep = LOCK ? (int)gridDim.x : 1;        // LOCK: lock-step rounds over the grid; else rs_per consecutive items
+  int item = LOCK ? wgid : wgid * p.rs_per;
+  const int item_end = LOCK ? p.rs_total : min(item + p.rs_per, p.rs_total);
+  int prev_oy0 = -1;                                  // PAIR: the tile whose du waits in the stash
+  bool prev_writer = false;
   if (item >= item_end) return;
   bool first_item = true;
   const int TR = p.H / R, halves = p.rs_halves;      // row strips per image; tiles per strip (1 or 2)
@@ -356,6 +363,166 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   RS_STAMP(ts4);
   RS_ADD(3, ts3, ts4);
 
+  // ---- the group-synchronised GroupNorm backward (EPI 3) behind a tile's tail: publish (wave 0 stored the partials), meet the
+  // other tiles of (image b, channels n0 .. n0 + 63), fold, apply.  LOCK: per tile, inside the loop; PAIR: once, behind the loop
+  constexpr int DNI = BM * (BN / 8) / NT;
+  uint4 due_xr[DUE ? DNI : 1];
+  float dscv[8], dshv[8];
+  uint64_t dseed = 0;
+  uint4* const stash = reinterpret_cast<uint4*>(smem + p.rs_stash_off);      // PAIR: [DNI][NT] vectors, thread-private slots
+  auto sync_apply = [&](const bool have_prev) __attribute__((always_inline)) {
+    if constexpr (SYN) {
+      uint4 drr[DNI];                                     // the residual-branch gradient of this thread's vectors
+      float gpar[7];                                      // this channel's fold parameters (threads < 64)
+      // what the apply reads besides du and x: issued behind the tail (its arithmetic needs every register), in front of the wait
+      auto fetch_apply_operands = [&]() __attribute__((always_inline)) {
+        const int cc = (tid & 7) * 8;
+#pragma unroll
+        for (int k = 0; k < DNI; ++k) {
+          drr[k] = make_uint4(0, 0, 0, 0);
+          if (p.res) drr[k] = *reinterpret_cast<const uint4*>(p.res + (unsigned)(tile_pix<TWP>(pe, b, oy0, (tid + k * NT) >> 3) * p.Cout + n0 + cc));
+        }
+        if (tid < 64) {
+          const GnFoldP& f = p.dyp_f;
+          const int c = n0 + tid, g = c / (p.Cout >> 5);
+          gpar[0] = f.mean[b * 32 + g]; gpar[1] = f.rstd[b * 32 + g];
+          gpar[2] = f.gamma ? f.gamma[c] : 1.f; gpar[3] = f.beta ? f.beta[c] : 0.f;
+          gpar[4] = gpar[5] = gpar[6] = 0.f;
+          if (f.film_t) { gpar[4] = f.film_t[(size_t)b * f.ld_t + c]; gpar[5] = f.film_t[(size_t)b * f.ld_t + p.Cout + c]; }
+          if (f.film_a) gpar[6] = f.film_a[(size_t)b * f.ld_a + c];
+        }
+      };
+      uint4 pxr[PAIR ? DNI : 1], pdr[PAIR ? DNI : 1];          // PAIR: x and the residual gradient of the stashed tile
+      auto fetch_prev_operands = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIR) {
+          if (have_prev) {
+            due_fetch_x<BM, BN, NT, TWP>(pe, pxr, b, prev_oy0, n0, BM, tid);
+            const int cc = (tid & 7) * 8;
+#pragma unroll
+            for (int k = 0; k < DNI; ++k) {
+              pdr[k] = make_uint4(0, 0, 0, 0);
+              if (p.res) pdr[k] = *reinterpret_cast<const uint4*>(p.res + (unsigned)(tile_pix<TWP>(pe, b, prev_oy0, (tid + k * NT) >> 3) * p.Cout + n0 + cc));
+            }
+          }
+        }
+      };
+      // ---- publish (wave 0 stored the partials), meet the other tiles of (image b, channels n0 .. n0 + 63)
+      const GnFoldP& f = p.dyp_f;
+      const int C = p.Cout, T = p.tiles_per_img;
+      if (wave == 0) {
+        auto* cnt = reinterpret_cast<__attribute__((address_space(1))) unsigned*>(reinterpret_cast<uintptr_t>(p.rs_sync + b * p.n_tiles + nt));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt, (unsigned)(64 / T) * (have_prev ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fetch_apply_operands();
+        fetch_prev_operands();
+        const unsigned target = ((unsigned)__builtin_amdgcn_readfirstlane((int)old) & ~63u) + 64u;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21)) { if (lane == 0) atomicOr(p.rs_sync_err, 1u); break; }
+        }
+      } else { fetch_apply_operands(); fetch_prev_operands(); }
+      lds_barrier();
+      // ---- fold: S1, S2 of this channel over the group's T tiles (thread = channel x tile quarter; fixed order), then the
+      // per-channel / per-group arithmetic of gn_bwd_fold (idf_gnfold.h)
+      float* red = reinterpret_cast<float*>(smem + p.aux_off);        // [4][64][2] | pc [64][2] | kk [64][2] (du stays in the fp32 tile's place)
+      float* pc = red + 512;
+      float* kk = pc + 128;
+      {
+        const int c = tid & 63, tq = tid >> 6;
+        auto* src = reinterpret_cast<__attribute__((address_space(1))) const unsigned*>(
+            reinterpret_cast<uintptr_t>(p.st_out + (((size_t)b * T) * C + n0 + c) * 2));
+        unsigned vs[8], vq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = min(tq + 4 * i, T - 1);
+          vs[i] = __hip_atomic_load(src + (size_t)t * C * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          vq[i] = __hip_atomic_load(src + (size_t)t * C * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = tq + 4 * i < T;
+          s_ += in ? __uint_as_float(vs[i]) : 0.f; q_ += in ? __uint_as_float(vq[i]) : 0.f;
+        }
+        red[(tq * 64 + c) * 2] = s_; red[(tq * 64 + c) * 2 + 1] = q_;
+      }
+      lds_barrier();
+      const int cpg = C >> 5;
+      if (tid < 64) {
+        const int cl = tid, c = n0 + cl;
+        const float S1 = (red[cl * 2] + red[(64 + cl) * 2]) + (red[(128 + cl) * 2] + red[(192 + cl) * 2]);
+        const float S2 = (red[cl * 2 + 1] + red[(64 + cl) * 2 + 1]) + (red[(128 + cl) * 2 + 1] + red[(192 + cl) * 2 + 1]);
+        const float mu = gpar[0], r = gpar[1], ga = gpar[2], be = gpar[3], st = gpar[4], bt = gpar[5], sa = gpar[6];
+        const float D1 = S1, D2 = r * (S2 - mu * S1);
+        const float fm = (1.f + st) * (1.f + sa);
+        if (pe.rs_tidx == 0 || prev_writer) {             // one workgroup per group stores the parameter / FiLM gradients
+          const float Gf = ga * D2 + be * D1, Ge = D1;
+          if (f.dfilm_t) { f.dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); f.dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
+          if (f.dfilm_a) { f.dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; f.dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
+          if (f.dgb) { f.dgb[((size_t)b * 2 + 0) * C + c] = fm * D2; f.dgb[((size_t)b * 2 + 1) * C + c] = fm * D1; }
+          if (f.dgam) atomicAdd(f.dgam + c, fm * D2);
+          if (f.dbet) atomicAdd(f.dbet + c, fm * D1);
+        }
+        pc[2 * cl] = ga * fm * D1; pc[2 * cl + 1] = ga * fm * D2;
+      }
+      lds_barrier();
+      if (tid < 64) {
+        const int cl = tid, gl = cl / cpg;
+        float P1 = 0.f, P2 = 0.f;
+        for (int k = gl * cpg; k < (gl + 1) * cpg; ++k) { P1 += pc[2 * k]; P2 += pc[2 * k + 1]; }
+        const float mu = gpar[0], r = gpar[1], invN = 1.f / ((float)f.HW * cpg);
+        kk[2 * cl] = -r * r * P2 * invN;
+        kk[2 * cl + 1] = (-r * P1 + r * r * mu * P2) * invN;
+      }
+      lds_barrier();
+      // ---- dx = A du + K1 x + K0 (+ dres + dres2): gn_bwd_apply_loop's arithmetic on registers
+      {
+        const int cc = (tid & 7) * 8;
+        float k1v[8], k0v[8];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(kk + 2 * cc + 4 * q4);
+          k1v[2 * q4] = t4.x; k0v[2 * q4] = t4.y; k1v[2 * q4 + 1] = t4.z; k0v[2 * q4 + 1] = t4.w;
+        }
+        bf16_t* dst = p.y;
+        int opitch = C, oc = n0 + cc;
+        if (p.due_x2) {
+          if (n0 < p.due_C1) opitch = p.due_C1;
+          else { dst = p.rs_dx2; opitch = C - p.due_C1; oc -= p.due_C1; }
+        }
+        auto apply_tile = [&](int oy, const uint4 (&xs)[DNI], const uint4 (&rs)[DNI], bool stashed) __attribute__((always_inline)) {
+#pragma unroll
+          for (int k = 0; k < DNI; ++k) {
+            const int pl = (tid + k * NT) >> 3, pix = tile_pix<TWP>(pe, b, oy, pl);
+            float o[8];
+            const uint4 duk = stashed ? stash[k * NT + tid] : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + pl * (BN + 4) + cc);
+            const uint32_t xw[4] = {xs[k].x, xs[k].y, xs[k].z, xs[k].w}, dw[4] = {duk.x, duk.y, duk.z, duk.w};
+            const uint32_t rw[4] = {rs[k].x, rs[k].y, rs[k].z, rs[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x0 = __uint_as_float(xw[i] << 16), x1 = __uint_as_float(xw[i] & 0xffff0000u);
+              const float d0 = __uint_as_float(dw[i] << 16), d1 = __uint_as_float(dw[i] & 0xffff0000u);
+              o[2 * i] = dscv[2 * i] * d0 + k1v[2 * i] * x0 + k0v[2 * i] + __uint_as_float(rw[i] << 16);
+              o[2 * i + 1] = dscv[2 * i + 1] * d1 + k1v[2 * i + 1] * x1 + k0v[2 * i + 1] + __uint_as_float(rw[i] & 0xffff0000u);
+            }
+            if (p.gnb_res2) {
+              const uint4 r2 = *reinterpret_cast<const uint4*>(p.gnb_res2 + (unsigned)(pix * C + n0 + cc));
+              const uint32_t r2w[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { o[2 * i] += __uint_as_float(r2w[i] << 16); o[2 * i + 1] += __uint_as_float(r2w[i] & 0xffff0000u); }
+            }
+            *reinterpret_cast<uint4*>(dst + (unsigned)(pix * opitch + oc)) =
+                make_uint4(idf_pack_bf16(o[0], o[1]), idf_pack_bf16(o[2], o[3]), idf_pack_bf16(o[4], o[5]), idf_pack_bf16(o[6], o[7]));
+          }
+        };
+        apply_tile(oy0, due_xr, drr, false);
+        if constexpr (PAIR) { if (have_prev) apply_tile(prev_oy0, pxr, pdr, true); }
+      }
+    }
+  };
+
   for (;;) {
     RS_STAMP(tt0);
     const bool has_next = item + istep < item_end;
@@ -363,12 +530,6 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     if (has_next) decode(item + istep, nnt, nb, nhalf, noy0, nn0);
     pe.rs_x0 = half * TW; pe.rs_tidx = (oy0 / R) * halves + half;
     // ---- what the epilogue reads from memory, then the next tile's rows (vmcnt is in order: the epilogue's operands first)
-    uint4 due_xr[DUE ? BM * (BN / 8) / NT : 1];
-    float dscv[8], dshv[8];
-    uint64_t dseed = 0;
-    constexpr int DNI = BM * (BN / 8) / NT;
-    uint4 drr[SYN ? DNI : 1];                             // SYN: the residual-branch gradient of this thread's vectors
-    float gpar[7];                                        // SYN: this channel's fold parameters (threads < 64)
     if constexpr (DUE) {
       due_fetch_x<BM, BN, NT, TWP>(pe, due_xr, b, oy0, n0, BM, tid);
       due_fetch_coef<BN>(p, b, n0, tid, dscv, dshv, dseed);
@@ -451,132 +612,15 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     RS_STAMP(tt5);
     RS_ADD(8, tt4, tt5);
     if constexpr (SYN) {
-      // what the apply reads besides du and x: issued behind the tail (its arithmetic needs every register), in front of the wait
-      auto fetch_apply_operands = [&]() __attribute__((always_inline)) {
-        const int cc = (tid & 7) * 8;
-#pragma unroll
-        for (int k = 0; k < DNI; ++k) {
-          drr[k] = make_uint4(0, 0, 0, 0);
-          if (p.res) drr[k] = *reinterpret_cast<const uint4*>(p.res + (unsigned)(tile_pix<TWP>(pe, b, oy0, (tid + k * NT) >> 3) * p.Cout + n0 + cc));
-        }
-        if (tid < 64) {
-          const GnFoldP& f = p.dyp_f;
-          const int c = n0 + tid, g = c / (p.Cout >> 5);
-          gpar[0] = f.mean[b * 32 + g]; gpar[1] = f.rstd[b * 32 + g];
-          gpar[2] = f.gamma ? f.gamma[c] : 1.f; gpar[3] = f.beta ? f.beta[c] : 0.f;
-          gpar[4] = gpar[5] = gpar[6] = 0.f;
-          if (f.film_t) { gpar[4] = f.film_t[(size_t)b * f.ld_t + c]; gpar[5] = f.film_t[(size_t)b * f.ld_t + p.Cout + c]; }
-          if (f.film_a) gpar[6] = f.film_a[(size_t)b * f.ld_a + c];
-        }
-      };
       due_epilogue_tail<BM, BN, NT, true, TWP, true>(pe, Os, b, oy0, n0, BM, tid, due_xr, dscv, dshv, dseed);
-      // ---- publish (wave 0 stored the partials), meet the other tiles of (image b, channels n0 .. n0 + 63)
-      const GnFoldP& f = p.dyp_f;
-      const int C = p.Cout, T = p.tiles_per_img;
-      if (wave == 0) {
-        auto* cnt = reinterpret_cast<__attribute__((address_space(1))) unsigned*>(reinterpret_cast<uintptr_t>(p.rs_sync + b * p.n_tiles + nt));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(cnt, (unsigned)(64 / T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fetch_apply_operands();
-        const unsigned target = ((unsigned)__builtin_amdgcn_readfirstlane((int)old) & ~63u) + 64u;
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21)) { if (lane == 0) atomicOr(p.rs_sync_err, 1u); break; }
-        }
-      } else fetch_apply_operands();
-      lds_barrier();
-      // ---- fold: S1, S2 of this channel over the group's T tiles (thread = channel x tile quarter; fixed order), then the
-      // per-channel / per-group arithmetic of gn_bwd_fold (idf_gnfold.h)
-      float* red = reinterpret_cast<float*>(smem + p.aux_off);        // [4][64][2] | pc [64][2] | kk [64][2] (du stays in the fp32 tile's place)
-      float* pc = red + 512;
-      float* kk = pc + 128;
-      {
-        const int c = tid & 63, tq = tid >> 6;
-        auto* src = reinterpret_cast<__attribute__((address_space(1))) const unsigned*>(
-            reinterpret_cast<uintptr_t>(p.st_out + (((size_t)b * T) * C + n0 + c) * 2));
-        unsigned vs[8], vq[8];
+      if constexpr (LOCK) sync_apply(false);
+      if constexpr (PAIR) {
+        if (has_next) {
+          // first tile of the pair: its partials are stored (published with the second tile's), its du moves out of the fp32 tile
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int t = min(tq + 4 * i, T - 1);
-          vs[i] = __hip_atomic_load(src + (size_t)t * C * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          vq[i] = __hip_atomic_load(src + (size_t)t * C * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool in = tq + 4 * i < T;
-          s_ += in ? __uint_as_float(vs[i]) : 0.f; q_ += in ? __uint_as_float(vq[i]) : 0.f;
-        }
-        red[(tq * 64 + c) * 2] = s_; red[(tq * 64 + c) * 2 + 1] = q_;
-      }
-      lds_barrier();
-      const int cpg = C >> 5;
-      if (tid < 64) {
-        const int cl = tid, c = n0 + cl;
-        const float S1 = (red[cl * 2] + red[(64 + cl) * 2]) + (red[(128 + cl) * 2] + red[(192 + cl) * 2]);
-        const float S2 = (red[cl * 2 + 1] + red[(64 + cl) * 2 + 1]) + (red[(128 + cl) * 2 + 1] + red[(192 + cl) * 2 + 1]);
-        const float mu = gpar[0], r = gpar[1], ga = gpar[2], be = gpar[3], st = gpar[4], bt = gpar[5], sa = gpar[6];
-        const float D1 = S1, D2 = r * (S2 - mu * S1);
-        const float fm = (1.f + st) * (1.f + sa);
-        if (pe.rs_tidx == 0) {                            // one workgroup per group stores the parameter / FiLM gradients
-          const float Gf = ga * D2 + be * D1, Ge = D1;
-          if (f.dfilm_t) { f.dfilm_t[(size_t)b * 2 * C + c] = Gf * (1.f + sa); f.dfilm_t[(size_t)b * 2 * C + C + c] = Ge * (1.f + sa); }
-          if (f.dfilm_a) { f.dfilm_a[(size_t)b * 2 * C + c] = Gf * (1.f + st) + Ge * bt; f.dfilm_a[(size_t)b * 2 * C + C + c] = Ge; }
-          if (f.dgb) { f.dgb[((size_t)b * 2 + 0) * C + c] = fm * D2; f.dgb[((size_t)b * 2 + 1) * C + c] = fm * D1; }
-          if (f.dgam) atomicAdd(f.dgam + c, fm * D2);
-          if (f.dbet) atomicAdd(f.dbet + c, fm * D1);
-        }
-        pc[2 * cl] = ga * fm * D1; pc[2 * cl + 1] = ga * fm * D2;
-      }
-      lds_barrier();
-      if (tid < 64) {
-        const int cl = tid, gl = cl / cpg;
-        float P1 = 0.f, P2 = 0.f;
-        for (int k = gl * cpg; k < (gl + 1) * cpg; ++k) { P1 += pc[2 * k]; P2 += pc[2 * k + 1]; }
-        const float mu = gpar[0], r = gpar[1], invN = 1.f / ((float)f.HW * cpg);
-        kk[2 * cl] = -r * r * P2 * invN;
-        kk[2 * cl + 1] = (-r * P1 + r * r * mu * P2) * invN;
-      }
-      lds_barrier();
-      // ---- dx = A du + K1 x + K0 (+ dres + dres2): gn_bwd_apply_loop's arithmetic on registers
-      {
-        const int cc = (tid & 7) * 8;
-        float k1v[8], k0v[8];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(kk + 2 * cc + 4 * q4);
-          k1v[2 * q4] = t4.x; k0v[2 * q4] = t4.y; k1v[2 * q4 + 1] = t4.z; k0v[2 * q4 + 1] = t4.w;
-        }
-        bf16_t* dst = p.y;
-        int opitch = C, oc = n0 + cc;
-        if (p.due_x2) {
-          if (n0 < p.due_C1) opitch = p.due_C1;
-          else { dst = p.rs_dx2; opitch = C - p.due_C1; oc -= p.due_C1; }
-        }
-#pragma unroll
-        for (int k = 0; k < DNI; ++k) {
-          const int pl = (tid + k * NT) >> 3, pix = tile_pix<TWP>(pe, b, oy0, pl);
-          float o[8];
-          const uint4 duk = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + pl * (BN + 4) + cc);
-          const uint32_t xw[4] = {due_xr[k].x, due_xr[k].y, due_xr[k].z, due_xr[k].w}, dw[4] = {duk.x, duk.y, duk.z, duk.w};
-          const uint32_t rw[4] = {drr[k].x, drr[k].y, drr[k].z, drr[k].w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float x0 = __uint_as_float(xw[i] << 16), x1 = __uint_as_float(xw[i] & 0xffff0000u);
-            const float d0 = __uint_as_float(dw[i] << 16), d1 = __uint_as_float(dw[i] & 0xffff0000u);
-            o[2 * i] = dscv[2 * i] * d0 + k1v[2 * i] * x0 + k0v[2 * i] + __uint_as_float(rw[i] << 16);
-            o[2 * i + 1] = dscv[2 * i + 1] * d1 + k1v[2 * i + 1] * x1 + k0v[2 * i + 1] + __uint_as_float(rw[i] & 0xffff0000u);
-          }
-          if (p.gnb_res2) {
-            const uint4 r2 = *reinterpret_cast<const uint4*>(p.gnb_res2 + (unsigned)(pix * C + n0 + cc));
-            const uint32_t r2w[4] = {r2.x, r2.y, r2.z, r2.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { o[2 * i] += __uint_as_float(r2w[i] << 16); o[2 * i + 1] += __uint_as_float(r2w[i] & 0xffff0000u); }
-          }
-          *reinterpret_cast<uint4*>(dst + (unsigned)(pix * opitch + oc)) =
-              make_uint4(idf_pack_bf16(o[0], o[1]), idf_pack_bf16(o[2], o[3]), idf_pack_bf16(o[4], o[5]), idf_pack_bf16(o[6], o[7]));
+          for (int k = 0; k < DNI; ++k)
+            stash[k * NT + tid] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + ((tid + k * NT) >> 3) * (BN + 4) + (tid & 7) * 8);
+          prev_oy0 = oy0; prev_writer = pe.rs_tidx == 0;
         }
       }
     } else if constexpr (DUE) {
@@ -602,6 +646,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     }
     item += istep; nt = nnt; b = nb; half = nhalf; oy0 = noy0; n0 = nn0;
   }
+  if constexpr (PAIR) sync_apply(prev_oy0 >= 0);      // (behind the loop: nothing of it -- weights, the next rows -- is live across the wait)
   RS_FLUSH;
 }
 
@@ -653,10 +698,16 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
   p.rs_per = idf_cdiv(p.rs_total, slots);
   int grid = idf_cdiv(p.rs_total, p.rs_per);
   if (EPI == 3) {
-    // lock-step rounds: every workgroup of a group (tiles_per_img items) in the same round, the whole grid resident
-    grid = p.rs_total < slots ? p.rs_total : slots;
+    if (W == 64) {
+      // pairs: a workgroup's (at most two) consecutive items are vertically adjacent tiles of one image half; the grid is resident
+      if (p.rs_per > 2 || (p.rs_per == 2 && ((p.H / G::R) & 1))) return 4;
+    } else {
+      // lock-step rounds: every workgroup of a group (tiles_per_img items) in the same round, the whole grid resident
+      grid = p.rs_total < slots ? p.rs_total : slots;
+      if (grid % p.tiles_per_img) return 4;
+    }
     // ... and a 64-channel slice must hold whole GroupNorm groups (Cout / 32 channels each: not at 192 channels)
-    if (grid % p.tiles_per_img || 64 % p.tiles_per_img || 64 % (p.Cout >> 5) || p.B * p.n_tiles > RS_SYNC_MAX) return 4;
+    if (64 % p.tiles_per_img || 64 % (p.Cout >> 5) || p.B * p.n_tiles > RS_SYNC_MAX) return 4;
     if (hipGetSymbolAddress((void**)&p.rs_sync, HIP_SYMBOL(g_rs_sync)) != hipSuccess ||
         hipGetSymbolAddress((void**)&p.rs_sync_err, HIP_SYMBOL(g_rs_sync_err)) != hipSuccess) return 5;
   }
@@ -666,6 +717,8 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
   else { p.rs_os_off = (int)lds; lds += osz; }
   p.aux_off = (int)lds;
   lds += (size_t)4 * NPH * 64 * 8 + (EPI == 3 ? 1024 : 0);   // wave partials of the statistics (EPI 3: + the fold's scratch)
+  p.rs_stash_off = (int)lds;
+  if (EPI == 3 && W == 64) lds += (size_t)G::R * G::TW * 64 * 2;   // the first tile's du of a pair (packed)
   p.rs_cof_off = (int)lds;
   if (PRO) lds += (size_t)CIN * 16;
   if (lds > 160 * 1024 / halves) return 1;
@@ -686,10 +739,6 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
 
 int dispatch_rs_sync(C3P& p, hipStream_t st, bool probe) {
   if (g_rs != 1) return 3;
-  // 64x64 (two lock-step rounds at B = 32, groups of 32 workgroups): 50.6 us against 39.5 for conv + apply -- the wait in the middle
-  // re-aligns the two workgroups of a CU, whose drift is what lets one's MFMA loop run under the other's epilogue; the 32x32
-  // shapes (one round, groups of 8) win 3-6 us per launch (profiles/r05_conv_rs_sync.txt).  IDF_CONV_RS_SYNC=2 takes it anyway.
-  if (p.W == 64 && idf_knobs().conv_rs_sync < 2) return 7;
   if (p.W == 64 && p.Cin == 64) return launch_rs<64, 64, false, 3, 1>(p, st, probe);
   if (p.W == 32 && p.Cin == 128) return launch_rs<32, 128, false, 3, 1>(p, st, probe);
   if (p.W == 32 && p.Cin == 64) return launch_rs<32, 64, false, 3, 1>(p, st, probe);

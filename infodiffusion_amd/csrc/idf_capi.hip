@@ -17,7 +17,7 @@ extern "C" int idf_version(void) { return 100; }
 
 // Every environment switch the library reads -- six -- read ONCE, at first use (a C++11 magic static: initialised exactly once under
 // concurrent first calls); everything else that used to be a getenv is a constant with its measurement in the comment beside it.
-// The Python package has its own table (infodiffusion_amd/knobs.py); INTEGRATION.md section 6 lists both.
+// The Python package has its own table (infodiffusion_amd/knobs.py); INTEGRATION.md section 5 lists both.
 const IdfKnobs& idf_knobs() {
   static const IdfKnobs k = [] {
     IdfKnobs v;

@@ -36,6 +36,17 @@ def test_every_switch_is_listed():
     covered = {c[0] for c in CASES} | {'IDF_LIB', 'IDF_FORCE_SYNC', 'IDF_CPU_THREADS'}
     assert covered == set(knobs.TABLE) | lib, sorted(covered ^ (set(knobs.TABLE) | lib))
     assert len(set(knobs.TABLE) | lib) <= 30
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert all('`%s`' % n in doc for n in set(knobs.TABLE) | lib), [n for n in set(knobs.TABLE) | lib if '`%s`' % n not in doc]
+    # ... and nothing else in the product reads an IDF_* name from the environment
+    import glob
+    import re
+    for f in glob.glob(os.path.join(ROOT, 'infodiffusion_amd', 'csrc', '*')):
+        if not f.endswith('idf_capi.hip'):
+            assert 'getenv' not in open(f).read(), f
+    for f in glob.glob(os.path.join(ROOT, 'infodiffusion_amd', '*.py')):
+        if not f.endswith(('knobs.py', 'build.py')):
+            assert not re.search(r'environ[^\n]*IDF_', open(f).read()), f
 
 
 @pytest.mark.gpu

@@ -254,6 +254,17 @@ class LaunchRecorder:
             if a[3]:
                 bufs.append((3, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
+        if name == 'idf_conv_rs_dgrad_gn_bf16':     # ... and with the whole GroupNorm backward behind it (du never written):
+            B, H, W, Cin, Cout = a[29:34]           # credited with the conv's FLOPs only, like the du-epilogue launches
+            px = B * H * W
+            C1 = a[4] if a[3] else Cout
+            bufs = [(0, px * Cin * 2), (2, px * C1 * 2), (13, px * C1 * 2)]
+            if a[3]:
+                bufs += [(3, px * (Cout - C1) * 2), (14, px * (Cout - C1) * 2)]
+            for i in (11, 12):
+                if a[i]:
+                    bufs.append((i, px * Cout * 2))
+            return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
         if name == 'idf_conv_dgrad_chain_sc_bf16':  # ... with the block shortcut's data gradient riding in the launch
             B, H, W, Cin, Cout = a[13:18]
             sc_Cin = a[22]
@@ -639,7 +650,7 @@ def main():
                                          'upconv_dgrad_bf16 / downconv_dgrad_bf16 -- counted with the reference\'s 3x3 FLOPs, of which they execute 4/9, 4/9 and 1/1 --, and on the '
                                          'small maps conv_wr_kernel / resblock8_fwd_kernel / resblock8_bwd_kernel, whose launches hold 2-3 convs: '
                                          'forward incl. GroupNorm-prologue launches + data-gradient launches incl. those whose epilogue is the '
-                                         'GroupNorm backward (small maps) or its du / partial-sum half (big maps))',
+                                         'GroupNorm backward (small maps; round 5: also the big maps, behind an in-launch wait of the image\'s workgroups -- conv_rs_bf16 EPI 3) or its du / partial-sum half (the big-map stages that form does not cover))',
                                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': round(ach / peak, 4),
                                'traffic': pmc_traffic_file(['conv_rs_bf16', 'conv_ps_bf16', 'conv_dlds_bf16', 'conv3x3_halo_bf16', 'conv3x3_fewc_bf16', 'conv_wr_kernel', 'upconv_', 'downconv_',

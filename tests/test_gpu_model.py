@@ -508,6 +508,10 @@ GRAD_TOL_P90, GRAD_TOL_TAIL, GRAD_TOL_TAIL_SHARE = 0.15, 0.20, 0.02
 # with its sub-pixel form, whose own error against fp32 is the same 2.36e-3 vs 2.34e-3 rel-L2).  The cap (GRAD_TOL_MAX), the rel-L2
 # bound and the median keep each parameter's own scale.
 GRAD_FLOOR = 1e-3
+# ... and a parameter the floor shelters from the distribution statistics is held by its ABSOLUTE error instead: at most GRAD_ABS_SMALL
+# x GRAD_FLOOR x the step's largest gradient entry (measured worst: see the a_dim 256 test)
+GRAD_ABS_SMALL = 0.5
+FIRST_PASS_TOL_MAX, FIRST_PASS_TOL_L2 = 0.45, 0.40
 
 
 def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD_TOL_L2, tol_median=GRAD_TOL_MEDIAN):
@@ -515,7 +519,7 @@ def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD
     back as clip_grad_norm_ does): per parameter, max-abs error relative to the reference's max-abs AND rel-L2; over all
     parameters, the median of the former.  Gradients that are mathematically zero (a conv bias in front of a GroupNorm,
     proj_k.bias) are pure rounding noise: they must stay small against the largest gradient of the step instead."""
-    worst, n = [], 0
+    worst, scales, n = [], [], 0
     top = max(float(g.abs().max()) for g in ref.values())
     for k, gr in ref.items():
         assert named[k].grad is not None, (what, k)
@@ -526,7 +530,11 @@ def _check_named_grads(named, ref, clip, what, tol_max=GRAD_TOL_MAX, tol_l2=GRAD
             continue
         err = float((got - gr).abs().max())
         worst.append((err / scale, float((got - gr).norm() / gr.norm()), k, err / max(scale, GRAD_FLOOR * top)))
+        scales.append(scale)
         n += 1
+    small = [(w[0] * sc_, k_) for w, sc_, k_ in ((w, s_, w[2]) for w, s_ in zip(worst, scales)) if sc_ < GRAD_FLOOR * top]
+    if small:
+        assert max(small)[0] < GRAD_ABS_SMALL * GRAD_FLOOR * top, (what, 'absolute error of a small gradient', max(small), GRAD_FLOOR * top)
     worst.sort(reverse=True)
     assert worst[0][0] < tol_max, (what, worst[:8])
     byl2 = sorted(worst, key=lambda t: -t[1])
@@ -686,9 +694,7 @@ def test_bf16_train_step_a_dim_256_at_the_per_gpu_batch():
     ref_loss, ref_grads, ref_gn = _oracle_step(cfg, sd, fix)
     # two passes on the same draws (lr 0): the first runs before the fragment-major weight shadows exist (the small-map convs
     # still take the register-staged kernels), the second is the steady state the benchmark measures -- image-resident 8x8
-    # blocks, fragment-major 16x16 convs.  Loss and gradient norm are held on both; the per-parameter band on the steady state
-    # (measured worst rel-L2: 0.34 on the first pass -- the encoder's one-element tail bias, a cancelling sum over 131072
-    # bf16 values -- and 0.18 on the second).
+    # blocks, fragment-major 16x16 convs.  Loss, gradient norm and the per-parameter band are held on both.
     for steady in (False, True):
         with _ReplayedDraws(fix):
             loss = model.loss_fn(args_of(cfg), fix['x'].to(DEV))
@@ -698,8 +704,14 @@ def test_bf16_train_step_a_dim_256_at_the_per_gpu_batch():
         assert rel(loss, ref_loss) < 1e-2, (steady, float(loss), float(ref_loss))
         gn = float(opt.total_norm())
         assert abs(gn - ref_gn) / ref_gn < 2e-2, (steady, gn, ref_gn)
-    n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)), 'a_dim 256, B=32')
-    assert n > 500
+        # the band on BOTH passes: a regression in the kernels only a network's first pass runs must not hide behind the steady
+        # state (the first pass with its own caps; measured worst, round 5: 0.15 max-abs / 0.12 rel-L2 on the first pass, 0.34 / 0.34 in
+        # the steady state -- the encoder's one-element tail bias, a cancelling sum over 131072 bf16 values: which pass it lands on moves
+        # with any re-ordering of roundings upstream)
+        n, _ = _check_named_grads(dict(model.named_parameters()), ref_grads, min(1.0, 1.0 / (gn + 1e-6)),
+                                  'a_dim 256, B=32, %s pass' % ('steady' if steady else 'first'),
+                                  **({} if steady else {'tol_max': FIRST_PASS_TOL_MAX, 'tol_l2': FIRST_PASS_TOL_L2}))
+        assert n > 500
 
 
 def test_cifar_two_phase_ddim_b64_first_images_match_small_batch():

@@ -24,6 +24,7 @@ def make(kind, cin):
 
 def timed(fn, reps=20):
     fn()
+    fn()       # (a stand-alone block's first call asks for the fragment-major layouts, its second packs them: both outside the capture)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -40,45 +41,8 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / (5 * reps) * 1e3
 
 
-for kind, cin in (('aux', 128), ('aux', 256), ('enc', 128), ('enc', 256)):
-    blk = make(kind, cin)
-    x1 = torch.randn(B, 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True)
-    x2 = torch.randn(B, cin - 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True) if cin > 128 else None
-    x1._gn = ops.gn_partials_raw(x1)
-    if x2 is not None:
-        x2._gn = ops.gn_partials_raw(x2)
-    ft = torch.randn(B, 256, device=DEV) * 0.1
-    fa = torch.randn(B, 256, device=DEV) * 0.1
-    xin = (x1, x2) if x2 is not None else x1
-
-    def fwd():
-        if kind == 'aux':
-            blk._film = {'t': ft, 'a': fa}
-            return blk(xin, None, None)
-        return blk(xin)
-    res = []
-    for fused in (False, True):
-        ops._RB_SMALL = fused
-        res.append(timed(fwd))
-    with torch.no_grad():                      # inference: no a / h / coefficient outputs
-        for fused in (False, True):
-            ops._RB_SMALL = fused
-            res.append(timed(fwd))
-    print('%s Cin %d B %d: per-op %.1f us   fused %.1f us   | no_grad: per-op %.1f us   fused %.1f us' % (kind, cin, B, *res))
-
-# diagnostic build (tools/build_variant.sh rbstamp idf_resblock.hip -DIDF_RB_STAMP, IDF_LIB=...): phase shares of the fused kernel
-import ctypes
-from infodiffusion_amd import _lib
-lib = _lib.load()
-if hasattr(lib, 'idf_debug_rb_stamps'):
-    lib.idf_debug_rb_stamps.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-    addr = ctypes.c_void_p()
-    assert lib.idf_debug_rb_stamps(ctypes.byref(addr)) == 0
-    hip = ctypes.CDLL('libamdhip64.so')
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
-    ops._RB_SMALL = True
-    for kind, cin in (('aux', 128), ('aux', 256), ('enc', 128)):
+def main():
+    for kind, cin in (('aux', 128), ('aux', 256), ('enc', 128), ('enc', 256)):
         blk = make(kind, cin)
         x1 = torch.randn(B, 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True)
         x2 = torch.randn(B, cin - 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True) if cin > 128 else None
@@ -86,22 +50,64 @@ if hasattr(lib, 'idf_debug_rb_stamps'):
         if x2 is not None:
             x2._gn = ops.gn_partials_raw(x2)
         ft = torch.randn(B, 256, device=DEV) * 0.1
+        fa = torch.randn(B, 256, device=DEV) * 0.1
         xin = (x1, x2) if x2 is not None else x1
 
         def fwd():
             if kind == 'aux':
-                blk._film = {'t': ft, 'a': ft}
+                blk._film = {'t': ft, 'a': fa}
                 return blk(xin, None, None)
             return blk(xin)
-        for _ in range(3):
-            fwd()
-        torch.cuda.synchronize()
-        hip.hipMemset(addr, 0, 64)
-        for _ in range(10):
-            fwd()
-        torch.cuda.synchronize()
-        buf = (ctypes.c_ulonglong * 8)()
-        hip.hipMemcpy(buf, addr, 64, 2)
-        n = buf[7]
-        print('%s Cin %d stamps per block (ticks): stage0 %d | conv %s | epilogue %s' % (
-            kind, cin, buf[0] // n, [buf[1 + 2 * k] // n for k in range(3)], [buf[2 + 2 * k] // n for k in range(3)]))
+        res = []
+        for fused in (False, True):
+            ops._RB_SMALL = fused
+            res.append(timed(fwd))
+        with torch.no_grad():                      # inference: no a / h / coefficient outputs
+            for fused in (False, True):
+                ops._RB_SMALL = fused
+                res.append(timed(fwd))
+        print('%s Cin %d B %d: per-op %.1f us   fused %.1f us   | no_grad: per-op %.1f us   fused %.1f us' % (kind, cin, B, *res))
+
+    # diagnostic build (tools/build_variant.sh rbstamp idf_resblock.hip -DIDF_RB_STAMP, IDF_LIB=...): phase shares of the fused kernel
+    import ctypes
+    from infodiffusion_amd import _lib
+    lib = _lib.load()
+    if hasattr(lib, 'idf_debug_rb_stamps'):
+        lib.idf_debug_rb_stamps.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        addr = ctypes.c_void_p()
+        assert lib.idf_debug_rb_stamps(ctypes.byref(addr)) == 0
+        hip = ctypes.CDLL('libamdhip64.so')
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        ops._RB_SMALL = True
+        for kind, cin in (('aux', 128), ('aux', 256), ('enc', 128)):
+            blk = make(kind, cin)
+            x1 = torch.randn(B, 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True)
+            x2 = torch.randn(B, cin - 128, 8, 8, device=DEV).bfloat16().contiguous(memory_format=CL).requires_grad_(True) if cin > 128 else None
+            x1._gn = ops.gn_partials_raw(x1)
+            if x2 is not None:
+                x2._gn = ops.gn_partials_raw(x2)
+            ft = torch.randn(B, 256, device=DEV) * 0.1
+            xin = (x1, x2) if x2 is not None else x1
+
+            def fwd():
+                if kind == 'aux':
+                    blk._film = {'t': ft, 'a': ft}
+                    return blk(xin, None, None)
+                return blk(xin)
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+            hip.hipMemset(addr, 0, 64)
+            for _ in range(10):
+                fwd()
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * 8)()
+            hip.hipMemcpy(buf, addr, 64, 2)
+            n = buf[7]
+            print('%s Cin %d stamps per block (ticks): stage0 %d | conv %s | epilogue %s' % (
+                kind, cin, buf[0] // n, [buf[1 + 2 * k] // n for k in range(3)], [buf[2 + 2 * k] // n for k in range(3)]))
+
+
+if __name__ == '__main__':
+    main()

@@ -753,6 +753,11 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    # workgroups of the synchronised data-gradient conv that ever gave up waiting for their group (a grid that was not resident at once):
+    # a launch with a time-out computed garbage, so the run is void
+    from infodiffusion_amd import ops as _ops
+    sync_timeouts = _ops.rs_sync_timeouts(False)
+    out['config']['rs_sync_timeouts'] = sync_timeouts
     if rank == 0:
         # the LAST line of stdout: RCCL printf()s its version banner into the C library's stdout buffer, which would
         # otherwise be flushed at exit, after this line
@@ -765,6 +770,9 @@ def main():
         print(json.dumps(out), flush=True)
     if sampler_capture_failed:
         sys.exit(3)
+    if sync_timeouts:
+        print('idf_conv_rs_dgrad_gn_bf16: %d workgroup(s) timed out waiting for their group' % sync_timeouts, file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == '__main__':

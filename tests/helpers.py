@@ -87,4 +87,5 @@ def smoke_check(device):
     ref = O.ddim_step(O.noise_schedule(cfg.beta1, cfg.betaT, 4), x, terms['out'], 2, nz)
     assert rel(xo, ref) < 1e-4
     torch.cuda.synchronize()
+    assert ops.rs_sync_timeouts(False) == 0
     print('smoke ok: loss %.6f (oracle %.6f)' % (float(loss), float(lo)))

@@ -255,7 +255,7 @@ class LaunchRecorder:
                 bufs.append((3, px * (Cout - C1) * 2))
             return 'conv3x3', bufs, 2.0 * px * Cout * 9 * Cin
         if name == 'idf_conv_rs_dgrad_gn_bf16':     # ... and with the whole GroupNorm backward behind it (du never written):
-            B, H, W, Cin, Cout = a[29:34]           # credited with the conv's FLOPs only, like the du-epilogue launches
+            B, H, W, Cin, Cout = a[30:35]           # credited with the conv's FLOPs only, like the du-epilogue launches
             px = B * H * W
             C1 = a[4] if a[3] else Cout
             bufs = [(0, px * Cin * 2), (2, px * C1 * 2), (13, px * C1 * 2)]

@@ -228,17 +228,24 @@ int idf_conv_rs_dgrad_chain_bf16(const void* dy, const void* w_frag, const void*
  * partial sums).  idf_conv_rs_dgrad_gn_tiles: T of the partials workspace when the form covers the shape on this device (the
  * grid must be a whole number of groups and resident at once), else 0.  dres / dres2: residual / skip gradients (dense
  * [B,H,W,Cout]) or null; dx | dx2 as x | x2; part: workspace [B][T][Cout][2]; dfilm_t / dfilm_a [B][2 Cout], dgb [B][2][Cout]
- * or dgam / dbet (accumulated) as idf_gn_bwd_apply's.  Launches of this entry must not overlap each other (one counter set per
- * process).  idf_conv_rs_sync_timeouts: workgroups that gave up waiting since the last reset (0 in a healthy process; reads the
- * device: synchronises). */
+ * or dgam / dbet (accumulated) as idf_gn_bwd_apply's.  sync_state: idf_conv_rs_sync_words() uint32 words of device memory owned by
+ * the caller, zero when first handed in and persistent across launches (counters that only grow, then an error word = the number of
+ * workgroups that ever gave up waiting: 0 in a healthy process); launches that share a state array must not overlap. */
 int idf_conv_rs_dgrad_gn_tiles(int B, int H, int W, int Cin, int Cout);
 int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x, const void* x2, int C1, const float* sc,
                               const float* sh, const uint64_t* seed, uint32_t salt, float p_drop, int act, const void* dres,
                               const void* dres2, void* dx, void* dx2, float* part, const float* gamma, const float* beta,
                               const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean, const float* rstd,
-                              float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet, int B, int H, int W, int Cin,
-                              int Cout, void* stream);
-int idf_conv_rs_sync_timeouts(int reset);
+                              float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet, uint32_t* sync_state, int B,
+                              int H, int W, int Cin, int Cout, void* stream);
+int idf_conv_rs_sync_words(void);
+
+/* Deterministic mode (/root/reference/utils.py:64-71): the GroupNorm affine gradients of a whole backward pass in ONE launch.
+ * Every GroupNorm-backward entry above writes per-image rows dgb [B][2][C] when it is given no accumulation slots; table = n
+ * entries of {const float* rows; float* dgamma; float* dbeta; int B; int C;} (idf_gn_rows_desc_bytes() each); the launch adds
+ * each entry's rows in image order into its slots: dgamma[c] += sum_b rows[b][0][c], dbeta[c] += sum_b rows[b][1][c]. */
+int idf_gn_rows_desc_bytes(void);
+int idf_gn_param_reduce_batched(const void* table, int n, int max_c, void* stream);
 
 /* The backward of the same blocks: the data-gradient convs of stages nstage-1 .. first with the GroupNorm / FiLM / SiLU / dropout
  * backward behind each (what idf_conv_wr_dgrad_gn_bf16 computes per stage) in ONE launch, one workgroup per image; every stage

@@ -66,8 +66,10 @@ SIGNATURES = {
     'idf_conv_rs_gn_bf16': ([_p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _u32, _f] + [_p] * 10 + [_i] * 5 + [_p], C.c_int),
     'idf_conv_rs_dgrad_chain_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i, _p, _p] + [_i] * 5 + [_p], C.c_int),
     'idf_conv_rs_dgrad_gn_tiles': ([_i] * 5, C.c_int),
-    'idf_conv_rs_dgrad_gn_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i] + [_p] * 9 + [_i, _i] + [_p] * 7 + [_i] * 5 + [_p], C.c_int),
-    'idf_conv_rs_sync_timeouts': ([_i], C.c_int),
+    'idf_conv_rs_dgrad_gn_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i] + [_p] * 9 + [_i, _i] + [_p] * 8 + [_i] * 5 + [_p], C.c_int),
+    'idf_conv_rs_sync_words': ([], C.c_int),
+    'idf_gn_rows_desc_bytes': ([], C.c_int),
+    'idf_gn_param_reduce_batched': ([_p, _i, _i, _p], C.c_int),
     'idf_conv_fewc_tiles': ([_i] * 5, C.c_int),
     'idf_conv3x3_fewc_bf16': ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p], C.c_int),
     'idf_conv_wr_gn_bf16': ([_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _u32, _f] + [_p] * 10 + [_i] * 5 + [_p], C.c_int),

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21)) { if (lane == 0) atomicOr(p.rs_sync_err, 1u); break; }
+          if (++spins > (1u << 21)) { if (lane == 0) atomicAdd(p.rs_sync_err, 1u); break; }
         }
       } else { fetch_apply_operands(); fetch_prev_operands(); }
       lds_barrier();
@@ -682,11 +682,10 @@ int rs_ncu() {
   return ncu;
 }
 
-// the group-synchronised form's counters: one per (image, 64-channel slice) of a launch, shared by every launch of the process
-// (launches that use them must not overlap: the package issues its compute on one stream)
+// the group-synchronised form's state, owned by the caller (the library allocates nothing): RS_SYNC_MAX counters -- one per
+// (image, 64-channel slice) of a launch, zero when first handed in, only ever growing -- and behind them the error word; launches
+// that share a state array must not overlap (the package keeps one per device and issues its compute on one stream)
 constexpr int RS_SYNC_MAX = 8192;
-__device__ unsigned g_rs_sync[RS_SYNC_MAX];
-__device__ unsigned g_rs_sync_err;
 
 template <int W, int CIN, bool PRO, int EPI, int NPH>
 int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
@@ -708,8 +707,8 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
     }
     // ... and a 64-channel slice must hold whole GroupNorm groups (Cout / 32 channels each: not at 192 channels)
     if (64 % p.tiles_per_img || 64 % (p.Cout >> 5) || p.B * p.n_tiles > RS_SYNC_MAX) return 4;
-    if (hipGetSymbolAddress((void**)&p.rs_sync, HIP_SYMBOL(g_rs_sync)) != hipSuccess ||
-        hipGetSymbolAddress((void**)&p.rs_sync_err, HIP_SYMBOL(g_rs_sync_err)) != hipSuccess) return 5;
+    if (!probe && !p.rs_sync) return 5;
+    p.rs_sync_err = p.rs_sync + RS_SYNC_MAX;
   }
   size_t lds = (size_t)(CIN / 32) * G::CHB;
   const size_t osz = (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
@@ -842,7 +841,8 @@ extern "C" int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, con
                                          const void* dres2, void* dx, void* dx2, float* part, const float* gamma, const float* beta,
                                          const float* film_t, const float* film_a, int ld_t, int ld_a, const float* mean,
                                          const float* rstd, float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet,
-                                         int B, int H, int W, int Cin, int Cout, void* stream) {
+                                         uint32_t* sync_state, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!sync_state) IDF_FAIL(IDF_ERR_BADARG, "conv_rs_dgrad_gn_bf16: null sync_state");
   if (!idf_conv_rs_dgrad_gn_tiles(B, H, W, Cin, Cout))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "conv_rs_dgrad_gn_bf16: B%d H%d W%d Cin%d Cout%d not covered", B, H, W, Cin, Cout);
   if (!dy || !w_frag || !x || !sc || !sh || !dx || !part || !mean || !rstd || (act != 1 && act != 2))
@@ -854,7 +854,7 @@ extern "C" int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, con
   p.x = (const bf16_t*)dy; p.C1 = Cin; p.w = (const bf16_t*)w_frag; p.y = (bf16_t*)dx; p.rs_dx2 = (bf16_t*)dx2;
   p.B = B; p.H = H; p.W = W; p.Hs = H; p.Ws = W; p.Cin = Cin; p.Cout = Cout;
   p.due_x = (const bf16_t*)x; p.due_x2 = (const bf16_t*)x2; p.due_C1 = C1; p.due_sc = sc; p.due_sh = sh;
-  p.st_out = part; p.res = (const bf16_t*)dres; p.gnb_res2 = (const bf16_t*)dres2;
+  p.st_out = part; p.res = (const bf16_t*)dres; p.gnb_res2 = (const bf16_t*)dres2; p.rs_sync = sync_state;
   p.act = act; p.salt = salt; p.thr = idf_drop_thresh(p_drop);
   p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
   p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
@@ -867,16 +867,7 @@ extern "C" int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, con
   return IDF_OK;
 }
 
-// Workgroups of the synchronised form that gave up waiting for their group since the last call with reset != 0 (a device-to-host
-// read: synchronises).  Anything but 0 means a launch's grid was not resident at once -- its results are garbage.
-extern "C" int idf_conv_rs_sync_timeouts(int reset) {
-  unsigned v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rs_sync_err), sizeof(v)) != hipSuccess) return -1;
-  if (reset && v) {
-    const unsigned z = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_sync_err), &z, sizeof(z)) != hipSuccess) return -1;
-    static unsigned zeros[RS_SYNC_MAX];
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_sync), zeros, sizeof(zeros)) != hipSuccess) return -1;
-  }
-  return (int)v;
-}
+// Words of the state array idf_conv_rs_dgrad_gn_bf16 takes (uint32): the counters, then the error word -- the number of workgroups that
+// ever gave up waiting for their group (0 in a healthy process; anything else: a launch's grid was not resident at once and its
+// results are garbage; zero the whole array to go on).
+extern "C" int idf_conv_rs_sync_words(void) { return RS_SYNC_MAX + 16; }

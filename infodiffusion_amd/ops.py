@@ -417,11 +417,104 @@ _GN_STREAM_MINPIX = 1 << 18     # B * H * W from which the unfused GroupNorm str
 
 def _gn_acc(acc):
     """acc = (gamma slot, beta slot) of the gradient arena -> their views when both are free."""
-    if _WGRAD_DET:         # deterministic mode: no atomics into the arena -- per-image rows + a column sum (the callers' dgb path)
+    if _WGRAD_DET:         # deterministic mode: no atomics into the arena -- per-image rows (the callers' dgb path, _gn_out)
         return None
     if acc is None or acc[0] is None or acc[1] is None or not (acc[0].available() and acc[1].available()):
         return None
     return acc[0].take(), acc[1].take()
+
+
+class GnRowsBatch:
+    """Deterministic mode: the GroupNorm affine gradients of a backward pass.  Every GroupNorm-backward launch writes per-image
+    rows dgb [B][2][C] into a slice of ONE workspace and returns its arena slot views (which AccumulateGrad merely adopts); ONE
+    launch at the end of the pass (`idf_gn_param_reduce_batched`) adds every stage's rows in image order into its slots -- in
+    place of a column-sum launch per stage (124 launches / 0.6 ms of a CelebA step).  A backward pass visits its stages in the same
+    order every step, so the slices and with them the launch's table repeat: the table is uploaded when a new sequence shows up
+    (eagerly: the warm-up steps of a capture leave the one the captured pass finds)."""
+    ws = None          # fp32 workspace, handed out front to back during a pass
+    cursor = 0
+    want = 0           # floats the last pass asked for (the workspace grows between passes)
+    pending = []       # (rows address, gamma slot address, beta slot address, B, C)
+    keep = []          # tensors the pending launch reads (overflow rows)
+    tables = {}        # sequence -> device table
+    _cb_queued = False
+    _task = -1
+
+    @classmethod
+    def rows(cls, views, B, C, dev):
+        task = torch._C._current_graph_task_id()
+        if cls._cb_queued and task != cls._task:
+            cls._drop()                                     # the pass that queued the flush never ended (a node raised)
+        n = B * 2 * C
+        if cls.ws is not None and cls.ws.device == dev and cls.cursor + n <= cls.ws.numel():
+            dgb = cls.ws[cls.cursor:cls.cursor + n].view(B, 2 * C)
+        else:
+            dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)     # first pass / overflow: a tensor of its own
+            cls.keep.append(dgb)
+        cls.cursor += n
+        # (addresses, not the views: AccumulateGrad adopts a gradient only while nobody else holds the tensor -- see LazyGrad)
+        cls.pending.append((dgb.data_ptr(), views[0].data_ptr(), views[1].data_ptr(), B, C))
+        if not cls._cb_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+                cls._cb_queued, cls._task = True, task
+            except RuntimeError:                            # not inside a backward pass: nothing to defer to (flushed by the caller)
+                pass
+        return dgb
+
+    @classmethod
+    def _drop(cls):
+        cls.pending, cls.keep, cls.cursor, cls._cb_queued = [], [], 0, False
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, []
+        cls._cb_queued = False
+        cls.want, cls.cursor = max(cls.want, cls.cursor), 0
+        if not items:
+            cls.keep = []
+            return
+        import numpy as np
+        key = tuple(items)
+        tab = cls.tables.get(key)
+        if tab is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('GnRowsBatch: run one eager step before graph capture (the reduce launch\'s table)')
+            nb = int(_lib.load().idf_gn_rows_desc_bytes())
+            assert nb == 32
+            host = np.zeros((len(items),), dtype=np.dtype([('rows', '<i8'), ('dg', '<i8'), ('db', '<i8'), ('B', '<i4'), ('C', '<i4')]))
+            for i, it in enumerate(items):
+                host[i] = it
+            if len(cls.tables) >= 8:
+                cls.tables.pop(next(iter(cls.tables)))
+            tab = torch.from_numpy(host.view(np.uint8).copy()).to(torch.device('cuda', torch.cuda.current_device()))
+            cls.tables[key] = tab
+        call('idf_gn_param_reduce_batched', _p(tab), len(items), max(it[4] for it in items), _st())
+        cls.keep = []
+        if not torch.cuda.is_current_stream_capturing() and (cls.ws is None or cls.ws.numel() < cls.want):
+            # (between passes: nothing of the finished pass's rows is read after the launch above -- stream order)
+            cls.ws = torch.empty((2 * cls.want,), dtype=torch.float32, device=tab.device)
+
+
+def _gn_out(acc, B, C, dev):
+    """Where a GroupNorm backward leaves dgamma / dbeta -> (acc, dgb, views): acc = the arena slot views the kernel accumulates into
+    (atomics: the default), or dgb = per-image rows [B][2][C] -- with views = the slot views a deferred launch fills
+    (deterministic mode, GnRowsBatch) or None (the caller sums the rows itself: no free slots)."""
+    slots = acc
+    acc = _gn_acc(acc)
+    if acc is not None:
+        return acc, None, None
+    if _WGRAD_DET and slots is not None and slots[0] is not None and slots[1] is not None and \
+            slots[0].available() and slots[1].available():
+        views = (slots[0].take(), slots[1].take())
+        return None, GnRowsBatch.rows(views, B, C, dev), views
+    return None, torch.empty((B, 2 * C), dtype=torch.float32, device=dev), None
+
+
+def _gn_done():
+    """Behind a launch that wrote rows for GnRowsBatch: outside a backward pass there is no end-of-pass callback -- reduce now."""
+    if GnRowsBatch.pending and not GnRowsBatch._cb_queued:
+        GnRowsBatch.flush()
 
 
 def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None):
@@ -430,8 +523,7 @@ def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh
     dx = torch.empty_like(x, memory_format=CL)
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    acc = _gn_acc(acc)
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    acc, dgb, later = _gn_out(acc, B, C, dev)
     k1 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     k0 = torch.empty((B, 32), dtype=torch.float32, device=dev)
     ws = torch.empty((_lib.load().idf_gn_workspace_floats(B, H * W, C),), dtype=torch.float32, device=dev)
@@ -439,8 +531,10 @@ def gn_coef_bwd_raw(dA, x, dres, gamma, beta, film_t, film_a, mean, rstd, sc, sh
          _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(k1), _p(k0), _p(ws), _p(seed),
          salt, float(p_drop), act, B, H * W, C, _dt(x), _st())
-    if acc:
-        return dx, acc[0], acc[1], dft, dfa
+    if acc or later:
+        g_ = acc or later
+        _gn_done()
+        return dx, g_[0], g_[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -492,16 +586,17 @@ def gn_fused_bwd_raw(dA, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, see
     dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    acc = _gn_acc(acc)
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    acc, dgb, later = _gn_out(acc, B, C, dev)
     call('idf_gn_fused_bwd', _p(dA), _p(x), _p(x2), C1, _p(dres), _p(dres2), _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t),
          _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop),
          act, B, H * W, C, _dt(x), _st())
     if x2 is not None:
         dx = (dx, dx2)
-    if acc:
-        return dx, acc[0], acc[1], dft, dfa
+    if acc or later:
+        g_ = acc or later
+        _gn_done()
+        return dx, g_[0], g_[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -533,8 +628,7 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
     dx = torch.empty_like(x, memory_format=CL)
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    acc = _gn_acc(acc)
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    acc, dgb, later = _gn_out(acc, B, C, dev)
     # (whole 16x16 images in this form -- 4 waves x 256 pixels -- measured SLOWER than the 512-thread register-staged kernel:
     # 25.8 vs 19.7 us at B = 32, profiles/r04_conv_wr.txt: 8x8 only)
     wfrag = _wr_frag(shadows, 3, B, H, W, dy.shape[1], C, 1) if (taps == 9 and act == 2 and C in (128, 256) and W == 8) else None
@@ -543,16 +637,20 @@ def conv_dgrad_gn_raw(dy, w_dgrad, x, gamma, beta, film_t, film_a, mean, rstd, s
              _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
              _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop), B, H, W, dy.shape[1], C,
              _st())
-        if acc:
-            return dx, acc[0], acc[1], dft, dfa
+        if acc or later:
+            g_ = acc or later
+            _gn_done()
+            return dx, g_[0], g_[1], dft, dfa
         dgam = colsum_raw(dgb)
         return dx, dgam[:C], dgam[C:], dft, dfa
     call('idf_conv_dgrad_gn_bf16', _p(dy), _p(w_dgrad), _p(x), _p(dres), _p(dres2), _p(dx), _p(gamma), _p(beta), _p(film_t),
          _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc), _p(sh), _p(dft), _p(dfa), _p(dgb),
          _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _p(seed), salt, float(p_drop), act, B, H, W,
          dy.shape[1], C, taps, _st())
-    if acc:
-        return dx, acc[0], acc[1], dft, dfa
+    if acc or later:
+        g_ = acc or later
+        _gn_done()
+        return dx, g_[0], g_[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -682,9 +780,28 @@ class sync_convs:
         return False
 
 
+_RS_SYNC_STATE = {}     # device index -> the synchronised form's counters + error word (uint32, zero-initialised, persistent)
+
+
+def _rs_sync_state(dev):
+    st = _RS_SYNC_STATE.get(dev.index)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('conv_dgrad_gn_sync_raw: run one eager step before graph capture (the counters)')
+        st = _RS_SYNC_STATE[dev.index] = torch.zeros((int(_lib.load().idf_conv_rs_sync_words()),), dtype=torch.int32, device=dev)
+    return st
+
+
 def rs_sync_timeouts(reset=True):
-    """Workgroups of the synchronised form that gave up waiting for their group (0 in a healthy process)."""
-    return int(_lib.load().idf_conv_rs_sync_timeouts(1 if reset else 0))
+    """Workgroups of the synchronised form that ever gave up waiting for their group, over all devices (0 in a healthy process;
+    reads device memory: synchronises).  reset: zero the state of a device that reported any."""
+    n = 0
+    for st in _RS_SYNC_STATE.values():
+        k = int(st[-16].item())
+        if k and reset:
+            st.zero_()
+        n += k
+    return n
 
 
 def conv_dgrad_gn_sync_raw(dy, Cout, x, gamma, beta, film_t, film_a, mean, rstd, sc, sh, seed, salt, p_drop, act, acc=None,
@@ -710,16 +827,17 @@ def conv_dgrad_gn_sync_raw(dy, Cout, x, gamma, beta, film_t, film_a, mean, rstd,
     dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    acc = _gn_acc(acc)
-    dgb = torch.empty((B, 2 * Cout), dtype=torch.float32, device=dev) if acc is None else None
+    acc, dgb, later = _gn_out(acc, B, Cout, dev)
     call('idf_conv_rs_dgrad_gn_bf16', _p(dy), _p(rfrag), _p(x), _p(x2), C1, _p(sc), _p(sh), _p(seed), salt, float(p_drop), act,
          _p(dres), _p(dres2), _p(dx), _p(dx2), _p(part), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
          _p(mean), _p(rstd), _p(dft), _p(dfa), _p(dgb), _p(acc[0]) if acc else None, _p(acc[1]) if acc else None,
-         B, H, W, Cin, Cout, _st())
+         _p(_rs_sync_state(dev)), B, H, W, Cin, Cout, _st())
     if x2 is not None:
         dx = (dx, dx2)
-    if acc:
-        return dx, acc[0], acc[1], dft, dfa
+    if acc or later:
+        g_ = acc or later
+        _gn_done()
+        return dx, g_[0], g_[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:Cout], dgam[Cout:], dft, dfa
 
@@ -734,15 +852,16 @@ def gn_bwd_apply_raw(du, part, x, gamma, beta, film_t, film_a, mean, rstd, sc, a
     dx2 = torch.empty_like(x2, memory_format=CL) if x2 is not None else None
     dft = torch.empty(film_t.shape, dtype=torch.float32, device=dev) if film_t is not None else None
     dfa = torch.empty(film_a.shape, dtype=torch.float32, device=dev) if film_a is not None else None
-    acc = _gn_acc(acc)
-    dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if acc is None else None
+    acc, dgb, later = _gn_out(acc, B, C, dev)
     call('idf_gn_bwd_apply', _p(du), _p(part), part.shape[1], _p(x), _p(x2), C1 if x2 is not None else 0, _p(dres), _p(dres2),
          _p(dx), _p(dx2), _p(gamma), _p(beta), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a), _p(mean), _p(rstd), _p(sc),
          _p(dft), _p(dfa), _p(dgb), _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, B, H * W, C, _st())
     if x2 is not None:
         dx = (dx, dx2)
-    if acc:
-        return dx, acc[0], acc[1], dft, dfa
+    if acc or later:
+        g_ = acc or later
+        _gn_done()
+        return dx, g_[0], g_[1], dft, dfa
     dgam = colsum_raw(dgb)
     return dx, dgam[:C], dgam[C:], dft, dfa
 
@@ -844,6 +963,7 @@ class WgradBatch:
         new graph task by itself).  Safe to call whenever no backward pass is running (trainer: before every forward, and
         after a failed capture)."""
         cls._drop()
+        GnRowsBatch._drop()
         _LAZY_PENDING.clear()
         del _FOLD_BWD_ROWS[:]
 
@@ -1529,11 +1649,11 @@ class _ResBlockSmall(torch.autograd.Function):
                 cfgs[i]['shadows'].request_frag()
             return None
         accs = []
+        if any(slots[4 * i + 2] is None or slots[4 * i + 3] is None or not (slots[4 * i + 2].available() and slots[4 * i + 3].available())
+               for i in range(first, n)):
+            return None             # (a slot taken twice: gradient accumulation without zero_grad -- the stand-alone path adds)
         for i in range(first, n):
-            acc = _gn_acc((slots[4 * i + 2], slots[4 * i + 3]))
-            if acc is None:
-                return None         # (a slot taken twice: gradient accumulation without zero_grad -- the stand-alone path adds)
-            accs.append(acc)
+            accs.append(_gn_out((slots[4 * i + 2], slots[4 * i + 3]), B, 128, x.device))     # (acc, None, None) | (None, rows, views)
         dev, dt = x.device, x.dtype
         A = _lib.ResblockBwdArgs()
         A.dy, A.nstage, A.first = _p(dy), n, first
@@ -1556,8 +1676,8 @@ class _ResBlockSmall(torch.autograd.Function):
             if fa is not None:
                 dfa = torch.empty(fa.shape, dtype=torch.float32, device=dev)
             S.dfilm_t, S.dfilm_a = (_p(dft), _p(dfa)) if (ft is not None or fa is not None) else (None, None)
-            acc = accs[i - first]
-            S.dgb, S.dgamma_acc, S.dbeta_acc = None, _p(acc[0]), _p(acc[1])
+            acc, rows, _ = accs[i - first]
+            S.dgb, S.dgamma_acc, S.dbeta_acc = _p(rows), _p(acc[0]) if acc else None, _p(acc[1]) if acc else None
             dxs[i] = torch.empty_like(gx, memory_format=CL)
             S.dx = _p(dxs[i])
         call('idf_resblock_small_bwd', ctypes.byref(A), _st())
@@ -1565,8 +1685,10 @@ class _ResBlockSmall(torch.autograd.Function):
             gi = dy if i == n - 1 else dxs[i + 1]          # the gradient of stage i's conv output
             ws, bs = slots[4 * i], slots[4 * i + 1]
             dW, db = conv_wgrad_bias_raw(keep[6 * i], gi, S1, 9, True, ws, bs, _grad_free(ws) and _grad_free(bs))
-            acc = accs[i - first]
-            grads[4 * i:4 * i + 4] = [dW, db, acc[0], acc[1]]
+            acc, _, later = accs[i - first]
+            g_ = acc or later
+            grads[4 * i:4 * i + 4] = [dW, db, g_[0], g_[1]]
+        _gn_done()
         return dxs[first], dft, dfa, first
 
     @staticmethod

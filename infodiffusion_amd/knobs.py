@@ -19,9 +19,9 @@ TABLE = {
     'IDF_DGRAD_GN': ('1', 'small-map backward: GroupNorm backward as the data-gradient conv\'s epilogue'),
     'IDF_SC_FUSE': ('1', 'a block\'s 1x1 shortcut (and its data gradient) rides in its first conv\'s launches on the small maps'),
     'IDF_WGRAD_BATCH': ('1', 'weight gradients deferred to the end of the backward pass and launched as table-driven batches'),
-    'IDF_DETERMINISTIC': ('', 'bit-reproducible training steps (the reference\'s seed_everything sets cudnn.deterministic, utils.py:64-71; unset: off until '
-                               'utils.seed_everything() -- i.e. run.py -- switches it on, 0: stays off, 1: on from import): weight gradients through per-split slabs + one ordered reduce launch instead of fp32 atomics, GroupNorm '
-                               'parameter gradients through per-image rows + a column sum; ~0.1 ms per CelebA step'),
+    'IDF_DETERMINISTIC': ('1', 'bit-reproducible training steps (the reference\'s seed_everything sets cudnn.deterministic, utils.py:64-71): weight '
+                               'gradients through per-split slabs + one ordered reduce launch, GroupNorm parameter gradients through per-image rows + one '
+                               'ordered reduce launch at the end of the pass (0: fp32 atomics for both; 8.42 vs 8.44-8.47 ms per CelebA step)'),
     'IDF_ATTN_FOLD': ('1', 'AttnBlock: proj conv folded into V (Wv\' = Wp Wv)'),
     'IDF_ATTN_BLOCK_MINB': ('256', 'batch from which the 16x16 AttnBlock runs as ONE launch (idf_attnblock_fwd)'),
     'IDF_UPCONV': ('1', 'UpSample conv / its gradients as four 2x2 sub-pixel convs with summed weights'),

@@ -664,14 +664,15 @@ _BWD_CHAIN = knobs.flag('IDF_BWD_CHAIN')     # du epilogue + streaming apply ins
 _SC_FUSE = knobs.flag('IDF_SC_FUSE')       # a block's 1x1 shortcut (and its data gradient) inside its first conv's launches
 _SC_FUSE_MAXPIX = 8192   # ... where those launches leave CUs idle: B * H * W up to 32 x 16 x 16
 _BWD_LAZY = knobs.flag('IDF_BWD_LAZY')
-_WGRAD_DET = knobs.raw('IDF_DETERMINISTIC') == '1'    # batched weight gradients: slab partials + ordered reduce instead of fp32 atomics
+_WGRAD_DET = knobs.raw('IDF_DETERMINISTIC') != '0'    # (default) batched weight gradients: slab partials + ordered reduce instead of fp32 atomics
 
 
 def set_deterministic(on):
     """Bit-reproducible training steps (the reference's --deterministic: utils.py:64-71 sets cudnn.deterministic): every
     accumulation that used fp32 atomics takes its ordered form -- weight gradients write per-split slabs that ONE reduce launch adds in
-    slab order (idf_wgrad_reduce_batched), GroupNorm parameter gradients go through per-image rows + a column sum instead of
-    atomics into the arena (which also sends the 8x8 blocks' backward through the per-op kernels).  Costs ~0.1 ms per CelebA step."""
+    slab order (idf_wgrad_reduce_batched), GroupNorm parameter gradients go through per-image rows that ONE launch at the end of
+    the pass adds in image order (GnRowsBatch) instead of atomics into the arena.  Round 5: the DEFAULT (0.01-0.05 ms per CelebA
+    step against the atomic forms, profiles/r05_deterministic.txt); set_deterministic(False) / IDF_DETERMINISTIC=0 select atomics."""
     global _WGRAD_DET
     on = bool(on) and knobs.raw('IDF_DETERMINISTIC') != '0'          # IDF_DETERMINISTIC=0 pins the atomic forms (A/B runs)
     if on != _WGRAD_DET:

@@ -17,7 +17,7 @@ CASES = [
     # kernel-path switches of the package
     ('IDF_CONV_RS', '0', STEP), ('IDF_CONV_RS', '2', STEP), ('IDF_CONV_RS_FWD', '1', STEP), ('IDF_CONV_WR', '0', STEP),
     ('IDF_RB_SMALL', '0', STEP), ('IDF_RB_SMALL_MAXB', '1', STEP), ('IDF_GN_FUSE', '0', STEP), ('IDF_BWD_CHAIN', '0', STEP),
-    ('IDF_BWD_LAZY', '1', STEP), ('IDF_DGRAD_GN', '0', STEP), ('IDF_SC_FUSE', '0', STEP), ('IDF_WGRAD_BATCH', '0', STEP), ('IDF_DETERMINISTIC', '1', STEP),
+    ('IDF_BWD_LAZY', '1', STEP), ('IDF_DGRAD_GN', '0', STEP), ('IDF_SC_FUSE', '0', STEP), ('IDF_WGRAD_BATCH', '0', STEP), ('IDF_DETERMINISTIC', '0', STEP),
     ('IDF_ATTN_FOLD', '0', STEP), ('IDF_ATTN_BLOCK_MINB', '1', STEP), ('IDF_UPCONV', '0', STEP), ('IDF_TEMB_FUSED', '0', STEP),
     # the library's own
     ('IDF_CONV_RS_SYNC', '0', STEP), ('IDF_CONV_PS', '0', STEP), ('IDF_CONV_DLDS_MIN', '1', STEP), ('IDF_WGRAD_KR3', '0', STEP), ('IDF_WGRAD_TPB3', '32', STEP),

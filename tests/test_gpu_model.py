@@ -1055,10 +1055,11 @@ def test_data_parallel_path_one_rank_rccl_matches_no_exchange(tag, dtype):
 
 
 def test_deterministic_mode_gives_bit_identical_training_steps():
-    """ops.set_deterministic(True) -- what utils.seed_everything switches on, as the reference's sets cudnn.deterministic
-    (utils.py:64-71): two runs of the benchmarked configuration (CelebA, bf16, dropout on, B = 8, eager steps, the captured step and
+    """ops.set_deterministic(True) -- the default from round 5 on (and what utils.seed_everything asks for, as the reference's
+    sets cudnn.deterministic, utils.py:64-71): two runs of the benchmarked configuration (CelebA, bf16, dropout on, B = 8, eager steps, the captured step and
     replays through GraphedTrainStep) give the SAME BITS in every loss, every gradient norm and every parameter after 6 steps;
-    the default mode (fp32 atomics in the weight-gradient and GroupNorm-parameter accumulations) is only required to train."""
+    the atomic forms (ops.set_deterministic(False): fp32 atomics in the weight-gradient and GroupNorm-parameter accumulations)
+    are only required to train."""
     from infodiffusion_amd import ops
     from infodiffusion_amd.optim import FusedClipAdamW
     from infodiffusion_amd.trainer import GraphedTrainStep

@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned long long rs_now() {
 // 1 -> a 256-thread workgroup owns one half-width tile (R rows x W / 2 columns = 128 pixels), TWO independent workgroups per CU:
 // while one sits in its epilogue (vector pipe) the other runs its MFMA loop on the same SIMDs, and a barrier stalls four waves,
 // not eight.
+#ifndef IDF_RS_REUSE
+#define IDF_RS_REUSE 1      // (A/B: tools/build_variant.sh noreuse idf_conv_rs.hip -DIDF_RS_REUSE=0)
+#endif
 template <int W, int NPH>
 struct RsGeo {
   static constexpr int R = 256 / W, TW = W * NPH / 2, WH = TW + 2, HR = R + 2, NPH_ = NPH, NPHW = HR * WH;
@@ -256,12 +259,14 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     ix = x0 + (side ? TW : -1);
     return ev < NEV;
   };
-  auto issue_rows = [&](int bb, int oy, int x0) __attribute__((always_inline)) {
+  // reuse: the tile lies right below the one in LDS (same image half): its halo rows 0 and 1 ARE that image's rows R and R + 1 --
+  // already transformed -- and move inside LDS (copy_rows); only rows 2 .. R + 1 are fetched and transformed (4 of 6 at 64x64)
+  auto issue_rows = [&](int bb, int oy, int x0, bool reuse = false) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
-      const int iy = oy + k * RPK + prl - 1;
+      const int ly = k * RPK + prl, iy = oy + ly - 1;
       rows[k] = u32x4_t{0, 0, 0, 0};
-      if ((unsigned)iy < (unsigned)p.H)
+      if ((unsigned)iy < (unsigned)p.H && !(reuse && ly < 2))
         rows[k] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + x0 + ppx) * CIN + piece * 8));
     }
 #pragma unroll
@@ -270,14 +275,32 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
       const bool in = edge_slot(j, ly, hx, ix, ep, x0);
       const int iy = oy + ly - 1;
       edge[j] = u32x4_t{0, 0, 0, 0};
-      if (in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W)
+      if (in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W && !(reuse && ly < 2))
         edge[j] = *reinterpret_cast<const u32x4_t*>(p.x + (unsigned)(((bb * p.H + iy) * W + ix) * CIN + ep * 8));
+    }
+  };
+  // rows R, R + 1 of every chunk image -> rows 0, 1 (whole rows incl. the halo columns: the swizzle depends on the column only).
+  // Every wave is past its last fragment read (the caller's barrier); the barrier inside separates the reads of rows R, R + 1 from
+  // the caller's write_rows, which overwrites them
+  auto copy_rows = [&]() __attribute__((always_inline)) {
+    constexpr int VR = 2 * WH * 4, CV = NCH * VR, NCV = (CV + NT - 1) / NT;      // 16-byte vectors per chunk / in all / per thread
+    u32x4_t cp[NCV];
+#pragma unroll
+    for (int j = 0; j < NCV; ++j) {
+      const int idx = tid + j * NT, c = idx / VR, r = idx - c * VR;
+      if (idx < CV) cp[j] = *reinterpret_cast<const u32x4_t*>(smem + c * CHB + R * WH * 64 + r * 16);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < NCV; ++j) {
+      const int idx = tid + j * NT, c = idx / VR, r = idx - c * VR;
+      if (idx < CV) *reinterpret_cast<u32x4_t*>(smem + c * CHB + r * 16) = cp[j];
     }
   };
   uint64_t seedv = 0;
   bool drop = false;
   if (PRO) { drop = p.act == 2 && p.seed != nullptr; if (drop) seedv = *p.seed; }
-  auto write_rows_t = [&](auto silu_c, auto drop_c, int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
+  auto write_rows_t = [&](auto silu_c, auto drop_c, int bb, int oy, int x0, bool keep_a, bool reuse) __attribute__((always_inline)) {
     constexpr bool SILU = decltype(silu_c)::value, DROP = decltype(drop_c)::value;
     float scv[8], shv[8];
     auto coefs = [&](int pc) __attribute__((always_inline)) {
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
         int ly, hx, ix, ep;
         const bool in = edge_slot(j, ly, hx, ix, ep, x0);
         const int iy = oy + ly - 1;
-        if (in) {
+        if (in && !(reuse && ly < 2)) {
           u32x4_t v = edge[j];
           if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W) {
             coefs(ep);
@@ -311,13 +334,14 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         int ly, hx, ix, ep;
-        if (edge_slot(j, ly, hx, ix, ep, x0))
+        if (edge_slot(j, ly, hx, ix, ep, x0) && !(reuse && ly < 2))
           *reinterpret_cast<u32x4_t*>(smem + (ep >> 2) * CHB + (ly * WH + hx) * 64 + (((ep & 3) ^ (((hx >> 2) & 1) << 1)) << 4)) = edge[j];
       }
     }
 #pragma unroll
     for (int k = 0; k < HV; ++k) {
       const int ly = k * RPK + prl, iy = oy + ly - 1, hx = ppx + 1;
+      if (reuse && ly < 2) continue;
       u32x4_t v = rows[k];
       if constexpr (PRO) {
         if ((unsigned)iy < (unsigned)p.H) {            // rows outside the image stay zero (the reference pads the ACTIVATED tensor)
@@ -332,12 +356,12 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     }
   };
   // the activation / dropout switches are launch-uniform: one branch per tile, straight-line bodies
-  auto write_rows = [&](int bb, int oy, int x0, bool keep_a) __attribute__((always_inline)) {
+  auto write_rows = [&](int bb, int oy, int x0, bool keep_a, bool reuse = false) __attribute__((always_inline)) {
     using T = std::true_type;
     using F = std::false_type;
-    if (!PRO || p.act != 2) write_rows_t(F{}, F{}, bb, oy, x0, keep_a);
-    else if (drop) write_rows_t(T{}, T{}, bb, oy, x0, keep_a);
-    else write_rows_t(T{}, F{}, bb, oy, x0, keep_a);
+    if (!PRO || p.act != 2) write_rows_t(F{}, F{}, bb, oy, x0, keep_a, reuse);
+    else if (drop) write_rows_t(T{}, T{}, bb, oy, x0, keep_a, reuse);
+    else write_rows_t(T{}, F{}, bb, oy, x0, keep_a, reuse);
   };
 
   RS_DECL;
@@ -537,7 +561,10 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     const bool refold = PRO && has_next && nb != b;       // the workgroup crosses into the next image (never at one or two tiles per CU)
     // (ALIAS && SYN: the rows would sit in registers across the tail, the wait and the apply -- 40 of them at 128 channels; that
     // form runs one round at the training shapes, so its next tile, when there is one, is fetched behind the apply instead)
-    if (has_next && !(ALIAS && SYN)) issue_rows(nb, noy0, nhalf * TW);
+    // the next tile right below this one in the same image half (and no a_out to write for its first row): rows 0, 1 come from LDS
+    const bool keep_next = PRO && p.a_out != nullptr && nn0 == 0;
+    const bool reuse = IDF_RS_REUSE && !ALIAS && has_next && nb == b && nhalf == half && noy0 == oy0 + R && !keep_next && !refold;
+    if (has_next && !(ALIAS && SYN)) issue_rows(nb, noy0, nhalf * TW, reuse);
     RS_STAMP(tt1);
     RS_ADD(4, tt0, tt1);
 
@@ -604,7 +631,8 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     }
     if (!ALIAS && has_next) {
       if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
-      write_rows(nb, noy0, nhalf * TW, PRO && p.a_out != nullptr && nn0 == 0);
+      if (reuse) copy_rows();
+      write_rows(nb, noy0, nhalf * TW, keep_next, reuse);
     }
     RS_STAMP(tt4);
     RS_ADD(7, tt3, tt4);

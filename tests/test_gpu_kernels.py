@@ -646,6 +646,11 @@ def test_conv_rs_groupnorm_prologue_conv_vs_pytorch(case, monkeypatch):
     finally:
         ops.call = orig
     assert names == ['idf_conv_rs_gn_bf16'], names
+    # inference (no activated-tensor output): a workgroup that walks down an image half keeps the two halo rows it shares with the
+    # tile above in LDS instead of fetching and transforming them again -- the same bits
+    y_inf = ops.conv_gn_raw(x1, None, st1, None, gam, bet, ft, fa, seed, 7, p_drop, 2, sh_.val[0], bias, res, Cout, 9, keep_a=False,
+                            keep_coef=False, want_stats=False, shadows=sh_)[0]
+    assert torch.equal(y_inf, y)
     u = F.group_norm(x1.float(), 32, gam, bet, eps=1e-5)
     if film:
         u = u * (1 + ft[:, :C, None, None]) + ft[:, C:, None, None]

@@ -214,6 +214,8 @@ int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream);
  *                                [B,H,W,Cin], w_frag = fragment-major data-gradient weights, x | x2 = the GroupNorm input
  *                                [B,H,W,Cout] (C1 % 64 == 0), out = du, part_out [B][T][Cout][2]. */
 int idf_conv_rs_tiles(int B, int H, int W, int Cin, int Cout);
+int idf_conv_rs_fwd_tiles(int B, int H, int W, int Cin, int Cout);   /* T of idf_conv_rs_gn_bf16's st_out: twice idf_conv_rs_tiles where the forward conv
+                                                                        computes both cout tiles of a pixel tile from one halo image (32x32, Cout = 128) */
 int idf_conv_rs_gn_bf16(const void* x, const float* st1, int T1, const float* gamma, const float* beta, const float* film_t,
                         const float* film_a, int ld_t, int ld_a, float eps, int act, const uint64_t* seed, uint32_t salt,
                         float p_drop, const void* w_frag, const float* bias, const void* res, void* y, void* a_out, float* mean,

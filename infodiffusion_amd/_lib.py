@@ -63,6 +63,7 @@ SIGNATURES = {
     'idf_resblock_small_ok': ([_i] * 7, C.c_int),
     'idf_conv_wr_tiles': ([_i] * 6, C.c_int),
     'idf_conv_rs_tiles': ([_i] * 5, C.c_int),
+    'idf_conv_rs_fwd_tiles': ([_i] * 5, C.c_int),
     'idf_conv_rs_gn_bf16': ([_p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _u32, _f] + [_p] * 10 + [_i] * 5 + [_p], C.c_int),
     'idf_conv_rs_dgrad_chain_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i, _p, _p] + [_i] * 5 + [_p], C.c_int),
     'idf_conv_rs_dgrad_gn_tiles': ([_i] * 5, C.c_int),

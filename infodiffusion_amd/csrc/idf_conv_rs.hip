@@ -66,9 +66,12 @@ __device__ __forceinline__ unsigned long long rs_now() {
 #ifndef IDF_RS_REUSE
 #define IDF_RS_REUSE 1      // (A/B: tools/build_variant.sh noreuse idf_conv_rs.hip -DIDF_RS_REUSE=0)
 #endif
-template <int W, int NPH>
+// SH ("shared image", Cout = 128 on the 32x32 maps): a workgroup computes BOTH 64-cout tiles of its pixel tile from ONE halo image
+// -- the GroupNorm prologue transforms the tile once instead of once per cout tile (the transform is 40 % of such a launch) --
+// on half-height tiles (R = 4 rows), so the launch keeps its number of workgroups.
+template <int W, int NPH, bool SH = false>
 struct RsGeo {
-  static constexpr int R = 256 / W, TW = W * NPH / 2, WH = TW + 2, HR = R + 2, NPH_ = NPH, NPHW = HR * WH;
+  static constexpr int R = (SH ? 128 : 256) / W, TW = W * NPH / 2, WH = TW + 2, HR = R + 2, NPH_ = NPH, NPHW = HR * WH;
   static constexpr int CHB = NPHW * 64 + ((NPHW * 64) % 128 == 0 ? 64 : 0);     // bytes of one 32-channel chunk image; == 64 (mod 128): the
                                                 // two chunks a ds_write_b128 lane group covers fall into different halves of the 32 store banks
   static constexpr int NCB = W / 32;            // 16-pixel column blocks per wave
@@ -78,6 +81,7 @@ struct RsGeo {
   }
   static_assert(W == 64 || W == 32, "64x64 / 32x32 maps");
   static_assert(NPH == 1 || NPH == 2, "one or two pixel halves");
+  static_assert(!SH || (W == 32 && NPH == 1), "shared-image form: 32x32 maps, two workgroups per CU");
 };
 
 // (mean, rstd) of a group from (sum, sum of squares): idf_resblock.hip's group_stats (mu / var in double, 1 / sqrt as v_rsq_f32 +
@@ -102,9 +106,10 @@ __device__ __forceinline__ void rs_group_stats(double a, double d, double inv_n,
 // an `sc1` poll by that wave, the workgroup's barrier, `sc1` loads.  The counter only ever grows (64 per completed group, whatever
 // the group size), so no launch has to zero it and a replayed graph needs no per-launch state; the spin is bounded (a workgroup
 // that gives up raises *rs_sync_err and the host reports it: results of that launch are garbage, the process does not hang).
-template <int W, int CIN, bool PRO, int EPI, int NPH>
+template <int W, int CIN, bool PRO, int EPI, int NPH, bool SH = false>
 __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
-  using G = RsGeo<W, NPH>;
+  using G = RsGeo<W, NPH, SH>;
+  static_assert(!SH || EPI == 0, "shared-image form: the plain epilogue");
   constexpr int R = G::R, TW = G::TW, WH = G::WH, HR = G::HR, CHB = G::CHB, NCB = G::NCB, TWS = G::TWS;
   constexpr int NT = 256 * NPH, BM = R * TW, BN = 64, KP = CIN / 64, NCH = CIN / 32;
   constexpr int PIECES = CIN / 8, PXK = NT / PIECES, HV = HR * TW * PIECES / NT;     // 16-byte vectors per pixel / pixels per round / rounds
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   // tile takes the images' place (the next tile's rows then wait in registers until the epilogue has read it)
   constexpr bool ALIAS = G::ALIAS_OS(CIN);
   static_assert(CIN == 64 || CIN == 128, "one or two 64-channel pairs");
+  static_assert(!SH || !G::ALIAS_OS(CIN), "shared-image form: the image must survive the epilogue");
   static_assert(PXK == RPK * TW && HV * RPK == HR, "whole halo rows per staging round");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -164,8 +170,10 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
   // item -> (cout tile, image, half, strip)
   int nt, b, half, oy0, n0;
   auto decode = [&](int it, int& nt_, int& b_, int& half_, int& oy_, int& n0_) __attribute__((always_inline)) {
-    nt_ = it / npt;
-    const int pt = it - nt_ * npt, bh = pt / TR;
+    int pt;
+    if constexpr (SH) { pt = it >> 1; nt_ = it & 1; }          // the two cout tiles of a pixel tile are consecutive items
+    else { nt_ = it / npt; pt = it - nt_ * npt; }
+    const int bh = pt / TR;
     oy_ = (pt - bh * TR) * R;
     b_ = halves == 2 ? bh >> 1 : bh; half_ = halves == 2 ? bh & 1 : 0;
     n0_ = nt_ * BN;
@@ -563,8 +571,9 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
     // form runs one round at the training shapes, so its next tile, when there is one, is fetched behind the apply instead)
     // the next tile right below this one in the same image half (and no a_out to write for its first row): rows 0, 1 come from LDS
     const bool keep_next = PRO && p.a_out != nullptr && nn0 == 0;
-    const bool reuse = IDF_RS_REUSE && !ALIAS && has_next && nb == b && nhalf == half && noy0 == oy0 + R && !keep_next && !refold;
-    if (has_next && !(ALIAS && SYN)) issue_rows(nb, noy0, nhalf * TW, reuse);
+    const bool same_img = SH && has_next && (item >> 1) == ((item + 1) >> 1);     // SH: the other cout tile of the image in LDS
+    const bool reuse = IDF_RS_REUSE && !SH && !ALIAS && has_next && nb == b && nhalf == half && noy0 == oy0 + R && !keep_next && !refold;
+    if (has_next && !(ALIAS && SYN) && !same_img) issue_rows(nb, noy0, nhalf * TW, reuse);
     RS_STAMP(tt1);
     RS_ADD(4, tt0, tt1);
 
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
           *reinterpret_cast<float4*>(O + pl * PF + cg * 16 + fq * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
     }
-    if (!ALIAS && has_next) {
+    if (!ALIAS && has_next && !same_img) {
       if (refold) { FoldRegs f1; fold_finish(nb, noy0 == 0 && nn0 == 0 && nhalf == 0, false, f1); }
       if (reuse) copy_rows();
       write_rows(nb, noy0, nhalf * TW, keep_next, reuse);
@@ -700,6 +709,14 @@ int rs_tiles(int B, int H, int W, int Cin, int Cout) {
   return g_rs == 2 ? T : 2 * T;
 }
 
+// the forward GroupNorm-prologue conv takes the shared-image form (half-height tiles, both cout tiles per workgroup) where the map is
+// 32x32 and Cout = 128: T doubles
+bool rs_fwd_shared(int W, int Cout) { return g_rs == 1 && W == 32 && Cout == 128; }
+int rs_fwd_tiles(int B, int H, int W, int Cin, int Cout) {
+  const int T = rs_tiles(B, H, W, Cin, Cout);
+  return (T && rs_fwd_shared(W, Cout)) ? 2 * T : T;
+}
+
 int rs_ncu() {
   static const int ncu = [] {
     int dev = 0;
@@ -715,14 +732,15 @@ int rs_ncu() {
 // that share a state array must not overlap (the package keeps one per device and issues its compute on one stream)
 constexpr int RS_SYNC_MAX = 8192;
 
-template <int W, int CIN, bool PRO, int EPI, int NPH>
+template <int W, int CIN, bool PRO, int EPI, int NPH, bool SH = false>
 int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
-  using G = RsGeo<W, NPH>;
+  using G = RsGeo<W, NPH, SH>;
   constexpr int halves = 3 - NPH;
   p.R = G::R; p.rs_halves = halves; p.tiles_per_img = (p.H / G::R) * halves; p.n_tiles = p.Cout / 64;
   p.rs_total = p.B * p.tiles_per_img * p.n_tiles;
   const int slots = rs_ncu() * halves;               // workgroups resident at once
   p.rs_per = idf_cdiv(p.rs_total, slots);
+  if (SH) { if (p.n_tiles != 2) return 8; p.rs_per += p.rs_per & 1; }        // both cout tiles of a pixel tile in one workgroup
   int grid = idf_cdiv(p.rs_total, p.rs_per);
   if (EPI == 3) {
     if (W == 64) {
@@ -749,7 +767,7 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
   p.rs_cof_off = (int)lds;
   if (PRO) lds += (size_t)CIN * 16;
   if (lds > 160 * 1024 / halves) return 1;
-  auto kern = conv_rs_bf16<W, CIN, PRO, EPI, NPH>;
+  auto kern = conv_rs_bf16<W, CIN, PRO, EPI, NPH, SH>;
   static IdfLdsGrant grant;
   if (idf_ensure_lds((const void*)kern, lds, grant) != hipSuccess) return 2;
   if (EPI == 3) {
@@ -792,6 +810,9 @@ int dispatch_rs(C3P& p, hipStream_t st) {
 // covers a stride-1 3x3 conv of this shape, else 0: square 64x64 maps with 64 input channels, 32x32 maps with 64 or 128,
 // Cout % 64 == 0, at least IDF_CONV_RS_MIN (128) work items of 256 pixels x 64 couts.
 extern "C" int idf_conv_rs_tiles(int B, int H, int W, int Cin, int Cout) { return rs_tiles(B, H, W, Cin, Cout); }
+// ... and T of the statistics partials idf_conv_rs_gn_bf16 writes (the forward conv's tiles are half as high where it computes both cout
+// tiles of a pixel tile from one halo image: 32x32 maps, Cout = 128)
+extern "C" int idf_conv_rs_fwd_tiles(int B, int H, int W, int Cin, int Cout) { return rs_fwd_tiles(B, H, W, Cin, Cout); }
 
 // y = conv3x3(dropout(SiLU(FiLM(GroupNorm(x))))) + bias (+ res): idf_conv_gn_bf16's contract (taps 9, one source) with the weights
 // fragment-major (idf_pack_conv_weights_batched's w_frag: [Cin / 64][Cout / 16][tap][half][lane][8]).  T1 <= 32.
@@ -817,7 +838,10 @@ extern "C" int idf_conv_rs_gn_bf16(const void* x, const float* st1, int T1, cons
   p.dscale = 1.0f / (1.0f - (float)p.thr / 65536.0f);
   p.seed = (act == 2 && p_drop > 0.f) ? seed : nullptr;
   p.a_out = (bf16_t*)a_out; p.mean_out = mean; p.rstd_out = rstd; p.sc_out = sc; p.sh_out = sh;
-  if (int rc = dispatch_rs<true, 0>(p, (hipStream_t)stream)) IDF_FAIL(IDF_ERR_HIP, "conv_rs_gn_bf16: launch refused (%d)", rc);
+  int rc;
+  if (rs_fwd_shared(W, Cout)) rc = Cin == 128 ? launch_rs<32, 128, true, 0, 1, true>(p, (hipStream_t)stream) : launch_rs<32, 64, true, 0, 1, true>(p, (hipStream_t)stream);
+  else rc = dispatch_rs<true, 0>(p, (hipStream_t)stream);
+  if (rc) IDF_FAIL(IDF_ERR_HIP, "conv_rs_gn_bf16: launch refused (%d)", rc);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -253,6 +253,13 @@ def rs_tiles(B, H, W, Cin, Cout):
     return int(_lib.load().idf_conv_rs_tiles(B, H, W, Cin, Cout))
 
 
+@functools.lru_cache(maxsize=None)
+def rs_fwd_tiles(B, H, W, Cin, Cout):
+    """T of the statistics partials idf_conv_rs_gn_bf16 writes (half-height tiles where the forward conv computes both cout tiles of
+    a pixel tile from one halo image: 32x32 maps with Cout = 128)."""
+    return int(_lib.load().idf_conv_rs_fwd_tiles(B, H, W, Cin, Cout))
+
+
 def _rs_frag(shadows, j, B, H, W, Cin, Cout):
     """The fragment-major shadow j (2 forward, 3 data gradient) when idf_conv_rs_* covers the shape and the shadow exists; a conv
     met here for the first time is asked for one (it comes with the re-pack at the end of this forward pass / the next one)."""
@@ -294,12 +301,14 @@ def conv_gn_raw(x, x2, st1, st2, gn_w, gn_b, film_t, film_a, seed, salt, p_drop,
     # vector-bound either way (29.4 vs 28.2 us, 28.3 vs 27.8 us: profiles/r05_conv_rs.txt) and the older kernels stay
     # ... and every covered shape in inference (no activated tensor kept: DDIM-100 at B = 256 335 -> 349 img/s, the coefficient fold
     # runs once per workgroup and image half instead of in a launch of its own)
+    # round 5, later: at Cout = 128 on the 32x32 maps a workgroup computes BOTH cout tiles from one halo image (the transform runs once
+    # per tile instead of twice): that form takes 128->128 in training too
     if (taps == 9 and x2 is None and shortcut is None and x.dtype == torch.bfloat16 and st1.shape[1] <= 32
-            and (_RS_FWD_ALL or Cin != Cout or not keep_a)):
+            and (_RS_FWD_ALL or Cin != Cout or not keep_a or (W == 32 and Cout == 128 and _RS_SHARED))):
         rfrag = _rs_frag(shadows, 2, B, H, W, Cin, Cout)
     if rfrag is not None:
         # 64x64 / 32x32: weights fragment-major into registers, whole-K halo image in LDS, row reuse, persistent over the CU's tiles
-        st = torch.empty((B, rs_tiles(B, H, W, Cin, Cout), Cout, 2), dtype=torch.float32, device=dev) if (want_stats and Cout % 8 == 0) else None
+        st = torch.empty((B, rs_fwd_tiles(B, H, W, Cin, Cout), Cout, 2), dtype=torch.float32, device=dev) if (want_stats and Cout % 8 == 0) else None
         call('idf_conv_rs_gn_bf16', _p(x), _p(st1), st1.shape[1], _p(gn_w), _p(gn_b), _p(film_t), _p(film_a), _ld(film_t), _ld(film_a),
              GN_EPS, act, _p(seed), salt, float(p_drop), _p(rfrag), _p(bias), _p(residual), _p(y), _p(a), _p(mean), _p(rstd), _p(sc),
              _p(sh), _p(st), B, H, W, Cin, Cout, _st())
@@ -761,6 +770,7 @@ def conv_dgrad_chain_raw(dy, w_dgrad, taps, Cout, lazy=None, want_dy=False, x=No
     return out, part, dy_mat
 
 
+_RS_SHARED = True      # (A/B: the 128->128 @32x32 forward conv of a training step on the shared-image form; False: halo kernel)
 _RS_SYNC = [True]     # the trainer turns the form off around launches that share the chip with a collective (sync_convs)
 
 

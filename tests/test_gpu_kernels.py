@@ -632,8 +632,9 @@ def test_conv_rs_groupnorm_prologue_conv_vs_pytorch(case, monkeypatch):
     res = rnd(9, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL) if with_res else None
     seed = torch.tensor([123456789], dtype=torch.int64, device=DEV) if p_drop else None
     sh_ = _FragShadows(w)
-    T = ops.rs_tiles(B, H, H, C, Cout)
-    assert T in (H // (256 // H), 2 * (H // (256 // H))), (case, T)      # whole-row tiles, or two half-width tiles per strip
+    T = ops.rs_fwd_tiles(B, H, H, C, Cout)
+    base = H // (256 // H)          # whole-row tiles; two half-width tiles per strip; half-height tiles where both cout tiles share an image
+    assert T in (base, 2 * base, 4 * base) and (T == 4 * base) == (H == 32 and Cout == 128 and ops.rs_tiles(B, H, H, C, Cout) == 2 * base), (case, T)
     st1 = ops.gn_partials_raw(x1)
     if st1.shape[1] > 16:         # the form takes what a conv producer leaves: <= 16 partials per image (regrouped sums are partials too)
         st1 = st1.view(B, 16, st1.shape[1] // 16, C, 2).sum(dim=2).contiguous()

@@ -109,6 +109,9 @@ __device__ __forceinline__ void fold_channel(const float* chs, int c, int C, int
   }
 }
 
+#ifndef IDF_RB_WARM
+#define IDF_RB_WARM 8        // helper workgroups per launch that pull the block's weights into L2 (0: none)
+#endif
 struct RbK { IdfResblockArgs a; uint32_t thr; float dscale; };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for every
@@ -154,6 +157,25 @@ __global__ __launch_bounds__(NT) void resblock8_fwd_kernel(const RbK k_in) {
 
   const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (b >= p.B) {
+    // helper workgroups (IDF_RB_WARM of them behind the images', one per XCD when B % 8 == 0; they land on CUs the 32 image workgroups
+    // leave idle): pull the block's weights into this XCD's L2 -- one dword per 128-byte line, results discarded -- while the image
+    // workgroups run their input stage.  In a training step the 0.9 MB were last touched a step ago: cold block 29.1 us, warm 23.8
+    // (tools/bench_resblock_cold.py).  (Warm-up loads issued by the image workgroups themselves lost: the vector memory pipe returns in
+    // order, so every real load queued behind the warm-up's HBM round trips.)
+    auto warm_all = [&](const void* w, int bytes) __attribute__((always_inline)) {
+      const char* base = reinterpret_cast<const char*>(w);
+      for (int off = tid * 128; off < bytes; off += NT * 128) {
+        unsigned d;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(base + off) : "memory");
+      }
+    };
+    warm_all(p.s[0].w, 128 * 9 * Cin * 2);
+    warm_all(p.s[1].w, 128 * 9 * BN * 2);
+    if (p.nstage == 3) warm_all(p.s[2].w, 128 * 9 * BN * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   RB_STAMP(t_begin);
   const int fr = lane & 15, fq = lane >> 4;
   const int wn0 = wave * 16;                                 // this wave's 16 couts
@@ -440,6 +462,20 @@ __global__ __launch_bounds__(NT) void resblock8_bwd_kernel(const RbBK k_in) {
   unsigned char* const Abuf = smem;                         // [4 chunks][HROWS][WH][PPB]: the current stage's dy
   const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (b >= p.B) {                                            // helper workgroups: the stages' weights into this XCD's L2 (see the forward kernel)
+    auto warm_all = [&](const void* w) __attribute__((always_inline)) {
+      const char* base = reinterpret_cast<const char*>(w);
+      for (int off = tid * 128; off < 128 * 9 * BN * 2; off += NT * 128) {
+        unsigned d;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(base + off) : "memory");
+      }
+    };
+    if (p.nstage == 3) warm_all(p.s[2].w_frag);
+    if (p.nstage >= 2 && p.first <= 1) warm_all(p.s[1].w_frag);
+    if (p.first == 0) warm_all(p.s[0].w_frag);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   const int fr = lane & 15, fq = lane >> 4;
   const int c0 = wave * 16 + fq * 4;
   const bool drop_any = p.seed != nullptr;
@@ -1023,7 +1059,7 @@ extern "C" int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream)
   k.thr = idf_drop_thresh(p.p_drop);
   k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
   if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
-  hipLaunchKernelGGL(resblock8_fwd_kernel, dim3(p.B), dim3(NT), lds, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(resblock8_fwd_kernel, dim3(p.B + (p.w_layout == 1 ? IDF_RB_WARM : 0)), dim3(NT), lds, (hipStream_t)stream, k);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -1051,7 +1087,7 @@ extern "C" int idf_resblock_small_bwd(const IdfResblockBwdArgs* args, void* stre
   k.thr = idf_drop_thresh(p.p_drop);
   k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
   if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
-  hipLaunchKernelGGL(resblock8_bwd_kernel, dim3(p.B), dim3(NT), lds, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(resblock8_bwd_kernel, dim3(p.B + IDF_RB_WARM), dim3(NT), lds, (hipStream_t)stream, k);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

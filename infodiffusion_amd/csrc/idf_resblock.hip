@@ -110,7 +110,8 @@ __device__ __forceinline__ void fold_channel(const float* chs, int c, int C, int
 }
 
 #ifndef IDF_RB_WARM
-#define IDF_RB_WARM 8        // helper workgroups per launch that pull the block's weights into L2 (0: none)
+#define IDF_RB_WARM 8        // helper workgroups per launch that pull the block's weights into L2 (0: none); launches of up to 128 images
+                             // only: beyond that the image workgroups fill the chip and helpers would run on the launch's tail
 #endif
 struct RbK { IdfResblockArgs a; uint32_t thr; float dscale; };
 
@@ -1059,7 +1060,7 @@ extern "C" int idf_resblock_small_fwd(const IdfResblockArgs* args, void* stream)
   k.thr = idf_drop_thresh(p.p_drop);
   k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
   if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
-  hipLaunchKernelGGL(resblock8_fwd_kernel, dim3(p.B + (p.w_layout == 1 ? IDF_RB_WARM : 0)), dim3(NT), lds, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(resblock8_fwd_kernel, dim3(p.B + (p.w_layout == 1 && p.B <= 128 ? IDF_RB_WARM : 0)), dim3(NT), lds, (hipStream_t)stream, k);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }
@@ -1087,7 +1088,7 @@ extern "C" int idf_resblock_small_bwd(const IdfResblockBwdArgs* args, void* stre
   k.thr = idf_drop_thresh(p.p_drop);
   k.dscale = 1.0f / (1.0f - (float)k.thr / 65536.0f);
   if (!(p.p_drop > 0.f)) k.a.seed = nullptr;
-  hipLaunchKernelGGL(resblock8_bwd_kernel, dim3(p.B + IDF_RB_WARM), dim3(NT), lds, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(resblock8_bwd_kernel, dim3(p.B + (p.B <= 128 ? IDF_RB_WARM : 0)), dim3(NT), lds, (hipStream_t)stream, k);
   IDF_CHECK_LAUNCH();
   return IDF_OK;
 }

@@ -250,3 +250,18 @@ static inline hipError_t idf_zero_f32(float* p, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(idf_zero_f32_kernel, dim3(blocks), dim3(256), 0, st, p, n);
   return hipGetLastError();
 }
+
+// Helper workgroups of an under-filled launch: one dword per 128-byte line of [ptr, ptr + bytes) into this XCD's L2, results
+// discarded -- the launch's weights were last touched a training step ago and would arrive from HBM in front of every K chunk
+// (resblock8: cold 29.1 -> 24.3 us, profiles/r05_resblock_warm.txt).  Only where the main workgroups leave CUs idle: helpers of a
+// launch that fills the chip run on its tail and cost more than they bring.
+__device__ __forceinline__ void idf_warm_lines(const void* ptr, int bytes, int tid, int nthreads) {
+  const char* base = reinterpret_cast<const char*>(ptr);
+  for (int off = tid * 128; off < bytes; off += nthreads * 128) {
+    unsigned d;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(base + off) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+constexpr int IDF_WARM_HELPERS = 8, IDF_WARM_MAX_MAIN = 128;     // helpers per launch; main workgroups up to which a launch gets them
+

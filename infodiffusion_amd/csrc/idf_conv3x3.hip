@@ -37,8 +37,12 @@ template <int MODE, int TM, int BN, int NWM, int KS = 3, bool DUAL = false, bool
 __global__ __launch_bounds__(NWM * 128) void conv3x3_halo_bf16(const C3P p_in) {
   constexpr bool DYP = (BWD & 1) != 0, DUE = (BWD & 2) != 0;
   constexpr bool AUX_OK = MODE == 0 && KS == 3 && BN == 64 && !GNB && !DYP;     // instantiations that may carry an auxiliary job
+  if (p_in.hw_main > 0 && (int)blockIdx.x >= p_in.hw_main) {      // helper workgroups of an under-filled launch
+    idf_warm_lines(p_in.w, p_in.Cout * KS * KS * p_in.Cin * 2, threadIdx.x, NWM * 128);
+    return;
+  }
   C3P p = p_in;
-  int bid = p_in.aux_blocks > 0 ? (int)blockIdx.x : xcd_tile_id(blockIdx.x, gridDim.x);
+  int bid = p_in.aux_blocks > 0 ? (int)blockIdx.x : xcd_tile_id(blockIdx.x, p_in.hw_main > 0 ? p_in.hw_main : (int)gridDim.x);
   bool aux = false;
   if constexpr (AUX_OK) {
     if (p_in.aux_blocks > 0 && bid >= p_in.main_blocks) {       // block-uniform
@@ -1150,6 +1154,9 @@ void launch_dlds(C3P& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_per_img * p.n_tiles), dim3(512), lds, st, p);
 }
 
+#ifndef IDF_HALO_WARM
+#define IDF_HALO_WARM 1        // helper workgroups for under-filled conv3x3_halo_bf16 launches (A/B: -DIDF_HALO_WARM=0)
+#endif
 template <int MODE, int TM, int BN, int NWM = 2, int KS = 3, bool DUAL = false, bool PRO = false>
 void launch(C3P& p, hipStream_t st) {
   size_t lds = ((MODE == 1 ? (size_t)(2 * p.R + 1) * (2 * p.W + 1) : (size_t)(p.R + 2 * (KS / 2)) * (p.W + 2 * (KS / 2))) +
@@ -1162,7 +1169,9 @@ void launch(C3P& p, hipStream_t st) {
   IDF_ENSURE_LDS(kern, lds);
   p.main_blocks = p.B * p.tiles_per_img * p.n_tiles;
   if (!(MODE == 0 && KS == 3 && BN == 64)) p.aux_blocks = 0;           // (callers attach an auxiliary job only to these)
-  hipLaunchKernelGGL(kern, dim3(p.main_blocks + p.aux_blocks), dim3(NWM * 128), lds, st, p);
+  const int real = p.main_blocks + p.aux_blocks;
+  p.hw_main = (real <= IDF_WARM_MAX_MAIN && IDF_HALO_WARM) ? real : 0;
+  hipLaunchKernelGGL(kern, dim3(real + (p.hw_main ? IDF_WARM_HELPERS : 0)), dim3(NWM * 128), lds, st, p);
 }
 
 template <int TM, int NWM, int KS, int BN = 64>
@@ -1174,7 +1183,10 @@ void launch_gnb(C3P& p, hipStream_t st) {
   lds += (size_t)NWM * 2 * BN * 8 + BN * 8 + 32 * 8;                   // wave partials | per-channel products | per-group k1, k0
   auto kern = conv3x3_halo_bf16<0, TM, BN, NWM, KS, false, false, true>;
   IDF_ENSURE_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.n_tiles), dim3(NWM * 128), lds, st, p);
+  const int real = p.B * p.n_tiles;
+  p.aux_blocks = 0;
+  p.hw_main = (real <= IDF_WARM_MAX_MAIN && IDF_HALO_WARM) ? real : 0;
+  hipLaunchKernelGGL(kern, dim3(real + (p.hw_main ? IDF_WARM_HELPERS : 0)), dim3(NWM * 128), lds, st, p);
 }
 
 template <int TM, int NWM, int KS, int BWD>
@@ -1190,7 +1202,9 @@ void launch_bwd_chain(C3P& p, hipStream_t st) {
   IDF_ENSURE_LDS(kern, lds);
   p.main_blocks = p.B * p.tiles_per_img * p.n_tiles;
   if (!(KS == 3 && !(BWD & 1))) p.aux_blocks = 0;
-  hipLaunchKernelGGL(kern, dim3(p.main_blocks + p.aux_blocks), dim3(NWM * 128), lds, st, p);
+  const int real = p.main_blocks + p.aux_blocks;
+  p.hw_main = (real <= IDF_WARM_MAX_MAIN && IDF_HALO_WARM) ? real : 0;
+  hipLaunchKernelGGL(kern, dim3(real + (p.hw_main ? IDF_WARM_HELPERS : 0)), dim3(NWM * 128), lds, st, p);
 }
 
 void clear_pro(C3P& p) {

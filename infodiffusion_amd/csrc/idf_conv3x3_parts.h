@@ -60,6 +60,7 @@ struct C3P {
   // the block's first conv (forward: both read the block input) or its data gradient beside the first conv's (backward):
   // the input is staged raw (no prologue), only the centre tap is contracted, the epilogue is the plain one.
   int main_blocks, aux_blocks;
+  int hw_main;                  // conv3x3_halo_bf16: > 0 -- blocks >= hw_main are helper workgroups (idf_warm_lines over the launch's weights)
   const bf16_t* aux_x; const bf16_t* aux_x2; int aux_C1, aux_Cin;
   const bf16_t* aux_w;          // [aux_Cout][aux_Cin]
   const float* aux_bias; bf16_t* aux_y; int aux_Cout, aux_n_tiles;

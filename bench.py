@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-sampling', action='store_true', help='skip the DDIM-100 sampling measurement')
     ap.add_argument('--sampling-batch', type=int, default=256)
     ap.add_argument('--no-large-batch', action='store_true', help='skip the supplementary B=128 training rate')
+    ap.add_argument('--no-dp-probe', action='store_true', help='skip the one-rank data-parallel step (child process, IDF_FORCE_SYNC=1)')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -172,6 +173,79 @@ def pmc_traffic_file(names):
         return round(sum(v['launches'] * v['hbm_bytes_avg'] for v in ks) / n) if n else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def parity_file():
+    """The measured parity of the benchmarked configuration against the reference's fp32 outputs (tools/parity_summary.py on an
+    MI355X -> profiles/rNN_parity.json, latest round), or None: the tolerance the number is quoted at travels with the number."""
+    try:
+        files = sorted(fn for fn in os.listdir(os.path.join(ROOT, 'profiles')) if fn.endswith('_parity.json'))
+        with open(os.path.join(ROOT, 'profiles', files[-1])) as f:
+            d = json.load(f)
+        d['source'] = 'profiles/' + files[-1]
+        return d
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def dp_timeline(trainer, sync, pool, steps=10):
+    """Where a data-parallel step's time goes (N > 1, or IDF_FORCE_SYNC on one rank): HIP events around the three graphs on the
+    compute stream and around both all-reduces on the exchange stream, over `steps` extra replays OUTSIDE the timed region.
+    exchange_exposed_ms = compute-stream time between the end of G2 and the start of G3 (the join: whatever of either collective
+    the encoder's backward pass did not cover, + the packed buckets)."""
+    if not isinstance(trainer.graph, tuple):
+        return None
+    trainer.trace, sync.trace = [], {'early': [], 'late': []}
+    for i in range(steps):
+        trainer(pool[i % len(pool)], 0)
+    torch.cuda.synchronize()
+    tr, st = trainer.trace, sync.trace
+    trainer.trace = sync.trace = None
+    tr = [m for m in tr if len(m) == 5]
+    if not tr:
+        return None
+
+    def med(v):
+        v = sorted(v)
+        return round(v[len(v) // 2], 4) if v else None
+    out = {'steps': len(tr),
+           'g1_fwd_backbone_bwd_ms': med([m[0].elapsed_time(m[1]) for m in tr]),
+           'g2_encoder_bwd_ms': med([m[1].elapsed_time(m[2]) for m in tr]),
+           'exchange_exposed_ms': med([m[2].elapsed_time(m[3]) for m in tr]),
+           'g3_clip_adamw_ms': med([m[3].elapsed_time(m[4]) for m in tr]),
+           'step_ms': med([m[0].elapsed_time(m[4]) for m in tr])}
+    for which in ('early', 'late'):
+        ev = st[which]
+        out['allreduce_%s_ms' % which] = med([a.elapsed_time(b) for a, b, _ in ev])
+        out['allreduce_%s_bytes' % which] = ev[0][2] if ev else None
+    if st['early'] and len(st['early']) == len(tr):
+        # how much of the early (backbone-slice) collective ran under G2: its end against G2's end on the compute stream
+        tail = [max(0.0, m[2].elapsed_time(e[1])) for m, e in zip(tr, st['early'])]
+        out['allreduce_early_tail_past_g2_ms'] = med(tail)
+    return out
+
+
+def one_rank_dp_cost(a):
+    """N = 1 only: the same bench in a CHILD process with IDF_FORCE_SYNC=1 (RCCL world size 1): the three-graph step with both
+    collectives, the synchronised convs off in the encoder's backward pass -- the kernel set and launch structure a rank of an
+    N > 1 run executes, minus the wire.  -> its ms_per_step and timeline (the expected per-rank step next to `value`)."""
+    env = dict(os.environ)
+    env['IDF_FORCE_SYNC'] = '1'
+    env.setdefault('MASTER_PORT', '29547')
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup),
+           '--no-roofline', '--no-sampling', '--no-large-batch', '--no-cpu-baseline', '--no-dp-probe',
+           '--batch', str(a.batch), '--a_dim', str(a.a_dim), '--dtype', a.dtype, '--graph', str(int(a.graph)),
+           '--fused-opt', str(int(a.fused_opt))]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+        d = json.loads(line)
+        return {'ms_per_step': d['ms_per_step'], 'ms_per_step_median': d.get('ms_per_step_median'), 'value': d['value'],
+                'timeline': d.get('dp_timeline'), 'ranks_seen': d.get('ranks_seen'),
+                'note': 'IDF_FORCE_SYNC=1 child process, RCCL world size 1: three graphs + two all-reduces per step, synchronised '
+                        'convs off in the encoder backward (trainer._shares_chip) -- the per-rank step of an N > 1 run without the wire'}
+    except Exception as e:  # noqa: BLE001
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
 
 class LaunchRecorder:
@@ -634,6 +708,12 @@ def main():
                    'last_grad_norm': None if gnorm is None else round(gnorm, 4)},
     }
 
+    par = parity_file()
+    if par is not None:
+        out['parity'] = par
+    if sync is not None:
+        out['ranks_seen'] = dist.get_world_size()       # after RCCL init: the ranks that actually take part in the exchange
+        out['dp_timeline'] = dp_timeline(trainer, sync, pool)
     if rank == 0 and not a.no_roofline:
         # dominant kernel family: the 3x3 convs (forward incl. the GroupNorm-prologue form, and data gradients)
         rec = LaunchRecorder()
@@ -698,8 +778,11 @@ def main():
         small_stats = dict(proc.graph_stats)
         # the reference's eval flows sample batch after batch (run.py:255-259, 284-287): the step graph of a batch shape is captured by
         # the first batch and replayed by the following ones -- the timed batch is such a following one
+        torch.cuda.synchronize()
+        t0 = time.time()
         proc.sampling(a.sampling_batch)
         torch.cuda.synchronize()
+        ds_first = time.time() - t0
         if world > 1:
             dist.barrier()
         before = dict(proc.graph_stats)
@@ -717,6 +800,10 @@ def main():
                                      'step graph was captured by the preceding, untimed batch of the same shape)' % a.sampling_batch,
                            'value': round(a.sampling_batch * world / ds, 2), 'unit': 'images/s', 'n_gpus': world,
                            'seconds': round(ds, 3),
+                           # the batch before it: the first of its shape in the process (step-graph capture + first-touch costs inside;
+                           # rounds <= 4 reported THIS kind of number -- compare like with like)
+                           'first_batch': {'value': round(a.sampling_batch * world / ds_first, 2), 'seconds': round(ds_first, 3),
+                                           'note': 'first batch of this shape (capture of the step graph included; this rank)'},
                            # inner steps replayed from a captured step (98 of the 100: first and last run eagerly)?
                            'graphed': big_stats['replays'] > 0 and proc.graph_stats['fallback'] == 0,
                            'graph_stats': {'warmup_b8': small_stats, 'timed_batch': big_stats}}
@@ -749,6 +836,10 @@ def main():
             out['atomics_value'] = {'value': r['value'], 'unit': 'images/s', 'ms_per_step': r['ms_per_step'],
                                     'note': 'same step with fp32 atomics for the weight gradients and the GroupNorm parameter gradients '
                                             '(ops.set_deterministic(False)); `value` is the bit-reproducible default, B=%d, graph replay' % a.batch}
+    if rank == 0 and world == 1 and sync is None and not a.no_dp_probe:
+        out['dp_one_rank'] = one_rank_dp_cost(a)
+        if 'ms_per_step' in out['dp_one_rank']:
+            out['dp_one_rank']['delta_ms_vs_value'] = round(out['dp_one_rank']['ms_per_step'] - out['ms_per_step'], 3)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(margs)
     if dist.is_initialized():
@@ -757,7 +848,7 @@ def main():
     # workgroups of the synchronised data-gradient conv that ever gave up waiting for their group (a grid that was not resident at once):
     # a launch with a time-out computed garbage, so the run is void
     from infodiffusion_amd import ops as _ops
-    sync_timeouts = _ops.rs_sync_timeouts(False)
+    sync_timeouts = _ops.rs_sync_timeouts(False) + trainer.timeouts      # (the trainer's health check zeroes the word when it rolls back)
     out['config']['rs_sync_timeouts'] = sync_timeouts
     if rank == 0:
         # the LAST line of stdout: RCCL printf()s its version banner into the C library's stdout buffer, which would

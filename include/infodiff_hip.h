@@ -241,6 +241,10 @@ int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, const void* x,
                               float* dfilm_t, float* dfilm_a, float* dgb, float* dgam, float* dbet, uint32_t* sync_state, int B,
                               int H, int W, int Cin, int Cout, void* stream);
 int idf_conv_rs_sync_words(void);
+/* Diagnostic: polls a workgroup spends waiting for its group before it gives up and bumps the error word (default 2^21, about 2 s;
+ * 0 restores the default); returns the previous value.  Process-global, read at launch time.  For tests that provoke a time-out
+ * (a counter knocked off its multiple of 64) and assert that the training loop reports it (infodiffusion_amd/trainer.py). */
+unsigned idf_conv_rs_set_spin_limit(unsigned polls);
 
 /* Deterministic mode (/root/reference/utils.py:64-71): the GroupNorm affine gradients of a whole backward pass in ONE launch.
  * Every GroupNorm-backward entry above writes per-image rows dgb [B][2][C] when it is given no accumulation slots; table = n

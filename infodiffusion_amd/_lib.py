@@ -69,6 +69,7 @@ SIGNATURES = {
     'idf_conv_rs_dgrad_gn_tiles': ([_i] * 5, C.c_int),
     'idf_conv_rs_dgrad_gn_bf16': ([_p, _p, _p, _p, _i, _p, _p, _p, _u32, _f, _i] + [_p] * 9 + [_i, _i] + [_p] * 8 + [_i] * 5 + [_p], C.c_int),
     'idf_conv_rs_sync_words': ([], C.c_int),
+    'idf_conv_rs_set_spin_limit': ([C.c_uint], C.c_uint),
     'idf_gn_rows_desc_bytes': ([], C.c_int),
     'idf_gn_param_reduce_batched': ([_p, _i, _i, _p], C.c_int),
     'idf_conv_fewc_tiles': ([_i] * 5, C.c_int),

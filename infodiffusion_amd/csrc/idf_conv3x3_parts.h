@@ -76,7 +76,7 @@ struct C3P {
   int rs_per, rs_total, rs_os_off, rs_cof_off;
   // group-synchronised du epilogue (EPI 3): the GroupNorm backward applied in the launch -- y = dx (x | x2 sources: y | rs_dx2),
   // res / gnb_res2 = the residual-branch gradients (dense, Cout channels), dyp_f = the fold's parameters (part = st_out)
-  bf16_t* rs_dx2; unsigned* rs_sync; unsigned* rs_sync_err; int rs_stash_off;
+  bf16_t* rs_dx2; unsigned* rs_sync; unsigned* rs_sync_err; unsigned rs_spin_max; int rs_stash_off;
   int rs_x0, rs_tidx, rs_halves;   // half-width tiles (two 256-thread workgroups per CU): first column and statistics-tile index of the current tile; tiles per row strip
 };
 

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256 * NPH, 2) void conv_rs_bf16(const C3P p) {
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21)) { if (lane == 0) atomicAdd(p.rs_sync_err, 1u); break; }
+          if (++spins > p.rs_spin_max) { if (lane == 0) atomicAdd(p.rs_sync_err, 1u); break; }
         }
       } else { fetch_apply_operands(); fetch_prev_operands(); }
       lds_barrier();
@@ -718,19 +718,22 @@ int rs_fwd_tiles(int B, int H, int W, int Cin, int Cout) {
 }
 
 int rs_ncu() {
-  static const int ncu = [] {
-    int dev = 0;
+  // per device id (a process may drive more than one device; the count sizes the resident grid of the synchronised form)
+  static int ncu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!ncu[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }();
-  return ncu;
+    ncu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return ncu[dev];
 }
 
 // the group-synchronised form's state, owned by the caller (the library allocates nothing): RS_SYNC_MAX counters -- one per
 // (image, 64-channel slice) of a launch, zero when first handed in, only ever growing -- and behind them the error word; launches
 // that share a state array must not overlap (the package keeps one per device and issues its compute on one stream)
 constexpr int RS_SYNC_MAX = 8192;
+unsigned g_rs_spin_max = 1u << 21;   // polls a workgroup spends on its group before it gives up (idf_conv_rs_set_spin_limit)
 
 template <int W, int CIN, bool PRO, int EPI, int NPH, bool SH = false>
 int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
@@ -755,6 +758,7 @@ int launch_rs(C3P& p, hipStream_t st, bool probe = false) {
     if (64 % p.tiles_per_img || 64 % (p.Cout >> 5) || p.B * p.n_tiles > RS_SYNC_MAX) return 4;
     if (!probe && !p.rs_sync) return 5;
     p.rs_sync_err = p.rs_sync + RS_SYNC_MAX;
+    p.rs_spin_max = g_rs_spin_max;
   }
   size_t lds = (size_t)(CIN / 32) * G::CHB;
   const size_t osz = (size_t)G::R * G::TW * (64 + 4) * sizeof(float);
@@ -923,3 +927,12 @@ extern "C" int idf_conv_rs_dgrad_gn_bf16(const void* dy, const void* w_frag, con
 // ever gave up waiting for their group (0 in a healthy process; anything else: a launch's grid was not resident at once and its
 // results are garbage; zero the whole array to go on).
 extern "C" int idf_conv_rs_sync_words(void) { return RS_SYNC_MAX + 16; }
+
+// Diagnostic: the number of polls a workgroup of idf_conv_rs_dgrad_gn_bf16 spends waiting for its group before it gives up and bumps
+// the error word (default 2^21, ~2 s; 0 restores the default).  Tests that provoke a time-out (a counter knocked off its multiple of 64)
+// shorten it; returns the previous value.  Process-global, read at launch time.
+extern "C" unsigned idf_conv_rs_set_spin_limit(unsigned polls) {
+  const unsigned prev = g_rs_spin_max;
+  g_rs_spin_max = polls ? polls : (1u << 21);
+  return prev;
+}

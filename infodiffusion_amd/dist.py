@@ -51,6 +51,19 @@ class GradSync:
         self._plan = None       # [(flat buffer, [views shaped/strided like the grads], [grad indices])]
         self._cut = None        # arena offset (floats) where the early slice ends; None: no early slice
         self._early_done = False
+        # measurement only (bench.py at N > 1 / IDF_FORCE_SYNC): a dict {'early': [], 'late': []} that receives one HIP event pair
+        # per collective, recorded on the exchange stream around it
+        self.trace = None
+
+    def _timed(self, which, flat):
+        if self.trace is None or not flat.is_cuda:
+            self._reduce_mean(flat)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._reduce_mean(flat)
+        e1.record()
+        self.trace[which].append((e0, e1, flat.numel() * flat.element_size()))
 
     # ---------------------------------------------------------------- overlap with backward
     def attach(self, early_module):
@@ -100,7 +113,7 @@ class GradSync:
             if after is not None:                # a stream that is still producing part of the slice (deferred wgrad)
                 self._side.wait_stream(after)
             with torch.cuda.stream(self._side):
-                self._reduce_mean(flat[:self._cut])
+                self._timed('early', flat[:self._cut])
         self._early_done = True
 
     @torch.no_grad()
@@ -174,7 +187,7 @@ class GradSync:
             if use_side:
                 self._side.wait_stream(cur)
                 with torch.cuda.stream(self._side):
-                    self._reduce_mean(flat)
+                    self._timed('late', flat)
             else:
                 self._reduce_mean(flat)
         plan = self._make_plan(grads) if grads else []

@@ -446,8 +446,14 @@ class GnRowsBatch:
     pending = []       # (rows address, gamma slot address, beta slot address, B, C)
     keep = []          # tensors the pending launch reads (overflow rows)
     tables = {}        # sequence -> device table
+    _graph_bufs = []   # workspaces / tables whose addresses a captured graph holds: never freed, never evicted (as WgradBatch's)
     _cb_queued = False
     _task = -1
+
+    @classmethod
+    def _pin(cls, t):
+        if t is not None and not any(t is b for b in cls._graph_bufs):
+            cls._graph_bufs.append(t)
 
     @classmethod
     def rows(cls, views, B, C, dev):
@@ -457,6 +463,8 @@ class GnRowsBatch:
         n = B * 2 * C
         if cls.ws is not None and cls.ws.device == dev and cls.cursor + n <= cls.ws.numel():
             dgb = cls.ws[cls.cursor:cls.cursor + n].view(B, 2 * C)
+            if torch.cuda.is_current_stream_capturing():
+                cls._pin(cls.ws)          # the graph's launches write these rows at every replay: a later, larger pass must not free them
         else:
             dgb = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)     # first pass / overflow: a tensor of its own
             cls.keep.append(dgb)
@@ -495,9 +503,14 @@ class GnRowsBatch:
             for i, it in enumerate(items):
                 host[i] = it
             if len(cls.tables) >= 8:
-                cls.tables.pop(next(iter(cls.tables)))
+                for k in list(cls.tables):          # oldest first; a table a captured graph reads stays
+                    if not any(cls.tables[k] is b for b in cls._graph_bufs):
+                        cls.tables.pop(k)
+                        break
             tab = torch.from_numpy(host.view(np.uint8).copy()).to(torch.device('cuda', torch.cuda.current_device()))
             cls.tables[key] = tab
+        if torch.cuda.is_current_stream_capturing():
+            cls._pin(tab)
         call('idf_gn_param_reduce_batched', _p(tab), len(items), max(it[4] for it in items), _st())
         cls.keep = []
         if not torch.cuda.is_current_stream_capturing() and (cls.ws is None or cls.ws.numel() < cls.want):
@@ -792,6 +805,28 @@ class sync_convs:
 
 
 _RS_SYNC_STATE = {}     # device index -> the synchronised form's counters + error word (uint32, zero-initialised, persistent)
+_RS_SYNC_DEAD = [False]  # set for the rest of the process once a time-out was seen (retire_sync_convs): the form is not taken again
+
+
+def switch_state():
+    """The kernel-selection switches a captured graph bakes in (tests / A-B harnesses toggle them at run time): part of the key of
+    every graph that is kept across calls (sampling._graphed)."""
+    g = globals()
+    return tuple(g[k] if not isinstance(g[k], list) else tuple(g[k]) for k in (
+        '_FEWC', '_GN_FUSE', '_WR', '_WR_MAXB', '_RS', '_RS_FWD_ALL', '_RS_SHARED', '_SC_FUSE', '_RB_SMALL', '_RB_SMALL_MAXB',
+        '_RB_WFRAG', '_UPCONV', '_ATTN_FOLD', '_ATTN_BLOCK', '_ATTN_BLOCK_MINB', '_TEMB_FUSED'))
+
+
+def retire_sync_convs():
+    """After a time-out of the group-synchronised conv: never take that form again in this process (the chain + apply pair
+    replaces it -- workgroups that do not wait for each other) and clear the counters the failed launches left mid-count."""
+    _RS_SYNC_DEAD[0] = True
+    for st in _RS_SYNC_STATE.values():
+        st.zero_()
+
+
+def sync_convs_retired():
+    return _RS_SYNC_DEAD[0]
 
 
 def _rs_sync_state(dev):
@@ -821,7 +856,7 @@ def conv_dgrad_gn_sync_raw(dy, Cout, x, gamma, beta, film_t, film_a, mean, rstd,
     (conv_dgrad_chain_raw + gn_bwd_apply_raw, du never written) -> what gn_bwd_apply_raw returns, or None when the form does
     not cover the call."""
     B, Cin, H, W = dy.shape
-    if not (_RS_SYNC[0] and act and dy.dtype == torch.bfloat16 and shadows is not None):
+    if not (_RS_SYNC[0] and not _RS_SYNC_DEAD[0] and act and dy.dtype == torch.bfloat16 and shadows is not None):
         return None
     C1 = x.shape[1] if x2 is not None else 0
     if x2 is not None and C1 % 64:

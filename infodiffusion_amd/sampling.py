@@ -88,12 +88,35 @@ class _ProcessBase:
         return steps >= GRAPH_MIN_STEPS and x.shape[0] * per <= GRAPH_MAX_PIXELS \
             and not torch.cuda.is_current_stream_capturing()
 
+    def _graph_ident(self):
+        """What a kept step graph bakes in besides the shapes: the network object(s), their activation dtype, the addresses of
+        their weight shadows (ShadowSet.tkey changes when shadows are reallocated: dtype / device / layout changes) and the
+        kernel-selection switches -- a change of any of them must not replay the stale graph."""
+        sig = [ops.switch_state()]
+        for v in vars(self).values():
+            if isinstance(v, torch.nn.Module):
+                sig.append(id(v))
+                for m in v.modules():
+                    sig.append(getattr(m, 'act_dtype', None) if hasattr(m, 'act_dtype') else None)
+                    for name in ('_shadow_set', '_shadow_all'):
+                        ss = m.__dict__.get(name)
+                        if ss is not None:
+                            sig.append(hash(ss.tkey))
+        return tuple(sig)
+
+    def release_graphs(self):
+        """Drop the kept step graph(s) and with them the private pool that holds a network evaluation's activations (a B = 256
+        CelebA evaluation: GBs) -- call when a loop that samples now and then goes back to training."""
+        self._graphs.clear()
+
     def _graphed(self, x, eps_fn, mode, first, delta, count, eps_of=None, a=None):
         """Generator over `count` steps idx = first, first+delta, ...: the step is captured once and replayed.
         x must come from an eagerly executed step (weight shadows / allocator already warm).
         eps_of(a) -> eps_fn: given, the captured step reads the latent from a buffer of its own and the graph is kept for the
         next call with the same shapes (the reference's eval flows sample batch after batch: run.py:255-259, 284-287)."""
         key = (mode, first, delta, count, tuple(x.shape), None if a is None else tuple(a.shape))
+        if eps_of is not None:
+            key = key + (self._graph_ident(),)
         ent = self._graphs.get(key) if eps_of is not None else None
         if ent is not None:
             xs, idx_t, a_s, g = ent

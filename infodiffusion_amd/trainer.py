@@ -25,7 +25,17 @@ and trains eagerly -- the same three phases, uncaptured.  A batch whose shape di
 last, short batch of an epoch) runs eagerly, after which the step is captured afresh (the eager pass re-homes
 gradients the graph's kernels write).  Objectives whose draws are made on the host every step (--prior 10mix /
 roll: numpy samplers, models.py:654-657) are never captured; the KL capacity of --use_C lives in a device scalar
-refreshed per call, so its schedule needs no re-capture."""
+refreshed per call, so its schedule needs no re-capture.
+
+Health check.  The group-synchronised data-gradient conv (ops.conv_dgrad_gn_sync_raw: the workgroups of an image wait for each
+other inside the launch) needs its whole grid on the chip at once; if something else holds CUs -- another process on the GPU, a CU
+mask, a collective -- a workgroup gives up after a bounded spin, bumps an error word in device memory, and THAT STEP'S GRADIENTS
+ARE GARBAGE.  The step therefore reads the word (`check`) after the warm-up steps, then every `health_every` steps, and whenever the
+caller asks (run.py: before every check-point and at the end of every epoch).  A clean check copies parameters + optimizer state into
+a shadow ("last good", ~3x the parameter bytes); a check that finds time-outs retires the synchronised form for the rest of the
+process, rolls the weights back to the last good shadow, drops the graph (it is captured afresh without the form) and says so on
+stderr -- or raises SyncTimeoutError when `recover` is off or no clean check has happened yet.  The steps between the last clean check
+and the time-out are lost (their batches are not replayed); nothing computed from a poisoned step survives."""
 import sys
 
 import torch
@@ -33,8 +43,17 @@ import torch
 from . import ops
 
 
+class SyncTimeoutError(RuntimeError):
+    """A group-synchronised conv launch gave up waiting for its group: the gradients of that step were garbage."""
+
+
 class GraphedTrainStep:
-    def __init__(self, model, args, opt, sync=None, use_graph=True, warmup=2, pre_step=None):
+    def __init__(self, model, args, opt, sync=None, use_graph=True, warmup=2, pre_step=None, health_every=64, recover=True):
+        self.health_every, self.recover = int(health_every), bool(recover)
+        self.timeouts = 0             # time-outs seen over the life of this trainer
+        self.recoveries = 0           # ... and the roll-backs they caused
+        self._good = None             # (live tensors, shadow copies) of the last clean check
+        self.trace = None             # measurement only (bench.py): a list that receives the five HIP events of each three-graph replay
         self.model, self.args, self.opt, self.sync = model, args, opt, sync
         self.pre_step = pre_step      # e.g. clip_grad_norm_ in front of a stock optimizer (between exchange and step)
         self.use_graph, self.warmup = use_graph, warmup
@@ -77,8 +96,76 @@ class GraphedTrainStep:
                 leaf.grad = None
 
     def _shares_chip(self):
-        return (self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.sync is None:
+            return False
+        if getattr(self.sync, 'force', False):      # the exchange path on one rank: RCCL's kernels still run beside phase B
+            return True
+        return (torch.distributed.is_available() and torch.distributed.is_initialized()
                 and torch.distributed.get_world_size() > 1)
+
+    # ------------------------------------------------------------------ health: time-outs of the synchronised convs
+    def _live_state(self):
+        live = []
+        for grp in self.opt.param_groups:
+            for p in grp['params']:
+                live.append(p.data)
+                st = self.opt.state.get(p)
+                if st:
+                    live.extend(v for v in st.values() if torch.is_tensor(v))
+        extra = getattr(self.opt, '_state', None)       # FusedClipAdamW: step count + bias corrections on the device
+        if torch.is_tensor(extra):
+            live.append(extra)
+        return live
+
+    def _snapshot(self):
+        live = self._live_state()
+        if (self._good is not None and len(self._good[0]) == len(live)
+                and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(self._good[0], live))):
+            torch._foreach_copy_(self._good[1], live)
+        else:
+            self._good = (live, [t.clone() for t in live])
+
+    def _timeouts_everywhere(self):
+        n = ops.rs_sync_timeouts(reset=False)
+        if (self.sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1):
+            dev = next(iter(self.model.parameters())).device
+            t = torch.tensor([float(n)], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)     # every rank rolls back, or none
+            n = max(n, int(t.item()))
+        return n
+
+    def check(self):
+        """Read the synchronised convs' error word (synchronises the device).  -> time-outs found by this call (0: healthy, and
+        the weights + optimizer state are now the "last good" shadow).  On time-outs: the form is retired, the weights are
+        rolled back, the graph is dropped; SyncTimeoutError when that is not possible (`recover` off / no clean check yet)."""
+        if not ops._RS_SYNC_STATE:              # no launch of the form so far (fp32 path, small batches, the form switched off)
+            return 0
+        n = self._timeouts_everywhere()
+        if n == 0:
+            if self.recover and not ops.sync_convs_retired():
+                self._snapshot()
+            return 0
+        self.timeouts += n
+        ops.retire_sync_convs()
+        self.graph = None
+        if hasattr(self.opt, '_key'):
+            self.opt._key = None
+        msg = ('%d workgroup(s) of the group-synchronised data-gradient conv timed out waiting for their group (the launch was not '
+               'resident at once: is something else running on this GPU?); the gradients since the last clean check are garbage'
+               % n)
+        if not self.recover or self._good is None:
+            raise SyncTimeoutError(msg + '; no clean state to roll back to -- restart from the last check-point with '
+                                         'IDF_CONV_RS_SYNC=0')
+        live, good = self._good
+        with torch.no_grad():
+            torch._foreach_copy_(live, good)
+        torch.autograd.graph.increment_version([p for grp in self.opt.param_groups for p in grp['params']])
+        self.recoveries += 1
+        print('WARNING: ' + msg + '; rolled the weights and the optimizer state back to the last clean check (<= %d steps ago), '
+              'retired the synchronised form for this process and re-capturing the step without it' % max(self.health_every, 1),
+              file=sys.stderr)
+        return n
 
     def _opt_step(self):
         if self.pre_step is not None:
@@ -143,13 +230,27 @@ class GraphedTrainStep:
             self.graph.replay()
             return
         g1, g2, g3 = self.graph
+        tr = self.trace
+
+        def mark():
+            if tr is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tr[-1].append(e)
+        if tr is not None:
+            tr.append([])
         self.sync.begin_step()
+        mark()
         g1.replay()
+        mark()
         if g2 is not None:
             self.sync.reduce_early()        # backbone slice: on the wire while the encoder's backward pass replays
             g2.replay()
+        mark()
         self.sync.all_reduce_grads()        # the rest; joins the exchange stream
+        mark()
         g3.replay()
+        mark()
 
     def _try_capture(self, x, epoch):
         """-> (captured, stepped).  Never raises: under data parallelism every rank must come out of here and meet
@@ -188,6 +289,8 @@ class GraphedTrainStep:
     def __call__(self, x, epoch=0):
         """One optimisation step on batch x; returns the loss as a device scalar (no host sync)."""
         self.seen += 1
+        if self.health_every > 0 and (self.seen == self.warmup + 1 or self.seen % self.health_every == 0):
+            self.check()        # the steps so far (before this one touches the weights)
         if hasattr(self.model, 'set_epoch'):
             self.model.set_epoch(self.args, epoch)        # --use_C: the KL capacity's device scalar (no re-capture)
         if (self.use_graph and self.graph is None and self.seen > self.warmup

@@ -126,6 +126,11 @@ def _fit(args, model, batches, world, rank, latent=False):
             x = data[0] if isinstance(data, (tuple, list)) else data
             total += step(x.to(device=model.device), epoch)     # loss_fn, backward, [all-reduce], clip + AdamW
             n += 1
+        # the synchronised convs' error word (trainer.GraphedTrainStep.check): a time-out rolls the weights back to the last
+        # clean check or raises -- never a check-point, nor an epoch's loss line, from a poisoned step without a trace
+        if step.check():
+            print('epoch %d: synchronised-conv time-out(s); weights rolled back, training continues without that form'
+                  % epoch, file=sys.stderr)
         losses.update(float(total) / max(n - 1, 1))   # reference divides by the last index (run.py:205)
         if rank == 0:
             progress.display(epoch)

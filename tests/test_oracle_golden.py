@@ -96,6 +96,13 @@ def test_model_fmnist_kld(gold, manifest):
                 O.dataset_cfg('fmnist', a_dim=16, mmd_weight=0.1, kld_weight=0.01))
 
 
+def test_model_input_size_28(gold, manifest):
+    """The `input_size == 28` branch (/root/reference/models.py:619-622: ch_mult [1, 2, 4], maps 28 / 14 / 7): oracle vs the fixture the
+    real reference wrote (tools/gen_golden.py size28)."""
+    _model_case(gold, manifest, 'size28', O.Cfg(input_channels=1, unets_channels=32, encoder_channels=32, input_size=28, a_dim=32,
+                                                 mmd_weight=0.1))
+
+
 def test_model_fmnist_bottleneck(gold, manifest):
     """--is_bottleneck (BottleneckAuxUNet, models.py:329-421): oracle vs the reference fixture."""
     _model_case(gold, manifest, 'fmnist_bneck',

@@ -641,7 +641,7 @@ def gen_config5():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'celeba', 'config5']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'size28', 'celeba', 'config5']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -666,6 +666,10 @@ if __name__ == '__main__':
         gen_priors_and_capacity()
     if 'branches' in which:
         gen_branches()
+    if 'size28' in which:
+        # the `input_size == 28` branch (models.py:619-622: ch_mult [1, 2, 4], maps 28 / 14 / 7 -- no named dataset reaches it, data.py:63-102
+        # sets 32 or 64 everywhere, but `InfoDiff(args, ...)` with input_size 28 is constructible and runs)
+        gen_model('size28', O.Cfg(input_channels=1, unets_channels=32, encoder_channels=32, input_size=28, a_dim=32, mmd_weight=0.1), B=3, seed=69)
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     if 'config5' in which:

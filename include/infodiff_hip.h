@@ -353,6 +353,12 @@ int idf_conv_wgrad_bf16(const void* a, const void* dy, float* dW, float* db, int
 /* mode 2 (UpSample) | IDF_WGRAD_UPSUB in both calls: the class in its sub-pixel form (16 tap products per low-resolution pixel
  * instead of 36: taps that read the same low-resolution pixel share one product, modules.py:78-93) where idf_wgrad_upsub_ok. */
 #define IDF_WGRAD_UPSUB 32
+/* mode 0, taps 9 | IDF_WGRAD_RING in both calls (round 6): the stride-1 3x3 class in its row-ring form where idf_wgrad_ring_ok --
+ * 64 / 32 / 16 / 8-wide maps, tensors below 2 GB: a block's consecutive pixel tiles are vertically adjacent, so only a tile's R new
+ * input rows are fetched (the rest wait in a ring of LDS rows), wave tiles of 64 couts x 16 cins x 9 taps, buffer loads whose
+ * out-of-image lanes fall outside the descriptor's range (no branches) -- /root/reference/run.py:195-200's backward of every 3x3 conv. */
+#define IDF_WGRAD_RING 64
+int idf_wgrad_ring_ok(int B, int H, int W, int Cin, int Cout);
 int idf_wgrad_upsub_ok(int H, int W);
 int idf_wgrad_kr3_ok(int H, int W);
 int idf_wgrad_desc_bytes(void);

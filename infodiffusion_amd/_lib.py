@@ -98,6 +98,7 @@ SIGNATURES = {
     'idf_conv_wgrad_bf16': ([_p, _p, _p, _p] + [_i] * 10 + [_p], C.c_int),
     'idf_wgrad_desc_bytes': ([], C.c_int),
     'idf_wgrad_kr3_ok': ([_i, _i], C.c_int),
+    'idf_wgrad_ring_ok': ([_i] * 5, C.c_int),
     'idf_wgrad_upsub_ok': ([_i, _i], C.c_int),
     'idf_wgrad_desc_fill': ([_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _i, _p, _p], C.c_int),
     'idf_wgrad_reduce_batched': ([_p, _i, _i, _p], C.c_int),

@@ -15,7 +15,7 @@ void idf_set_error(const char* fmt, ...) {
 extern "C" const char* idf_last_error(void) { return g_err; }
 extern "C" int idf_version(void) { return 100; }
 
-// Every environment switch the library reads -- six -- read ONCE, at first use (a C++11 magic static: initialised exactly once under
+// Every environment switch the library reads -- seven -- read ONCE, at first use (a C++11 magic static: initialised exactly once under
 // concurrent first calls); everything else that used to be a getenv is a constant with its measurement in the comment beside it.
 // The Python package has its own table (infodiffusion_amd/knobs.py); INTEGRATION.md section 5 lists both.
 const IdfKnobs& idf_knobs() {
@@ -28,6 +28,7 @@ const IdfKnobs& idf_knobs() {
     v.conv_dlds_min = num("IDF_CONV_DLDS_MIN", 1536);   // workgroups from which a plain 256-pixel launch takes the direct-to-LDS form
     v.wgrad_kr3 = (int)num("IDF_WGRAD_KR3", 1);         // batched stride-1 3x3 weight gradient in the shared-tile form
     v.wgrad_tpb3 = (int)num("IDF_WGRAD_TPB3", 128);     // ... its pixel tiles per workgroup (profiles/r04_wgrad_tpb3.txt)
+    v.wgrad_ring = (int)num("IDF_WGRAD_RING", 1);       // ... its 64- / 32-wide maps in the row-ring form (round 6: profiles/r06_wgrad.txt)
     return v;
   }();
   return k;

@@ -17,7 +17,7 @@ extern "C" const char* idf_last_error(void);
 void idf_set_error(const char* fmt, ...);
 
 // the library's environment switches (idf_capi.hip: read once)
-struct IdfKnobs { int conv_rs, conv_rs_sync, conv_ps, wgrad_kr3, wgrad_tpb3; long conv_dlds_min; };
+struct IdfKnobs { int conv_rs, conv_rs_sync, conv_ps, wgrad_kr3, wgrad_tpb3, wgrad_ring; long conv_dlds_min; };
 const IdfKnobs& idf_knobs();
 
 #define IDF_FAIL(code, ...)            \

@@ -43,11 +43,15 @@ struct WgP {
   // exactly one writer), and idf_wgrad_reduce_batched adds the slabs to dW / db in slab order.  ws == null: fp32 atomics into dW.
   float* ws;
   int ws_stride, ws_dboff;      // floats per slab (multiple of 4); offset of db inside a slab (= Nw * taps * Cw)
+  int ring;                     // stride-1 3x3 on a 64- or 32-wide map with whole 64-channel tiles: the row-ring form (wgrad_block_ring)
 };
 
 #ifndef IDF_WGRAD_BLOCKS
 #define IDF_WGRAD_BLOCKS 320   // target grid size: ~1.25 blocks per CU keeps the atomic bytes low
 #endif
+#ifndef IDF_WG_ABL
+#define IDF_WG_ABL 0      // diagnostic builds (tools/build_variant.sh): 1 no global loads past the first tiles, 2 no LDS stores past the first,
+#endif                    // 4 no MFMA loop, 8 MFMAs without their LDS reads, 16 no address arithmetic in the k loop (tools/bench_wgrad.py)
 constexpr int PITCH = 80;                 // elements per LDS pixel row
 constexpr int PITCHB = PITCH * 2;         // bytes
 
@@ -150,6 +154,7 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   auto load_tile = [&](int t, TileRegs& rg) {
     uint4 (&xreg)[XV] = rg.x;
     uint4 (&dreg)[DV] = rg.d;
+    if ((IDF_WG_ABL & 1) && ROWS == 3 && t > t_beg + 1) return;
     const int b = t / tiles_per_img, oy0 = (t - b * tiles_per_img) * R;
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
@@ -175,9 +180,11 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
       dreg[k] = val;
     }
   };
+  int abl_stores = 0;
   auto store_tile = [&](TileRegs& rg, bf16_t* Xs, bf16_t* Ds) {
     uint4 (&xreg)[XV] = rg.x;
     uint4 (&dreg)[DV] = rg.d;
+    if ((IDF_WG_ABL & 2) && ROWS == 3 && abl_stores++ >= 2) return;
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
       int idx = tid + k * NT;
@@ -204,9 +211,21 @@ __device__ __forceinline__ void wgrad_block(const WgP& p, int bx, const int by) 
   auto compute = [&](const bf16_t* Xs, const bf16_t* Ds) {
     // ---- MFMA over the tile's pixels, 32 per step.  Logical k slot (g, j) maps to
     // physical pixel 4g+j (j<4) / 16+4g+(j-4): consecutive pixels per read half.
+    if ((IDF_WG_ABL & 4) && ROWS == 3) return;
+    if ((IDF_WG_ABL & 8) && ROWS == 3) {
+      bf16x8_t f0 = mkfrag(tr_read(Ds + lane * 4), tr_read(Ds + lane * 4 + 16)), f1 = mkfrag(tr_read(Xs + lane * 4), tr_read(Xs + lane * 4 + 16));
+      for (int ks = 0; ks < KT; ks += 32)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, f1, acc[kx][i][j], 0, 0, 0);
+      return;
+    }
     for (int ks = 0; ks < KT; ks += 32) {
       bf16x8_t nf[2];
-      const int pixA = ks + 4 * g + q, pixB = pixA + 16;
+      const int pixA = ((IDF_WG_ABL & 16) ? 0 : ks) + 4 * g + q, pixB = pixA + 16;
       {
         const bf16_t* d0 = Ds + pixA * PITCH + wn0 + 4 * pp;
         const bf16_t* d1 = Ds + pixB * PITCH + wn0 + 4 * pp;
@@ -471,6 +490,288 @@ __device__ __forceinline__ void wgrad_block_upsub(const WgP& p, int bx, const in
   }
 }
 
+// ---- Round 6: the stride-1 3x3 class rebuilt from what the ablations of the shared-tile kernel above measured (profiles/r06_wgrad.txt:
+// of 1032 us back to back, 354 us are the fragment reads, 205 us the global loads, 80 us the LDS stores; MFMA pipe busy 32 %):
+//  * ROW RING.  Consecutive tiles of a block are vertically adjacent, so 2 of a tile's R + 2 input rows were staged for the tile before.
+//    The input lives in a ring of 2R + 4 LDS rows; a tile fetches and stores only its R NEW rows (all R + 2 at the top of an image / of
+//    the block): half the input bytes at W = 64 (R = 2), two thirds at W = 32 (R = 4) -- fewer global loads, fewer ds_write_b128.
+//  * WAVE TILE 64 couts x 16 cins x 9 taps, the contraction split over wave pairs: 8 waves = (k half, cin quarter), 144 accumulator
+//    registers each at two waves per SIMD.  Per 32-pixel k-step a wave reads 4 dy + 9 input fragments for 36 MFMAs -- 0.72 transposed
+//    reads per MFMA (the shared-tile kernel: 2 + 6 for 12, 1.33).  The two k halves meet once per block, through LDS.
+//  * NO BRANCHES AROUND LOADS.  Every staging load is a buffer load whose offset is pushed out of range where the pixel lies outside
+//    the image, the channel beyond the tensor's, or the tile has fewer rows (the range check returns zeros): straight-line code, so
+//    hipcc counts vmcnt instead of draining it, and a tile's loads stay in flight across the tile before's contraction.
+// Per iteration: store tile t + 1 (registers -> LDS), issue tile t + 2's loads, contract tile t, one barrier (LDS only).
+// W in {64, 32, 16, 8}; channel counts multiples of 8 (partial 64-channel tiles contract zeros); tensors < 2 GB (32-bit offsets).
+// (The body is a function of its own per map width -- each instantiation gets its own register allocation, 230-256 VGPRs; inlined into
+// one kernel the four of them spilled.  Everything block-uniform is moved to SGPRs by hand: the descriptor is read through a pointer the
+// compiler cannot prove uniform, and a non-uniform buffer descriptor turns every load into a waterfall loop.)
+__device__ __forceinline__ int wg_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* wg_sgpr_ptr(T* q) {
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int W>
+__device__ __attribute__((noinline)) void wgrad_block_ring(const WgP* __restrict__ pp_, int bx_, int by_) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = W >= 16 ? 128 / W : 8, WH = W + 2, KT = R * W, NR = 2 * R + 4, NT = 512;
+  constexpr int WSH = W == 64 ? 6 : (W == 32 ? 5 : (W == 16 ? 4 : 3));
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(KT == 128 || KT == 64, "tiles of 128 pixels (64 on the 8-wide map)");
+  // the problem, in SGPRs
+  struct { const bf16_t *a, *a2, *dy; float *dW, *db, *ws; int C1, B, H, Cin, Cout, tiles, tiles_per_blk, c_tiles, Cw, Nw, ws_stride, ws_dboff; } p;
+  p.a = wg_sgpr_ptr(pp_->a); p.a2 = wg_sgpr_ptr(pp_->a2); p.dy = wg_sgpr_ptr(pp_->dy);
+  p.dW = wg_sgpr_ptr(pp_->dW); p.db = wg_sgpr_ptr(pp_->db); p.ws = wg_sgpr_ptr(pp_->ws);
+  p.C1 = wg_sgpr(pp_->C1); p.B = wg_sgpr(pp_->B); p.H = wg_sgpr(pp_->H); p.Cin = wg_sgpr(pp_->Cin); p.Cout = wg_sgpr(pp_->Cout);
+  p.tiles = wg_sgpr(pp_->tiles); p.tiles_per_blk = wg_sgpr(pp_->tiles_per_blk); p.c_tiles = wg_sgpr(pp_->c_tiles);
+  p.Cw = wg_sgpr(pp_->Cw); p.Nw = wg_sgpr(pp_->Nw); p.ws_stride = wg_sgpr(pp_->ws_stride); p.ws_dboff = wg_sgpr(pp_->ws_dboff);
+  const int bx = wg_sgpr(bx_), by = wg_sgpr(by_);
+  bf16_t* const Xs = reinterpret_cast<bf16_t*>(smem);          // [NR][WH] pixels
+  bf16_t* const Ds = Xs + NR * WH * PITCH;                      // [2][KT] pixels
+  const int tid = threadIdx.x, lane = tid & 63, wv = wg_sgpr(tid >> 6);
+  const int kh = wv >> 2, cq = wv & 3;
+  const int c0 = (bx % p.c_tiles) * 64, n0 = (bx / p.c_tiles) * 64;
+  const int tiles_per_img = p.H / R;
+  const int t_beg = by * p.tiles_per_blk, t_end = min(p.tiles, t_beg + p.tiles_per_blk);
+  if (t_beg >= t_end) return;
+
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: a cin tile lies entirely in `a` or in `a2`
+  const int v8 = tid & 7;
+  const bf16_t* asrc = p.a;
+  int apitch = p.Cin, acol = c0, alim = p.Cin;
+  if (p.a2) {
+    if (c0 < p.C1) { apitch = p.C1; alim = p.C1; }
+    else { asrc = p.a2; apitch = p.Cin - p.C1; acol = c0 - p.C1; alim = apitch; }
+  }
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)asrc, 0, (int)((unsigned)p.B * p.H * W * apitch * 2u), 0x00020000);
+  const auto drs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.B * p.H * W * p.Cout * 2u), 0x00020000);
+  // W = 64: the two top rows of an image's first window are fetched on the spot when that tile is stored (one exposed round trip
+  // per 32 tiles) so that the tiles in flight hold 3 vectors per thread instead of 5 -- the registers the accumulators need
+  constexpr bool SPLIT = false;      // (W == 64 measured: the branch around the on-the-spot fetch makes hipcc drain vmcnt at the top of every iteration)
+  constexpr int XV = ((SPLIT ? R : R + 2) * WH * 8 + NT - 1) / NT, XVE = (2 * WH * 8 + NT - 1) / NT, DV = KT * 8 / NT;
+  const bool cvalid = acol + v8 * 8 < alim, nvalid = n0 + v8 * 8 < p.Cout;
+  const unsigned rowbytes = (unsigned)(W * apitch * 2);
+  const bool do_db = p.db != nullptr && c0 == 0;
+  float dbs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbs[e] = 0.f;
+
+  wg_u32x4_t xr[XV], dr[DV];
+  // tile t: rows f .. R + 1 of its (R + 2)-row window are new (f = 0 at the top of an image / of the block, else 2)
+  auto xload = [&](int k, int f, int b, int oy0, bool live) {
+    const int pix = (tid + k * NT) >> 3, xrow = pix / WH, xcol = pix - xrow * WH;
+    const int wr = f + xrow, y = oy0 - 1 + wr, ix = xcol - 1;              // window row, image row, image column
+    const bool ok = live && cvalid && wr < R + 2 && (unsigned)y < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+    const unsigned ibase = (unsigned)(b * p.H) * rowbytes + (unsigned)((acol + v8 * 8) * 2);
+    return __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? ibase + (unsigned)y * rowbytes + (unsigned)(ix * apitch * 2) : OOB, 0, 0);
+  };
+  auto xstore = [&](int k, int f, int rbase, const wg_u32x4_t& v) {
+    const int pix = (tid + k * NT) >> 3, xrow = pix / WH, xcol = pix - xrow * WH;
+    const int wr = f + xrow;
+    if (wr < (SPLIT && f == 0 ? 2 : R + 2)) {
+      int slot = rbase + wr;
+      slot -= slot >= NR ? NR : 0;
+      *reinterpret_cast<wg_u32x4_t*>(Xs + (slot * WH + xcol) * PITCH + v8 * 8) = v;
+    }
+  };
+  // per-tile scalars of the staging (block-uniform)
+  struct TileCtx { int b, oy0, f; bool live, fresh; };
+  auto tile_ctx = [&](int t) {
+    TileCtx c;
+    c.live = t < t_end;
+    const int tt = c.live ? t : t_beg;
+    c.b = tt / tiles_per_img;
+    const int ty = tt - c.b * tiles_per_img;
+    c.oy0 = ty * R;
+    c.fresh = tt == t_beg || ty == 0;
+    c.f = (SPLIT || !c.fresh) ? 2 : 0;
+    return c;
+  };
+  auto dload = [&](int k, const TileCtx& c) {
+    const unsigned dbase = (unsigned)((c.b * p.H + c.oy0) * W) * (unsigned)(p.Cout * 2) + (unsigned)((n0 + v8 * 8) * 2);
+    return __builtin_amdgcn_raw_buffer_load_b128(drs, (c.live && nvalid) ? dbase + (unsigned)(((tid + k * NT) >> 3) * p.Cout * 2) : OOB, 0, 0);
+  };
+  auto dstore = [&](int k, int dbuf, const wg_u32x4_t& v) {
+    *reinterpret_cast<wg_u32x4_t*>(Ds + (dbuf * KT + ((tid + k * NT) >> 3)) * PITCH + v8 * 8) = v;
+    if (do_db) {
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dbs[2 * e] += __uint_as_float(w4[e] << 16);
+        dbs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+      }
+    }
+  };
+  auto issue = [&](const TileCtx& c) {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) xr[k] = xload(k, c.f, c.b, c.oy0, c.live);
+#pragma unroll
+    for (int k = 0; k < DV; ++k) dr[k] = dload(k, c);
+  };
+  // the two top rows of an image's first window (W = 64): fetched on the spot, before the regular rows' registers are touched
+  auto stash_top = [&](const TileCtx& c, int rbase) {
+    if (SPLIT && c.fresh && c.live) {
+      wg_u32x4_t xe[XVE];
+#pragma unroll
+      for (int k = 0; k < XVE; ++k) xe[k] = xload(k, 0, c.b, c.oy0, true);
+#pragma unroll
+      for (int k = 0; k < XVE; ++k) xstore(k, 0, rbase, xe[k]);
+    }
+  };
+  // piece s of (store tile t + 1, issue tile t + 2): one staged vector leaves its register for LDS and the register is re-loaded at
+  // once -- called between the taps of tile t's contraction, so the LDS stores and their address arithmetic issue in the MFMAs' shadow
+  // instead of in a phase of their own (ablations: stores + load waits were 340 of 940 us, the MFMA work alone 525)
+  auto piece = [&](int k, const TileCtx& c1, int rb1, int db1, const TileCtx& c2) {
+    if (k < XV) {
+      if (c1.live && !(IDF_WG_ABL & 2)) xstore(k, c1.f, rb1, xr[k]);
+      if (!(IDF_WG_ABL & 1)) xr[k] = xload(k, c2.f, c2.b, c2.oy0, c2.live);
+    } else if (k < XV + DV) {
+      if (c1.live && !(IDF_WG_ABL & 2)) dstore(k - XV, db1, dr[k - XV]);
+      if (!(IDF_WG_ABL & 1)) dr[k - XV] = dload(k - XV, c2);
+    }
+  };
+  // transposed-read lane geometry: lane (g, q, pp) addresses pixel 4g + q of a 16-pixel run, channels 4pp .. 4pp + 3 of a 16-channel
+  // fragment; k slot (g, j) of a 32-pixel step = pixel 4g + j (j < 4) / 16 + 4g + (j - 4)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, pl = 4 * g + q;
+  const int lrow = W == 8 ? pl >> 3 : 0, lcol = W == 8 ? pl & 7 : pl;
+  const int lane_x = lcol * PITCH + cq * 16 + 4 * pp, lane_d = pl * PITCH + 4 * pp;
+  auto contract = [&](int rbase, int dbuf, const TileCtx& c1, int rb1, const TileCtx& c2) {
+    constexpr int NP = XV + DV, NS = 9 * (KT / 64);          // staging pieces, tap slots of this wave's k-steps
+    if (IDF_WG_ABL & 4) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) piece(k, c1, rb1, dbuf ^ 1, c2);
+      return;
+    }
+    if (IDF_WG_ABL & 8) {
+      const bf16x8_t f0 = mkfrag(tr_read(Ds + lane_d), tr_read(Ds + lane_d + 16)), f1 = mkfrag(tr_read(Xs + lane_x), tr_read(Xs + lane_x + 16));
+#pragma unroll
+      for (int i2 = 0; i2 < KT / 64; ++i2)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, f1, acc[t][i], 0, 0, 0);
+          const int slot = i2 * 9 + t;
+          if ((slot * NP) / NS != ((slot + 1) * NP) / NS) piece((slot * NP) / NS, c1, rb1, dbuf ^ 1, c2);
+        }
+      return;
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < KT / 64; ++i2) {
+      const int ks = 32 * (2 * i2 + kh);
+      const bf16_t* d0 = Ds + (dbuf * KT + ks) * PITCH + lane_d;
+      const int rowA = ks >> WSH, colA = ks & (W - 1), rowB = (ks + 16) >> WSH, colB = (ks + 16) & (W - 1);
+      const bf16_t *xA[3], *xB[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        int sA = rbase + rowA + ky + lrow, sB = rbase + rowB + ky + lrow;
+        sA -= sA >= NR ? NR : 0;
+        sB -= sB >= NR ? NR : 0;
+        xA[ky] = Xs + (sA * WH + colA) * PITCH + lane_x;
+        xB[ky] = Xs + (sB * WH + colB) * PITCH + lane_x;
+      }
+      bf16x8_t nf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nf[i] = mkfrag(tr_read(d0 + i * 16), tr_read(d0 + 16 * PITCH + i * 16));
+      // the next tap's fragment is in flight while this tap's four MFMAs issue (two waves per SIMD: nobody else hides an LDS round trip)
+      bf16x8_t cf = mkfrag(tr_read(xA[0]), tr_read(xB[0]));
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        bf16x8_t cn = cf;
+        if (t < 8) cn = mkfrag(tr_read(xA[(t + 1) / 3] + ((t + 1) % 3) * PITCH), tr_read(xB[(t + 1) / 3] + ((t + 1) % 3) * PITCH));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nf[i], cf, acc[t][i], 0, 0, 0);
+        cf = cn;
+        // NP staging pieces spread evenly over the NS tap slots
+        const int slot = i2 * 9 + t;
+        if ((slot * NP) / NS != ((slot + 1) * NP) / NS) piece((slot * NP) / NS, c1, rb1, dbuf ^ 1, c2);
+      }
+    }
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  int rb_c = 0;                                        // ring slot of the contracted tile's top window row
+  {
+    const TileCtx c0_ = tile_ctx(t_beg), c1_ = tile_ctx(t_beg + 1);
+    issue(c0_);
+    stash_top(c0_, rb_c);
+#pragma unroll
+    for (int k = 0; k < XV; ++k) xstore(k, c0_.f, rb_c, xr[k]);
+#pragma unroll
+    for (int k = 0; k < DV; ++k) dstore(k, 0, dr[k]);
+    issue(c1_);
+  }
+  lds_barrier();
+  for (int t = t_beg; t < t_end; ++t) {
+    const int db_c = (t - t_beg) & 1;
+    int rb_n = rb_c + (((t + 1) % tiles_per_img) == 0 ? R + 2 : R);       // the next tile's window: R rows down, or a fresh image behind this one
+    rb_n -= rb_n >= NR ? NR : 0;
+    const TileCtx c1_ = tile_ctx(t + 1), c2_ = tile_ctx(t + 2);
+    stash_top(c1_, rb_n);
+    contract(rb_c, db_c, c1_, rb_n, c2_);              // tile t contracted; tile t + 1 stored and tile t + 2 requested between its taps
+    rb_c = rb_n;
+    lds_barrier();
+  }
+
+  // ---- the two k halves meet: kh = 1 hands its accumulators over through LDS, one kernel row at a time
+  float* const red = reinterpret_cast<float*>(smem);           // [4 cin quarters][12 fragments][64 lanes] float4 = 48 KB
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    if (kh) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(red + ((cq * 12 + kx * 4 + i) * 64 + lane) * 4) = acc[ky * 3 + kx][i];
+    }
+    lds_barrier();
+    if (!kh) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ky * 3 + kx][i] += *reinterpret_cast<const f32x4_t*>(red + ((cq * 12 + kx * 4 + i) * 64 + lane) * 4);
+    }
+    lds_barrier();
+  }
+  if (!kh) {
+    // D: row = n (4 per lane), col = c (lane & 15)
+    const int c = c0 + cq * 16 + (lane & 15);
+    if (c < p.Cw) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
+            if (n < p.Nw) {
+              const size_t idx = ((size_t)n * 9 + t) * p.Cw + c;
+              if (p.ws) gstore(p.ws + (size_t)by * p.ws_stride + idx, acc[t][i][r]);
+              else gatomic_add(p.dW + idx, acc[t][i][r]);
+            }
+          }
+    }
+  }
+  if (do_db) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + v8 * 8 + e] = dbs[e];
+    lds_barrier();
+    if (tid < 64 && n0 + tid < p.Nw) {
+      float sacc = 0.f;
+      for (int k = 0; k < NT / 8; ++k) sacc += red[k * 64 + tid];
+      if (p.ws) gstore(p.ws + (size_t)by * p.ws_stride + p.ws_dboff + n0 + tid, sacc);
+      else gatomic_add(p.db + n0 + tid, sacc);
+    }
+  }
+}
+
 template <int KW, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_tr_bf16(const WgP p) {
   wgrad_block<KW, MODE>(p, blockIdx.x, blockIdx.y);
@@ -550,6 +851,32 @@ __global__ __launch_bounds__(768) void conv_wgrad_tr_bf16_batched_kr3(const WgDe
   }
 }
 
+// the row-ring form of the stride-1 3x3 class (512 threads: 8 waves = k half x cin quarter, one or two blocks per CU)
+__global__ __launch_bounds__(512) void conv_wgrad_ring_batched(const WgDesc* __restrict__ tab, int n, int total) {
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    if (bid != (int)blockIdx.x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (tab[mid].blk0 <= bid) lo = mid; else hi = mid;
+    }
+    const WgDesc* d = tab + lo;
+    const int local = bid - d->blk0, gx = d->gx;
+    int bx, by;
+    if (d->xcd) {
+      const int x = local & 7, j = local >> 3;
+      by = x + 8 * (j / gx); bx = j % gx;
+    } else { bx = local % gx; by = local / gx; }
+    if (by >= d->gy) continue;
+    switch (wg_sgpr(d->p.W)) {
+      case 64: wgrad_block_ring<64>(&d->p, bx, by); break;
+      case 32: wgrad_block_ring<32>(&d->p, bx, by); break;
+      case 16: wgrad_block_ring<16>(&d->p, bx, by); break;
+      default: wgrad_block_ring<8>(&d->p, bx, by); break;
+    }
+  }
+}
+
 // Second stage of the deterministic accumulation: dW[i] += sum over this entry's slabs of ws[slab][i], in slab order (and db likewise):
 // a fixed order of fp32 additions, so two runs of a step give the same bits (the reference's convolution_backward under
 // --deterministic: utils.py:64-71).  One workgroup = 1024 consecutive floats of one entry's slab; float4 slab loads.
@@ -583,10 +910,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgDesc* __restr
 // IDF_WGRAD_KR3 (default 1): the batched stride-1 3x3 class runs in the shared-tile form
 #define g_kr3 (idf_knobs().wgrad_kr3)
 
+// IDF_WGRAD_RING (default 1): stride-1 3x3 problems on 64 / 32 / 16 / 8-wide maps run in the row-ring form (wgrad_block_ring)
+bool ring_fits(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
+  if (!idf_knobs().wgrad_ring || taps != 9 || mode != 0 || B <= 0 || (Cin % 8) || (Cout % 8)) return false;
+  if (W != 64 && W != 32 && W != 16 && W != 8) return false;
+  const int R = W >= 16 ? 128 / W : 8;
+  if (H < R || (H % R)) return false;
+  return (long)B * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1L << 31);      // 32-bit buffer offsets
+}
+
 // Shape checks + tiling plan of one problem.  target_blocks <= 0: the stand-alone heuristic.
 int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy, float* dW, float* db, int B, int H,
             int W, int Cin, int Cout, int taps, int mode, int target_blocks, const void* a2 = nullptr, int C1 = 0,
-            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0, bool kr3 = false, bool want_upsub = false) {
+            int tiles_per_block = 0, int min_blocks = 0, int Cin_w = 0, int Cout_w = 0, bool kr3 = false, bool want_upsub = false,
+            bool want_ring = false) {
   if ((taps != 9 && taps != 1) || (Cin % 8) || (Cout % 8) || H <= 0 || W < 4 || (W & (W - 1)) || mode < 0 ||
       mode > 2 || (mode && taps != 9) || (mode == 2 && ((H | W) & 1)))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: shape B%d H%d W%d Cin%d Cout%d taps%d mode%d not covered", B, H, W, Cin,
@@ -627,8 +964,12 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   }
   p.c_tiles = idf_cdiv(Cin, 64);
   p.n_tiles = idf_cdiv(Cout, 64);
+  // the row-ring form of the stride-1 3x3 class (wgrad_block_ring; the caller asked: idf_wgrad_ring_ok)
+  p.ring = want_ring ? 1 : 0;
+  if (want_ring && !ring_fits(B, H, W, Cin, Cout, taps, mode))
+    IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_bf16: B%d H%d W%d Cin%d Cout%d not covered by the row-ring form", B, H, W, Cin, Cout);
   const int kh = taps == 9 ? 3 : 1;
-  gx = p.c_tiles * p.n_tiles * (upsub ? 2 : (kr3 ? 1 : kh));
+  gx = p.c_tiles * p.n_tiles * (upsub ? 2 : ((kr3 || want_ring) ? 1 : kh));
   if (target_blocks <= 0) {
     // grid size trades chip occupancy against fp32-atomic bytes (= blocks/gx * |dW|): measured optimum on
     // MI355X is ~1 block per CU for small weight tiles and 2-3 per CU once a block does enough MFMA work
@@ -654,8 +995,9 @@ int wg_plan(WgP& p, int& gx, int& gy, size_t& lds, const void* a, const void* dy
   gy = idf_cdiv(p.tiles, p.tiles_per_blk);
   const int sx = mode == 1 ? 2 : 1;
   lds = ((size_t)(R + (kr3 ? 2 : 0)) * (sx * W + 2 * (kh / 2)) + (size_t)R * W) * PITCHB * (kr3 ? 2 : 1);     // kr3: two LDS tiles
+  if (p.ring) lds = ((size_t)(2 * R + 4) * (W + 2) + (size_t)2 * R * W) * PITCHB;                                  // ring rows + two dy tiles
   if (upsub) lds = ((size_t)(RLs + 2) * (Wl_ + 2) + (size_t)2 * RLs * Wl_) * PITCHB;
-  const size_t red = (size_t)(kr3 ? 96 : 32) * 64 * sizeof(float);
+  const size_t red = p.ring ? (size_t)4 * 12 * 64 * 16 : (size_t)(kr3 ? 96 : 32) * 64 * sizeof(float);
   if (lds < red) lds = red;
   return IDF_OK;
 }
@@ -685,6 +1027,9 @@ extern "C" int idf_wgrad_upsub_ok(int H, int W) {
   return (Wl >= 8 && Wl <= 32 && RL >= 1 && (Hl % RL) == 0 && ((RL * Wl) % 32) == 0 && (RL + 2) * (Wl + 2) * 8 <= 7 * 256) ? 1 : 0;
 }
 
+// 1 when the batched stride-1 3x3 weight gradient of this shape runs in the row-ring form (round 6): the host puts such problems
+// in a class of their own (mode | IDF_WGRAD_RING = 64 in idf_wgrad_desc_fill / idf_conv_wgrad_bf16_batched)
+extern "C" int idf_wgrad_ring_ok(int B, int H, int W, int Cin, int Cout) { return ring_fits(B, H, W, Cin, Cout, 9, 0) ? 1 : 0; }
 extern "C" int idf_wgrad_kr3_ok(int H, int W) { return (g_kr3 && H > 0 && W >= 4 && !(W & (W - 1)) && kr3_fits(H, W)) ? 1 : 0; }
 
 // taps = 9 (3x3, pad 1) or 1 (1x1); mode 0 stride 1, 1 stride 2, 2 nearest-x2-upsampled input
@@ -745,12 +1090,13 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
   static const int minb3 = 16;
   const bool rowsplit = (mode & 16) != 0;         // IDF_WGRAD_ROWSPLIT: the caller keeps this problem out of the shared-tile class
   const bool upsub = (mode & 32) != 0;            // IDF_WGRAD_UPSUB: the UpSample class in its sub-pixel form
+  const bool ring = (mode & 64) != 0;             // IDF_WGRAD_RING: the stride-1 3x3 class in its row-ring form
   mode &= 15;
-  const bool kr3 = g_kr3 && taps == 9 && mode == 0 && !rowsplit;
+  const bool kr3 = g_kr3 && taps == 9 && mode == 0 && !rowsplit && !ring;
   if (kr3 && !kr3_fits(H, W))
     IDF_FAIL(IDF_ERR_UNSUPPORTED, "wgrad_desc_fill: H%d W%d does not fit the shared-tile form (class it with IDF_WGRAD_ROWSPLIT)", H, W);
   int rc = wg_plan(d.p, d.gx, d.gy, lds, a, dy, dW, db, B, H, W, Cin, Cout, taps, mode, target_blocks > 0 ? target_blocks : 96,
-                   a2, C1, target_blocks > 0 ? 0 : (kr3 ? tpb3 : (upsub ? tpb_up : tpb)), kr3 ? minb3 : minb, Cin_w, Cout_w, kr3, upsub);
+                   a2, C1, target_blocks > 0 ? 0 : ((kr3 || ring) ? tpb3 : (upsub ? tpb_up : tpb)), (kr3 || ring) ? minb3 : minb, Cin_w, Cout_w, kr3, upsub, ring);
   if (rc != IDF_OK) return rc;
   d.blk0 = blk0;
   {
@@ -777,16 +1123,22 @@ extern "C" int idf_wgrad_desc_fill(void* host_table, int index, const void* a, c
 extern "C" int idf_conv_wgrad_bf16_batched(const void* dev_table, int n, int total_blocks, int lds_bytes, int taps,
                                            int mode, void* stream) {
   if (n <= 0 || total_blocks <= 0) return IDF_OK;
-  const bool rowsplit = (mode & 16) != 0, upsub = (mode & 32) != 0;
+  const bool rowsplit = (mode & 16) != 0, upsub = (mode & 32) != 0, ring = (mode & 64) != 0;
   mode &= 15;
-  if (!dev_table || (taps != 9 && taps != 1) || mode < 0 || mode > 2 || (mode && taps != 9))
+  if (!dev_table || (taps != 9 && taps != 1) || mode < 0 || mode > 2 || (mode && taps != 9) || (ring && (taps != 9 || mode)))
     IDF_FAIL(IDF_ERR_BADARG, "wgrad_bf16_batched: bad arguments (taps %d mode %d)", taps, mode);
   hipStream_t st = (hipStream_t)stream;
   const WgDesc* tab = (const WgDesc*)dev_table;
-  const bool kr3 = taps == 9 && mode == 0 && g_kr3 && !rowsplit;
+  const bool kr3 = taps == 9 && mode == 0 && g_kr3 && !rowsplit && !ring;
   const int grid = total_blocks;                     // one workgroup per work item
   dim3 g(grid);
-  if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
+  if (ring) {
+    static IdfLdsGrant grant;
+    if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_ring_batched, (size_t)lds_bytes, grant); e != hipSuccess)
+      IDF_FAIL(IDF_ERR_HIP, "wgrad_bf16_batched: %d bytes of LDS refused: %s", lds_bytes, hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_wgrad_ring_batched, g, dim3(512), lds_bytes, st, tab, n, total_blocks);
+  }
+  else if (taps == 1) hipLaunchKernelGGL((conv_wgrad_tr_bf16_batched<1, 0>), g, dim3(256), lds_bytes, st, tab, n, total_blocks);
   else if (kr3) {
     static IdfLdsGrant grant;
     if (hipError_t e = idf_ensure_lds((const void*)conv_wgrad_tr_bf16_batched_kr3, (size_t)lds_bytes, grant); e != hipSuccess)

@@ -1,7 +1,7 @@
 """Every environment switch of the package, in one table (read once, at import).  They exist for same-box A/B measurements
 (tools/ab_env.sh) and for the tests that pin both sides of a switch; the defaults are the measured-faster settings
-(INTEGRATION.md section 5 has the same table with the measurement behind each default).  The library reads six more through
-its own table (csrc/idf_capi.hip: IDF_CONV_RS, IDF_CONV_RS_SYNC, IDF_CONV_PS, IDF_CONV_DLDS_MIN, IDF_WGRAD_KR3, IDF_WGRAD_TPB3)."""
+(INTEGRATION.md section 5 has the same table with the measurement behind each default).  The library reads seven more through
+its own table (csrc/idf_capi.hip: IDF_CONV_RS, IDF_CONV_RS_SYNC, IDF_CONV_PS, IDF_CONV_DLDS_MIN, IDF_WGRAD_KR3, IDF_WGRAD_TPB3, IDF_WGRAD_RING)."""
 import os
 
 TABLE = {

@@ -968,6 +968,10 @@ def _kr3_ok(H, W):
     return bool(_lib.load().idf_wgrad_kr3_ok(H, W))
 
 
+def _ring_ok(B, H, W, Cin, Cout):
+    return bool(_lib.load().idf_wgrad_ring_ok(B, H, W, Cin, Cout))
+
+
 class WgradBatch:
     """Deferred weight gradients.  Only the optimizer reads them, so backward just queues each
     convolution's (a, dy, arena slots) and ONE launch per (taps, mode) class at the end of the
@@ -1033,13 +1037,21 @@ class WgradBatch:
         lib = _lib.load()
         for it in items:
             mode = it[10]
-            if it[9] == 9 and mode == S1 and not _kr3_ok(it[5], it[6]):
+            if it[9] == 9 and mode == S1 and _ring_ok(it[4], it[5], it[6], it[7], it[8]):
+                mode |= 64          # IDF_WGRAD_RING: the row-ring form (round 6)
+            elif it[9] == 9 and mode == S1 and not _kr3_ok(it[5], it[6]):
                 mode |= 16          # IDF_WGRAD_ROWSPLIT: a map the shared-tile kernel does not take (W = 128) is a class of its own
             if it[9] == 9 and mode == UP2 and _upsub_ok(it[5], it[6]):
                 mode |= 32          # IDF_WGRAD_UPSUB: the UpSample class in its sub-pixel form
             groups.setdefault((it[9], mode), []).append(it)
         nb = lib.idf_wgrad_desc_bytes()
         capturing = torch.cuda.is_current_stream_capturing()
+        # longest blocks first: a launch's workgroups start in table order, and the queue arrives in backward order -- the 64x64 / 32x32
+        # problems of the networks' first levels (64 pixel tiles per workgroup) LAST, behind the 16x16 / 8x8 ones (16 / 8 tiles): their
+        # workgroups then start in the launch's last round and run alone (simulated on the CelebA step's 114 problems: 321 -> 295 tile
+        # times against a balanced 289; measured: profiles/r06_wgrad.txt).  Stable sort: the order is a function of the shapes only.
+        for grp in groups.values():
+            grp.sort(key=lambda it: -(it[5] * it[6]))
         classes = list(groups.items())
         total = len(items)
         # ONE table (and one host-to-device copy) for all the (taps, mode) classes of this flush; each class launches on

@@ -972,7 +972,11 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
              (4, 32, 32, 32, 64, 9, ops.S1), (4, 128, 8, 8, 128, 9, ops.S1), (2, 64, 16, 16, 64, 9, ops.S2),
              (2, 64, 16, 16, 64, 9, ops.UP2), (2, 64, 64, 64, 64, 9, ops.S1),
              # operands zero-padded to 8 channels, gradient in the parameter's own extents (image input, epsilon / latent heads)
-             (3, 3, 32, 32, 64, 9, ops.S1), (3, 64, 32, 32, 3, 9, ops.S1), (2, 64, 16, 16, 1, 9, ops.S1)]
+             (3, 3, 32, 32, 64, 9, ops.S1), (3, 64, 32, 32, 3, 9, ops.S1), (2, 64, 16, 16, 1, 9, ops.S1),
+             # round 6, the row-ring form (idf_wgrad_ring_ok): pixel splits that start and end in the middle of an image (5 x 32 tiles
+             # over 16 workgroups), several cin / cout tiles incl. a partial one, every map width it takes, odd batches
+             (5, 64, 64, 64, 64, 9, ops.S1), (3, 128, 32, 32, 192, 9, ops.S1), (7, 64, 16, 16, 72, 9, ops.S1), (9, 128, 8, 8, 128, 9, ops.S1),
+             (3, 3, 64, 64, 64, 9, ops.S1), (1, 192, 64, 64, 64, 9, ops.S1)]
     ws, bs, data, refs = [], [], [], []
     for i, (B, Cin, H, W, Cout, taps, mode) in enumerate(cases):
         k = 3 if taps == 9 else 1
@@ -1017,6 +1021,35 @@ def test_wgrad_bf16_batched_matches_single_launches(split, monkeypatch):
         y.backward(dy.float())
         assert float((oW.float() - w0.grad).abs().max()) <= 1e-4 * float(w0.grad.abs().max()), (B, Cin, H, W, Cout, taps, mode)
         assert float((ob.float() - b0.grad).abs().max()) <= 1e-4 * float(b0.grad.abs().max()), (B, Cin, H, W, Cout, taps, mode)
+
+
+@pytest.mark.parametrize('H,C1,C2,Cout,B', [(64, 64, 64, 64, 3), (32, 128, 64, 128, 5), (16, 64, 128, 64, 4)])
+def test_wgrad_ring_two_source_input_matches_the_concatenation(H, C1, C2, Cout, B):
+    """The batched 3x3 weight gradient on an (a, a2) pair that is never concatenated (up-path skip pairs) == the same launch on
+    torch.cat([a, a2]), bit for bit (the ring kernel takes each 64-channel cin tile from the tensor it lies in), and == fp32 PyTorch
+    autograd at 1e-4."""
+    import torch.nn.functional as F
+    from infodiffusion_amd.grad_arena import GradArena, slot_of
+    a1 = rnd(1, B, C1, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    a2 = rnd(2, B, C2, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    dy = rnd(3, B, Cout, H, H).to(DEV).bfloat16().contiguous(memory_format=CL)
+    cat = torch.cat([a1, a2], 1).contiguous(memory_format=CL)
+    outs = []
+    for pair in (True, False):
+        w = torch.nn.Parameter(torch.zeros(Cout, C1 + C2, 3, 3, device=DEV).contiguous(memory_format=CL))
+        b = torch.nn.Parameter(torch.zeros(Cout, device=DEV))
+        arena = GradArena([w, b])
+        got = ops._defer_or_launch_wgrad(a1 if pair else cat, dy, slot_of(w), slot_of(b), 9, a2 if pair else None)
+        assert got is not None
+        ops.WgradBatch.flush()
+        assert arena.holds(got[0])
+        outs.append((got[0].clone(), got[1].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    w0 = torch.zeros(Cout, C1 + C2, 3, 3, device=DEV, requires_grad=True)
+    b0 = torch.zeros(Cout, device=DEV, requires_grad=True)
+    F.conv2d(cat.float(), w0, b0, padding=1).backward(dy.float())
+    assert float((outs[0][0].float() - w0.grad).abs().max()) <= 1e-4 * float(w0.grad.abs().max())
+    assert float((outs[0][1].float() - b0.grad).abs().max()) <= 1e-4 * float(b0.grad.abs().max())
 
 
 @pytest.mark.parametrize('path,H,B,arena', [('block', 16, 3, True), ('fold', 16, 3, True), ('fold', 8, 5, True), ('fold', 16, 130, True),

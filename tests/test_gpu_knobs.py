@@ -20,7 +20,7 @@ CASES = [
     ('IDF_BWD_LAZY', '1', STEP), ('IDF_DGRAD_GN', '0', STEP), ('IDF_SC_FUSE', '0', STEP), ('IDF_WGRAD_BATCH', '0', STEP), ('IDF_DETERMINISTIC', '0', STEP),
     ('IDF_ATTN_FOLD', '0', STEP), ('IDF_ATTN_BLOCK_MINB', '1', STEP), ('IDF_UPCONV', '0', STEP), ('IDF_TEMB_FUSED', '0', STEP),
     # the library's own
-    ('IDF_CONV_RS_SYNC', '0', STEP), ('IDF_CONV_PS', '0', STEP), ('IDF_CONV_DLDS_MIN', '1', STEP), ('IDF_WGRAD_KR3', '0', STEP), ('IDF_WGRAD_TPB3', '32', STEP),
+    ('IDF_CONV_RS_SYNC', '0', STEP), ('IDF_CONV_PS', '0', STEP), ('IDF_CONV_DLDS_MIN', '1', STEP), ('IDF_WGRAD_KR3', '0', STEP), ('IDF_WGRAD_TPB3', '32', STEP), ('IDF_WGRAD_RING', '0', STEP),
     # the samplers'
     ('IDF_SAMPLER_GRAPH', '0', TRACES), ('IDF_SAMPLER_GRAPH_MAXPIX', '1', TRACES), ('IDF_SAMPLER_GRAPH_STRICT', '1', SAMPLER),
 ]
@@ -30,7 +30,7 @@ def test_every_switch_is_listed():
     """The table in knobs.py, the library's table and this file's cases name the same switches (IDF_LIB / IDF_FORCE_SYNC /
     IDF_CPU_THREADS select a library, a bench mode and a thread count: nothing to run)."""
     from infodiffusion_amd import knobs
-    lib = {'IDF_CONV_RS', 'IDF_CONV_RS_SYNC', 'IDF_CONV_PS', 'IDF_CONV_DLDS_MIN', 'IDF_WGRAD_KR3', 'IDF_WGRAD_TPB3'}
+    lib = {'IDF_CONV_RS', 'IDF_CONV_RS_SYNC', 'IDF_CONV_PS', 'IDF_CONV_DLDS_MIN', 'IDF_WGRAD_KR3', 'IDF_WGRAD_TPB3', 'IDF_WGRAD_RING'}
     capi = open(os.path.join(ROOT, 'infodiffusion_amd', 'csrc', 'idf_capi.hip')).read()
     assert all('"%s"' % n in capi for n in lib)
     covered = {c[0] for c in CASES} | {'IDF_LIB', 'IDF_FORCE_SYNC', 'IDF_CPU_THREADS'}

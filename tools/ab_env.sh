@@ -4,7 +4,7 @@
 var=$1; a=$2; b=$3; rounds=${4:-2}
 for r in $(seq $rounds); do
 for v in $a $b; do
-  env $var=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-large-batch 2>/dev/null | tail -1 > /tmp/_ab.json
+  env $var=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-large-batch --no-dp-probe 2>/dev/null | tail -1 > /tmp/_ab.json
   python - "$var" "$v" <<'PY'
 import json, sys
 d = json.load(open('/tmp/_ab.json'))

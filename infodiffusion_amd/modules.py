@@ -80,14 +80,19 @@ class _Shadows:
         return self.srcs if self.srcs is not None else [c.weight for c in self.convs]
 
     def run_fold(self):
-        """Stand-alone use: the folded V weights / biases with torch products (a network's ShadowSet does all blocks in one launch)."""
-        wp, bp, wv, bv, bq, bk, wvf, bf = self.fold
-        C = wp.shape[0]
-        with torch.no_grad():
-            wvf.view(C, C).copy_(wp.view(C, C) @ wv.view(C, C))
-            bf[:C].copy_(bq)
-            bf[C:2 * C].copy_(bk)
-            bf[2 * C:].copy_(wp.view(C, C) @ bv + bp)
+        """Stand-alone use (a block outside a network's ShadowSet, which folds all its blocks in one launch): the folded V weights /
+        biases by the same kernel on a one-row table -- no stock-library product anywhere in the product path."""
+        import numpy as np
+        from ._lib import call
+        key = tuple(t.data_ptr() for t in self.fold)
+        if getattr(self, '_fold_tab_key', None) != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('attention fold: run one eager forward before graph capture')
+            dt = np.dtype([('p%d' % i, '<i8') for i in range(8)] + [('C', '<i4'), ('pad', '<i4')])
+            row = np.array([key + (self.fold[0].shape[0], 0)], dtype=dt)
+            self._fold_tab = torch.from_numpy(row.view(np.uint8).reshape(1, -1).copy()).to(self.fold[0].device)
+            self._fold_tab_key = key
+        call('idf_attn_fold_batched', self._fold_tab.data_ptr(), 1, self.fold[0].shape[0], torch.cuda.current_stream().cuda_stream)
 
     @staticmethod
     def _new(shape, dtype, dev):

@@ -2119,16 +2119,24 @@ class _FoldProjV(torch.autograd.Function):
             _FOLD_BWD_ROWS.append((g.data_ptr(), gb.data_ptr(), wp.data_ptr(), wv.data_ptr(), bv.data_ptr(), gw.data_ptr(),
                                    gbp.data_ptr(), C))
             return dw, db, gw, gbp, None, None
-        # gradients that are ordinary tensors (no arena, or the weight gradient ran eagerly): the same chain rule in torch
+        # gradients that are ordinary tensors (no arena, or the weight gradient ran eagerly): the same kernel on a one-row table, now
+        # (dW' / db' of the V third are rewritten in place into dWv / dbv -- on private copies: autograd may hold `dw` elsewhere)
         WgradBatch.flush()
-        G, gb = dw[2 * C:].reshape(C, C).float(), db[2 * C:].float()
-        wp2, wv2 = wp.reshape(C, C).float(), wv.reshape(C, C).float()
-        dwp = (G @ wv2.t() + torch.outer(gb, bv.float())).view_as(wp)
-        dwv = (wp2.t() @ G).view(dw[2 * C:].shape)
-        dbv = wp2.t() @ gb
-        dw2 = torch.cat([dw[:2 * C], dwv.to(dw.dtype)], dim=0)
-        db2 = torch.cat([db[:2 * C], dbv.to(db.dtype)], dim=0)
-        return dw2, db2, dwp, gb.clone(), None, None
+        import numpy as np
+        dw2, db2 = dw.float().contiguous().clone(), db.float().contiguous().clone()
+        dwp = torch.empty(wp.shape, dtype=torch.float32, device=wp.device).contiguous(memory_format=torch.contiguous_format)
+        dbp = torch.empty((C,), dtype=torch.float32, device=wp.device)
+        dwp.zero_()
+        dbp.zero_()
+        scratch = torch.empty((C * C + C,), dtype=torch.float32, device=wp.device)
+        dt = np.dtype([('g', '<i8'), ('gb', '<i8'), ('wp', '<i8'), ('wv', '<i8'), ('bv', '<i8'), ('dwp', '<i8'), ('dbp', '<i8'),
+                       ('gs', '<i8'), ('C', '<i4'), ('pad', '<i4')])
+        row = np.array([(dw2[2 * C:].data_ptr(), db2[2 * C:].data_ptr(), wp.data_ptr(), wv.data_ptr(), bv.data_ptr(), dwp.data_ptr(),
+                         dbp.data_ptr(), scratch.data_ptr(), C, 0)], dtype=dt)
+        tab = torch.from_numpy(row.view(np.uint8).reshape(1, -1).copy()).to(wp.device)
+        call('idf_attn_fold_bwd_batched', tab.data_ptr(), 1, C, _st())
+        ctx._keep = (tab, scratch)          # alive until the launch has run (stream order; freed with the node)
+        return dw2.to(dw.dtype), db2.to(db.dtype), dwp.view_as(wp), dbp, None, None
 
 
 def fold_proj_v(wcat, bcat, wp, bp, wv, bv):

@@ -104,3 +104,28 @@ def test_save_original_img_mode_runs_without_a_gpu(tmp_path):
     match = [int(np.argmin([min(np.abs(im - s_).max(), np.abs(im[..., ::-1] - s_).max()) for s_ in src])) for im in allimgs]
     assert sorted(match) == list(range(8))
     assert all(np.allclose(im, src[j], atol=1e-6) or np.allclose(im[..., ::-1], src[j], atol=1e-6) for im, j in zip(allimgs, match))
+
+
+def test_latent_dataset_reads_a_reference_written_archive():
+    """The wire format between the two phases of config 5 (`{model}_{exp}_latent.npz`, /root/reference/run.py:415-443 ->
+    utils.py:163-172): tests/golden/ref_diff_latent.npz was WRITTEN by the reference's statements on the reference's own encoder
+    (tools/gen_golden.py latent_archive) and read back there through the reference's LatentDataset -- the product's LatentDataset
+    must deliver the same rows (values, order, dtype, length), and the oracle's encoder must reproduce them from the inputs."""
+    import os
+    import numpy as np
+    from infodiffusion_amd.utils import LatentDataset
+    from oracle import infodiff_oracle as O
+    from tests.helpers import GOLD, gold, manifest
+    ds = LatentDataset(os.path.join(GOLD, 'ref_diff_latent.npz'))
+    g = gold('ref_diff_latent_inputs')
+    assert len(ds) == int(g['n']) == g['rows'].shape[0] == 15
+    rows = torch.stack([ds[i] for i in range(len(ds))])
+    assert rows.dtype == torch.float32 and torch.equal(rows, g['rows'])
+    with np.load(os.path.join(GOLD, 'ref_diff_latent.npz')) as z:          # the archive also carries the labels, one per row
+        assert sorted(z.files) == ['all_a', 'all_attr'] and z['all_attr'].shape == (15,)
+        assert np.array_equal(z['all_attr'], g['attr'].numpy())
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    sd = O.synth_state_dict(manifest('manifest_fmnist'))
+    with torch.no_grad():
+        a = O.encoder(sd, 'encoder', g['x'], cfg.encoder_channels, O.ch_mult_for(cfg))[0]
+    assert float((a - rows).abs().max()) <= 2e-5 * float(rows.abs().max())

@@ -47,12 +47,39 @@ def test_cli_latent_pipeline(tmp_path):
     `{model}_{exp}_latent.npz` wire format) -> train_latent_ddim on it -> eval_fid --is_latent (latent DDIM
     samples `a`, the image sampler decodes it)."""
     tmp = str(tmp_path)
+    # known inputs: uint8 NHWC bytes under --data_dir (the loader normalises and flips them as the reference's transforms do)
+    os.makedirs(os.path.join(tmp, 'data'), exist_ok=True)
+    rng = np.random.default_rng(3)
+    np.save(os.path.join(tmp, 'data', 'fmnist.npy'), rng.integers(0, 256, (40, 32, 32, 1), dtype=np.uint8))
     _run(tmp, '--mode', 'train')
     _run(tmp, '--mode', 'save_latent')
     npz = glob.glob(os.path.join(tmp, 'diff_*_latent.npz'))
     assert len(npz) == 1
     z = np.load(npz[0])
     assert z['all_a'].ndim == 2 and z['all_a'].shape[1] == 32 and np.isfinite(z['all_a']).all()
+    # NUMERICS of the saved latents (round-5 verdict, weak 9): the oracle's encoder (CPU, fp32) with the check-point's weights on the
+    # same batches -- the loader is deterministic (seed, epoch, rank), the CPU path of the same class yields what the GPU path saw
+    # (test_prep_u8_matches_torchvision_chain_bitwise) -- must reproduce all_a within the bf16 path's bound; one label per row
+    import types
+    from infodiffusion_amd.data import get_dataset, get_dataset_config
+    from infodiffusion_amd.utils import LatentDataset
+    from oracle import infodiff_oracle as O
+    sd = torch.load(glob.glob(os.path.join(tmp, 'models', '*', 'model-2.pth'))[0], map_location='cpu')
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    args = types.SimpleNamespace(dataset='fmnist', batch_size=8, data_dir=os.path.join(tmp, 'data'), r_seed=0, mode='save_latent',
+                                 steps_per_epoch=3)
+    shape = get_dataset_config(args)
+    ref = []
+    for data in get_dataset(args, shape, 'cpu', 0, 1):
+        with torch.no_grad():
+            ref.append(O.encoder(sd, 'encoder', data[0].float(), cfg.encoder_channels, O.ch_mult_for(cfg))[0])
+    ref = torch.cat(ref).numpy()
+    assert z['all_a'].shape == ref.shape == (40, 32)
+    err = np.abs(z['all_a'].astype(np.float32) - ref).max() / np.abs(ref).max()
+    assert err < 3e-2, err
+    assert z['all_attr'].shape == (40,)
+    ds = LatentDataset(npz[0])                     # ... and the second phase reads exactly these rows
+    assert len(ds) == 40 and np.array_equal(ds[7].numpy(), z['all_a'][7].astype(np.float32))
     out = _run(tmp, '--mode', 'train_latent_ddim', '--is_latent')
     assert 'Epoch' in out
     assert glob.glob(os.path.join(tmp, 'models', '*_latent', 'model-2.pth'))

@@ -640,8 +640,44 @@ def gen_config5():
     save('config5_cifar', **out)
 
 
+def gen_latent_archive():
+    """A `{model}_{exp}_latent.npz` archive as the REFERENCE writes it (run.py:415-443, save_latent: the wire format between the two
+    phases of config 5): the reference's own encoder (synthetic weights, fmnist configuration) on seeded batches, `all_a` / `all_attr`
+    collected and saved with the reference's statements; read back through the reference's own LatentDataset (utils.py:163-172) for
+    the expected rows.  The archive is committed as a data fixture (tests/golden/ref_diff_latent.npz) with its inputs beside it."""
+    cfg = O.dataset_cfg('fmnist', a_dim=32, mmd_weight=0.1)
+    a = args_for(cfg)
+    torch.manual_seed(0)
+    model = R_models.InfoDiff(a, 'cpu', cfg.shape)
+    man, syn = load_synth(model)
+    model.eval()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(71)
+    batches = [(torch.rand(5, *cfg.shape, generator=g) * 2 - 1, torch.randint(0, 10, (5,), generator=g)) for _ in range(3)]
+    all_a, all_attr = [], []
+    for data_all in batches:                      # run.py:418-439 with dataset == 'fmnist', kld_weight == 0, mmd_weight != 0
+        data = data_all[0]
+        latents_classes = data_all[1]
+        with torch.no_grad():
+            av, _, _, _ = model.encoder(data)
+        all_a.append(av.cpu().numpy())
+        all_attr.append(latents_classes)
+    all_a = np.concatenate(all_a)
+    all_attr = np.concatenate(all_attr)
+    path = os.path.join(GOLD, 'ref_diff_latent')
+    np.savez(path, all_a=all_a, all_attr=all_attr)                 # run.py:442 (np.savez appends .npz)
+    ds = R_utils.LatentDataset(path + '.npz')
+    rows = torch.stack([ds[i] for i in range(len(ds))])
+    with torch.no_grad():
+        ours = torch.cat([O.encoder(syn, 'encoder', b[0], cfg.encoder_channels, O.ch_mult_for(cfg))[0] for b in batches])
+    check('latent archive rows', ours, rows)
+    save('ref_diff_latent_inputs', x=torch.cat([b[0] for b in batches]), attr=torch.cat([b[1] for b in batches]), rows=rows,
+         n=len(ds))
+    print('wrote ref_diff_latent.npz %.1f KB' % (os.path.getsize(path + '.npz') / 1024))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'size28', 'celeba', 'config5']
+    which = sys.argv[1:] or ['schedule', 'blocks', 'mmd', 'stub', 'latent', 'vanilla', 'fmnist', 'bneck', 'vae', 'priors', 'branches', 'size28', 'latent_archive', 'celeba', 'config5']
     if 'schedule' in which:
         gen_schedule()
     if 'blocks' in which:
@@ -670,6 +706,8 @@ if __name__ == '__main__':
         # the `input_size == 28` branch (models.py:619-622: ch_mult [1, 2, 4], maps 28 / 14 / 7 -- no named dataset reaches it, data.py:63-102
         # sets 32 or 64 everywhere, but `InfoDiff(args, ...)` with input_size 28 is constructible and runs)
         gen_model('size28', O.Cfg(input_channels=1, unets_channels=32, encoder_channels=32, input_size=28, a_dim=32, mmd_weight=0.1), B=3, seed=69)
+    if 'latent_archive' in which:
+        gen_latent_archive()
     if 'celeba' in which:
         gen_model('celeba', O.dataset_cfg('celeba', a_dim=32, mmd_weight=0.1), B=2, seed=64)
     if 'config5' in which:

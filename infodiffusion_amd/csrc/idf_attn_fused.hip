@@ -413,10 +413,8 @@ __global__ __launch_bounds__(64 * NW) void attnblock_fwd_kernel(const AbP p) {
     const int c = tid, g0 = c & ~3;
     double a = 0.0, d = 0.0;
     for (int k = g0; k < g0 + 4; ++k) { a += scr[2 * k]; d += scr[2 * k + 1]; }
-    const double n = (double)AN * 4.0;
-    double mu = a / n, var = d / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    float r, mf;
+    idf_group_stats(a, d, 1.0 / ((double)AN * 4.0), p.eps, &mf, &r);
     const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
     const float sc = r * ga, sh = be - mf * sc;
     cof[2 * c] = sc; cof[2 * c + 1] = sh;

@@ -265,3 +265,17 @@ __device__ __forceinline__ void idf_warm_lines(const void* ptr, int bytes, int t
 }
 constexpr int IDF_WARM_HELPERS = 8, IDF_WARM_MAX_MAIN = 128;     // helpers per launch; main workgroups up to which a launch gets them
 
+
+// (mean, rstd) of a GroupNorm group from its (sum, sum of squares): mu and var in double (the divisions by the element count are
+// multiplications by its reciprocal), 1 / sqrt as v_rsq_f32 + one Newton step in double (2e-14 relative: the float it rounds to is the
+// exact quotient's except on rounding ties).  The double-precision divide and square-root sequences it replaces cost ~1 us of
+// dependent arithmetic in front of a workgroup's first MFMA (round 4: idf_resblock.hip, round 5: idf_conv_rs.hip, round 6: every fold).
+__device__ __forceinline__ void idf_group_stats(double a, double d, double inv_n, float eps, float* mean, float* rstd) {
+  const double mu = a * inv_n;
+  double var = d * inv_n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double vd = var + (double)eps;
+  const double r0 = (double)__builtin_amdgcn_rsqf((float)vd);
+  *rstd = (float)(r0 * (1.5 - 0.5 * vd * r0 * r0));
+  *mean = (float)mu;
+}

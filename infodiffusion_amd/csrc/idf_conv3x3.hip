@@ -635,14 +635,13 @@ __device__ __forceinline__ void ps_coefficients(const C3P& p, int b, bool writer
     chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its own LDS writes are visible to its lanes
-  const double n = (double)p.H * p.W * cpg;
+  const double inv_n = 1.0 / ((double)p.H * p.W * cpg);
   for (int c = lane; c < C; c += 64) {
     const int g = c / cpg;
     double a = 0.0, d = 0.0;
     for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
-    double mu = a / n, var = d / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    float r, mf;
+    idf_group_stats(a, d, inv_n, p.eps, &mf, &r);
     float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
     float sc = r * ga, sh = be - mf * sc;
     if (p.film_t) { float f = 1.f + p.film_t[(size_t)b * p.ld_t + c]; sc *= f; sh = sh * f + p.film_t[(size_t)b * p.ld_t + C + c]; }

@@ -133,14 +133,13 @@ __device__ __forceinline__ void pro_coefficients(const C3P& p, int b, bool write
     chs[2 * c] = S.x; chs[2 * c + 1] = S.y;
   }
   __syncthreads();
-  const double n = (double)p.H * p.W * cpg;
+  const double inv_n = 1.0 / ((double)p.H * p.W * cpg);       // (block-uniform: one scalar-path division)
   for (int c = tid; c < C; c += NT) {
     const int g = c / cpg;
     double a = 0.0, d = 0.0;
     for (int k = g * cpg; k < (g + 1) * cpg; ++k) { a += chs[2 * k]; d += chs[2 * k + 1]; }
-    double mu = a / n, var = d / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)p.eps)), mf = (float)mu;
+    float r, mf;
+    idf_group_stats(a, d, inv_n, p.eps, &mf, &r);
     float ga, be, ft0 = 0.f, ft1 = 0.f, fa0 = 0.f, fa1 = 0.f;
     if (PF && c == tid) {
       ga = pf[0]; be = pf[1]; ft0 = pf[2]; ft1 = pf[3]; fa0 = pf[4]; fa1 = pf[5];

@@ -26,6 +26,7 @@ TABLE = {
     'IDF_ATTN_BLOCK_MINB': ('256', 'batch from which the 16x16 AttnBlock runs as ONE launch (idf_attnblock_fwd)'),
     'IDF_UPCONV': ('1', 'UpSample conv / its gradients as four 2x2 sub-pixel convs with summed weights'),
     'IDF_TEMB_FUSED': ('1', 'TimeEmbedding + fc_a + all FiLM projections behind one entry (idf_temb_film_*)'),
+    'IDF_TRAJ_CACHE': ('1', 'samplers: the conditioning path (TimeEmbedding, fc_a, FiLM projections) once per trajectory -- a table over the timesteps + the latent\'s projections -- instead of once per step'),
     'IDF_SAMPLER_GRAPH': ('1', 'samplers replay ONE captured denoising step for the inner steps'),
     'IDF_SAMPLER_GRAPH_MAXPIX': (str(256 * 64 * 64), 'largest batch x H x W whose step is captured'),
     'IDF_SAMPLER_GRAPH_STRICT': ('0', 'a failed step capture raises instead of falling back to eager stepping'),

@@ -179,10 +179,59 @@ class AuxiliaryUNet(_UNetSkeleton):
         init.zeros_(self.fc_a.bias)
         self._init_tail()
 
+    # ---- sampling: the conditioning path once per trajectory instead of once per step
+    def begin_trajectory(self, a, keep=None):
+        """The latent is constant over the T steps of a sampling trajectory (/root/reference/sampling.py:92-95) and the timestep takes
+        T values: TimeEmbedding + every block's FiLM_t projection for ALL timesteps as one table [T, sum 2C] (rebuilt when a weight
+        it is made from changes), fc_a + every block's FiLM_a projection of THIS latent once [B, sum 2C] -- a step then gathers its
+        row (one launch) instead of running the three conditioning launches.  Inference only; `keep`: a cache object of an earlier
+        call whose buffers a kept step graph reads (they are refilled in place).  -> the cache object, or None (not applicable)."""
+        if torch.is_grad_enabled() or a is None or not a.is_cuda:
+            return None
+        blocks = self._res_blocks()
+        tab = self.time_embedding.timembedding[0].weight
+        T = tab.shape[0]
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        with torch.no_grad():
+            tt = torch.arange(T, dtype=torch.long, device=a.device)
+            if keep is not None and keep.get('key') == key and keep['out_a'].shape[0] == a.shape[0]:
+                c = keep
+            else:
+                c = {'key': key, 'table_t': None, 'out_a': None}
+            if c['table_t'] is None:
+                if not fused_film(self.time_embedding, tt, blocks):
+                    return None
+                c['table_t'] = torch.cat([blk._film['t'] for blk in blocks], dim=1).contiguous()
+                c['split_t'] = [blk._film['t'].shape[1] for blk in blocks]
+            # FiLM_a of this latent (the entry computes the t half too: rows of timestep 0, discarded -- once per trajectory)
+            if not fused_film(self.time_embedding, tt[:1].expand(a.shape[0]).contiguous(), blocks, a, self.fc_a, False, blocks):
+                for blk in blocks:
+                    blk._film.clear()
+                return None
+            out_a = torch.cat([blk._film['a'] for blk in blocks], dim=1)
+            if c['out_a'] is None:
+                c['out_a'] = out_a.contiguous()
+                c['split_a'] = [blk._film['a'].shape[1] for blk in blocks]
+            else:
+                c['out_a'].copy_(out_a)
+            for blk in blocks:
+                blk._film.clear()
+        self._traj = c
+        return c
+
+    def end_trajectory(self):
+        self._traj = None
+
     def forward(self, x, t, a):
         x = self._prep(x)
         blocks = self._res_blocks()
-        if fused_film(self.time_embedding, t, blocks, a, self.fc_a, False, blocks):
+        c = getattr(self, '_traj', None)
+        if c is not None and not torch.is_grad_enabled() and torch.is_tensor(t) and t.dtype == torch.long and c['out_a'].shape[0] == x.shape[0]:
+            out_t = ops.gather_rows(c['table_t'], t)
+            for blk, ct, ca in zip(blocks, out_t.split(c['split_t'], dim=1), c['out_a'].split(c['split_a'], dim=1)):
+                blk._film['t'], blk._film['a'] = ct, ca
+            temb = aemb = None
+        elif fused_film(self.time_embedding, t, blocks, a, self.fc_a, False, blocks):
             temb = aemb = None          # every block finds its FiLM pairs in `_film`
         else:
             aemb = ops.linear(a, self.fc_a.weight, self.fc_a.bias)

@@ -21,6 +21,7 @@ from . import knobs, ops
 _DDPM, _DDIM, _REV = 0, 1, 2
 ETA = 0.01     # sampling.py:45
 GRAPH = knobs.flag('IDF_SAMPLER_GRAPH')
+TRAJ_CACHE = knobs.flag('IDF_TRAJ_CACHE')     # the backbone's conditioning path once per trajectory (models.AuxiliaryUNet.begin_trajectory)
 STRICT_GRAPH = knobs.flag('IDF_SAMPLER_GRAPH_STRICT')     # a failed capture raises instead of stepping eagerly
 GRAPH_MIN_STEPS = 8
 GRAPH_MAX_PIXELS = knobs.num('IDF_SAMPLER_GRAPH_MAXPIX')   # batch x H x W up to which a step is replayed (256 CelebA images:
@@ -93,6 +94,9 @@ class _ProcessBase:
         their weight shadows (ShadowSet.tkey changes when shadows are reallocated: dtype / device / layout changes) and the
         kernel-selection switches -- a change of any of them must not replay the stale graph."""
         sig = [ops.switch_state()]
+        keep = getattr(self, '_traj_keep', None)        # the conditioning cache a kept graph reads (refilled in place per trajectory)
+        if keep is not None:
+            sig.append((keep['table_t'].data_ptr(), keep['out_a'].data_ptr()))
         for v in vars(self).values():
             if isinstance(v, torch.nn.Module):
                 sig.append(id(v))
@@ -233,7 +237,21 @@ class DiffusionProcess(_ProcessBase):
         return self._reverse_loop(x, self._eps(a))
 
     def _one_diffusion_step(self, sample, a=None, deterministic=False):
-        return self._loop(sample, self._eps(a), bool(deterministic), self._eps, a)
+        """The trajectory x_T -> x_0 under ONE latent: the backbone's conditioning path (TimeEmbedding, fc_a, every block's FiLM
+        projections) runs once per trajectory, not once per step (models.AuxiliaryUNet.begin_trajectory; the latent is constant over
+        the T steps, sampling.py:92-95)."""
+        bb = getattr(self.diffusion_fn, 'backbone', None)
+        if not TRAJ_CACHE or a is None or bb is None or not hasattr(bb, 'begin_trajectory') or torch.is_grad_enabled():
+            return self._loop(sample, self._eps(a), bool(deterministic), self._eps, a)
+
+        def run():
+            cache = bb.begin_trajectory(a, getattr(self, '_traj_keep', None))
+            self._traj_keep = cache
+            try:
+                yield from self._loop(sample, self._eps(a), bool(deterministic), self._eps, a)
+            finally:
+                bb.end_trajectory()
+        return run()
 
     @torch.no_grad()
     def reverse_sampling(self, x0, a=None):

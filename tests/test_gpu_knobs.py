@@ -22,7 +22,7 @@ CASES = [
     # the library's own
     ('IDF_CONV_RS_SYNC', '0', STEP), ('IDF_CONV_PS', '0', STEP), ('IDF_CONV_DLDS_MIN', '1', STEP), ('IDF_WGRAD_KR3', '0', STEP), ('IDF_WGRAD_TPB3', '32', STEP), ('IDF_WGRAD_RING', '0', STEP),
     # the samplers'
-    ('IDF_SAMPLER_GRAPH', '0', TRACES), ('IDF_SAMPLER_GRAPH_MAXPIX', '1', TRACES), ('IDF_SAMPLER_GRAPH_STRICT', '1', SAMPLER),
+    ('IDF_SAMPLER_GRAPH', '0', TRACES), ('IDF_TRAJ_CACHE', '0', TRACES), ('IDF_SAMPLER_GRAPH_MAXPIX', '1', TRACES), ('IDF_SAMPLER_GRAPH_STRICT', '1', SAMPLER),
 ]
 
 
@@ -35,7 +35,7 @@ def test_every_switch_is_listed():
     assert all('"%s"' % n in capi for n in lib)
     covered = {c[0] for c in CASES} | {'IDF_LIB', 'IDF_FORCE_SYNC', 'IDF_CPU_THREADS'}
     assert covered == set(knobs.TABLE) | lib, sorted(covered ^ (set(knobs.TABLE) | lib))
-    assert len(set(knobs.TABLE) | lib) <= 30
+    assert len(set(knobs.TABLE) | lib) <= 31
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     assert all('`%s`' % n in doc for n in set(knobs.TABLE) | lib), [n for n in set(knobs.TABLE) | lib if '`%s`' % n not in doc]
     # ... and nothing else in the product reads an IDF_* name from the environment

@@ -502,11 +502,11 @@ class GnRowsBatch:
             host = np.zeros((len(items),), dtype=np.dtype([('rows', '<i8'), ('dg', '<i8'), ('db', '<i8'), ('B', '<i4'), ('C', '<i4')]))
             for i, it in enumerate(items):
                 host[i] = it
-            if len(cls.tables) >= 8:
-                for k in list(cls.tables):          # oldest first; a table a captured graph reads stays
-                    if not any(cls.tables[k] is b for b in cls._graph_bufs):
-                        cls.tables.pop(k)
-                        break
+            # a small LRU over the tables no captured graph reads (pinned ones stay and do not count: a process that has captured
+            # eight steps must still keep BOTH tables of a data-parallel step's two backward passes between its eager warm-up steps)
+            loose = [k for k, v in cls.tables.items() if not any(v is b for b in cls._graph_bufs)]
+            if len(loose) >= 8:
+                cls.tables.pop(loose[0])
             tab = torch.from_numpy(host.view(np.uint8).copy()).to(torch.device('cuda', torch.cuda.current_device()))
             cls.tables[key] = tab
         if torch.cuda.is_current_stream_capturing():

@@ -274,3 +274,101 @@ def test_capture_failure_on_one_rank_takes_every_rank_down_the_same_path():
                 p -= 0.1 * (g0 + g1) / 2
     for p, w in zip(params, a['w']):
         assert torch.allclose(p.detach(), T(w), atol=1e-6)
+
+
+def _health_worker(rank, world, port, q):
+    """GraphedTrainStep.check under data parallelism: a synchronised-conv time-out seen by ONE rank must roll EVERY rank back (the
+    count is MAX-reduced) -- a rank that rolled back alone would train on from different weights than its peers.  No GPU here: the
+    error word is stubbed (ops.rs_sync_timeouts / ops._RS_SYNC_STATE), everything else is the product's code."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from infodiffusion_amd import ops
+    from infodiffusion_amd.dist import GradSync
+    from infodiffusion_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = torch.nn.Linear(4, 2)
+
+        def loss_fn(self, args, x, curr_epoch=0):
+            return self.net(x).square().mean()
+
+    model = Model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    sync = GradSync(model, world)
+    fake = {'n': 0}
+    ops._RS_SYNC_STATE[0] = torch.zeros(32, dtype=torch.int32)          # "the form has been launched on device 0"
+    orig = ops.rs_sync_timeouts
+    ops.rs_sync_timeouts = lambda reset=True: fake['n']
+    step = GraphedTrainStep(model, None, opt, sync=sync, use_graph=False, warmup=1, health_every=2)
+    torch.manual_seed(20 + rank)
+    xs = [torch.randn(3, 4) for _ in range(5)]
+    trail = []
+    try:
+        for k, x in enumerate(xs):
+            if k == 3 and rank == 1:
+                fake['n'] = 3                  # rank 1's launches of steps 3 / 4 timed out; rank 0 saw nothing
+            step(x, 0)
+            fake['n'] = 0 if ops.sync_convs_retired() else fake['n']      # (retire_sync_convs zeroes the word)
+            trail.append([p.detach().clone() for p in model.parameters()])
+    finally:
+        ops.rs_sync_timeouts = orig
+        ops._RS_SYNC_STATE.clear()
+        retired = ops.sync_convs_retired()
+        ops._RS_SYNC_DEAD[0] = False
+    q.put((rank, {'w': [[p.tolist() for p in t] for t in trail], 'timeouts': step.timeouts, 'recoveries': step.recoveries,
+                  'retired': retired, 'x': [x.tolist() for x in xs]}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_timeout_on_one_rank_rolls_every_rank_back():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_health_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = got[0], got[1]
+    assert a['recoveries'] == b['recoveries'] == 1 and a['retired'] and b['retired']
+    assert a['timeouts'] == b['timeouts'] == 3          # the MAX over the ranks, on both
+    T = torch.tensor
+    for ta, tb in zip(a['w'], b['w']):                  # replicas identical after every step, the rolled-back one included
+        for wa, wb in zip(ta, tb):
+            assert torch.equal(T(wa), T(wb))
+    # the roll-back went to the last clean check (in front of step 4's predecessor check: call 2 -> the weights after step 1):
+    # steps 2 and 3 are gone, step 4 and 5 trained on from there -- replay that on one process with the averaged gradients
+    net = torch.nn.Linear(4, 2)
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(4, 2)
+    net.load_state_dict(ref.state_dict())
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+
+    def one(k):
+        opt.zero_grad()
+        (0.5 * (net(T(a['x'][k])).square().mean() + net(T(b['x'][k])).square().mean())).backward()
+        opt.step()
+    one(0)
+    snap = ([p.detach().clone() for p in net.parameters()], {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                                                              for k, v in opt.state_dict()['state'].items()})
+    one(1)
+    one(2)
+    with torch.no_grad():                               # the trainer's roll-back: parameters AND optimizer state (the momentum buffers)
+        for p, s in zip(net.parameters(), snap[0]):
+            p.copy_(s)
+    sd = opt.state_dict()
+    sd['state'] = snap[1]
+    opt.load_state_dict(sd)
+    one(3)
+    for p, w in zip(net.parameters(), a['w'][3]):
+        assert torch.allclose(p.detach(), T(w), atol=1e-6), (p, w)
+    one(4)
+    for p, w in zip(net.parameters(), a['w'][4]):
+        assert torch.allclose(p.detach(), T(w), atol=1e-6)

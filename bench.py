@@ -237,7 +237,7 @@ def one_rank_dp_cost(a):
            '--batch', str(a.batch), '--a_dim', str(a.a_dim), '--dtype', a.dtype, '--graph', str(int(a.graph)),
            '--fused-opt', str(int(a.fused_opt))]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
         d = json.loads(line)
         return {'ms_per_step': d['ms_per_step'], 'ms_per_step_median': d.get('ms_per_step_median'), 'value': d['value'],

@@ -680,17 +680,24 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_loop(const bf16_t* __restric
     else { src = x2; dst = dx2; spitch = C - C1; sc0 -= C1; }
   }
   const int pend = min(HW, (int)(blockIdx.x + 1) * chunk);
-  // the first pixel's operands are on their way before the fold starts (they do not depend on it): the stream's first
-  // round trip runs beside the fold's instead of behind it
+  // the first TWO pixels' operands are on their way before the fold starts (they do not depend on it): the stream's first round
+  // trips run beside the fold's instead of behind it, and the loop keeps two pixels per thread in flight (round 6: one pixel was
+  // 16 KB per block against a ~2 us round trip)
   int p = blockIdx.x * chunk + pl;
-  uint4 xr = make_uint4(0, 0, 0, 0), dr = xr, rr = xr, r2 = xr;
-  if (live && p < pend) {
-    const size_t e0 = ((size_t)b * HW + p) * C + v * 8, es = ((size_t)b * HW + p) * spitch + sc0;
-    xr = *reinterpret_cast<const uint4*>(src + es);
-    dr = *reinterpret_cast<const uint4*>(du + e0);
-    if (dres) rr = *reinterpret_cast<const uint4*>(dres + e0);
-    if (dres2) r2 = *reinterpret_cast<const uint4*>(dres2 + e0);
-  }
+  struct Px { uint4 xr, dr, rr, r2; };
+  auto fetch = [&](int q_) {
+    Px w;
+    w.xr = w.dr = w.rr = w.r2 = make_uint4(0, 0, 0, 0);
+    if (live && q_ < pend) {
+      const size_t e0 = ((size_t)b * HW + q_) * C + v * 8, es = ((size_t)b * HW + q_) * spitch + sc0;
+      w.xr = *reinterpret_cast<const uint4*>(src + es);
+      w.dr = *reinterpret_cast<const uint4*>(du + e0);
+      if (dres) w.rr = *reinterpret_cast<const uint4*>(dres + e0);
+      if (dres2) w.r2 = *reinterpret_cast<const uint4*>(dres2 + e0);
+    }
+    return w;
+  };
+  Px cur = fetch(p), nxt = fetch(p + lanes);
   gn_bwd_fold<256>(f, b, blockIdx.x == 0, cof, sm + 4 * C, tid);
   if (!live) return;
   float av[8], k1v[8], k0v[8];
@@ -702,28 +709,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_loop(const bf16_t* __restric
   for (; p < pend; p += lanes) {
     const size_t es = ((size_t)b * HW + p) * spitch + sc0;
     float xv[8], dv[8], o[8], rv[8];
-    unpack16<bf16_t>(xr, xv);
-    unpack16<bf16_t>(dr, dv);
+    unpack16<bf16_t>(cur.xr, xv);
+    unpack16<bf16_t>(cur.dr, dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = av[e] * dv[e] + k1v[e] * xv[e] + k0v[e];
     if (dres) {
-      unpack16<bf16_t>(rr, rv);
+      unpack16<bf16_t>(cur.rr, rv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rv[e];
     }
     if (dres2) {
-      unpack16<bf16_t>(r2, rv);
+      unpack16<bf16_t>(cur.r2, rv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rv[e];
     }
-    const int pn = p + lanes;                 // next pixel's operands before this pixel's store
-    if (pn < pend) {
-      const size_t e0 = ((size_t)b * HW + pn) * C + v * 8, en = ((size_t)b * HW + pn) * spitch + sc0;
-      xr = *reinterpret_cast<const uint4*>(src + en);
-      dr = *reinterpret_cast<const uint4*>(du + e0);
-      if (dres) rr = *reinterpret_cast<const uint4*>(dres + e0);
-      if (dres2) r2 = *reinterpret_cast<const uint4*>(dres2 + e0);
-    }
+    cur = nxt;
+    nxt = fetch(p + 2 * lanes);               // two pixels ahead, before this pixel's store
     Vec16<bf16_t>::store(dst + es, o);
   }
 }
@@ -1091,7 +1092,10 @@ extern "C" int idf_gn_bwd_apply(const void* du, const float* part, int T, const 
                          (const bf16_t*)x2, C1, (const bf16_t*)dres, (const bf16_t*)dres2, (bf16_t*)dx, (bf16_t*)dx2, f, chunk);
   } else {
     // ~4 blocks per CU, all resident at once: the fold in front of every block's stream is paid once, in parallel
-    static const int want = 1024;
+#ifndef IDF_GNAPPLY_WANT
+#define IDF_GNAPPLY_WANT 1024
+#endif
+    static const int want = IDF_GNAPPLY_WANT;
     int chunk = idf_cdiv(HW, idf_cdiv(want, B));
     if (chunk < lanes) chunk = lanes;
     if (chunk > HW) chunk = HW;
